@@ -1,0 +1,259 @@
+"""Deterministic synthetic weights and inputs for the deep front-end.
+
+No pretrained weights exist offline (``scripts/download_model_weights.sh:6-21`` fetches them with
+wget), so parity work and benchmarks use seeded synthetic ``state_dict``s that follow the tensor names and shapes of
+the reference checkpoints:
+
+* SuperPoint  -- ``thirdparty/SuperGluePretrainedNetwork/models/superpoint.py:117-134``
+* SuperGlue   -- ``thirdparty/SuperGluePretrainedNetwork/models/superglue.py:49-60,92-138,205-220``
+* LightGlue   -- upstream ``cvg/LightGlue`` ``lightglue/lightglue.py`` module names (source absent from the
+  reference tree)
+
+The raw Kaiming-uniform initialisation gives degenerate outputs (one keypoint per 8x8 cell, zero matches), so a few
+tensors are rescaled to obtain realistic keypoint counts and non-trivial match lists. The same blob is fed to the
+oracle and to the HIP path.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+StateDict = Dict[str, torch.Tensor]
+
+
+def _conv_init(gen: torch.Generator, cout: int, cin: int, k: int, nd: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Kaiming-uniform(a=sqrt(5)) weight and matching bias, as torch.nn.ConvNd constructs them."""
+    fan_in = cin * k**nd
+    bound = 1.0 / math.sqrt(fan_in)
+    shape = (cout, cin) + (k,) * nd
+    w = (torch.rand(shape, generator=gen) * 2 - 1) * bound
+    b = (torch.rand((cout,), generator=gen) * 2 - 1) * bound
+    return w, b
+
+
+def _linear_init(gen: torch.Generator, cout: int, cin: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    bound = 1.0 / math.sqrt(cin)
+    w = (torch.rand((cout, cin), generator=gen) * 2 - 1) * bound
+    b = (torch.rand((cout,), generator=gen) * 2 - 1) * bound
+    return w, b
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# SuperPoint
+# ----------------------------------------------------------------------------------------------------------------
+
+SUPERPOINT_LAYERS = (
+    # name, cin, cout, kernel
+    ("conv1a", 1, 64, 3),
+    ("conv1b", 64, 64, 3),
+    ("conv2a", 64, 64, 3),
+    ("conv2b", 64, 64, 3),
+    ("conv3a", 64, 128, 3),
+    ("conv3b", 128, 128, 3),
+    ("conv4a", 128, 128, 3),
+    ("conv4b", 128, 128, 3),
+    ("convPa", 128, 256, 3),
+    ("convPb", 256, 65, 1),
+    ("convDa", 128, 256, 3),
+    ("convDb", 256, 256, 1),
+)
+
+
+def synthetic_superpoint_state_dict(seed: int = 1234, logit_gain: float = 12.0, dustbin_bias: float = 11.5) -> StateDict:
+    """Seeded SuperPoint weights (24 tensors, 1 300 865 parameters).
+
+    ``sqrt(2)``-scaled encoder weights keep ReLU activations O(1) through the 8-layer stack; ``logit_gain`` widens the
+    65-way detector logits and ``dustbin_bias`` raises the "no keypoint" channel so that only a few percent of the
+    pixels clear the 0.005 threshold, as with trained weights.
+    """
+    gen = torch.Generator().manual_seed(seed)
+    sd: StateDict = {}
+    for name, cin, cout, k in SUPERPOINT_LAYERS:
+        w, b = _conv_init(gen, cout, cin, k, 2)
+        if name not in ("convPb", "convDb"):
+            w = w * math.sqrt(6.0)  # variance-preserving for ReLU: Var(w) = 2 / fan_in
+        sd[f"{name}.weight"] = w
+        sd[f"{name}.bias"] = b
+    sd["convPb.weight"] = sd["convPb.weight"] * logit_gain
+    bias = sd["convPb.bias"].clone()
+    bias[64] += dustbin_bias
+    sd["convPb.bias"] = bias
+    return {k: v.contiguous() for k, v in sd.items()}
+
+
+def synthetic_gray_image(height: int, width: int, seed: int = 0, blur: int = 3) -> np.ndarray:
+    """Seeded low-pass-filtered uint8 noise: box blur of uniform noise,
+    contrast-stretched back to the full 8-bit range."""
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, size=(height + 2 * blur, width + 2 * blur)).astype(np.float64)
+    if blur > 0:
+        k = 2 * blur + 1
+        c = np.cumsum(np.pad(img, ((1, 0), (0, 0))), axis=0)
+        img = (c[k:, :] - c[:-k, :]) / k
+        c = np.cumsum(np.pad(img, ((0, 0), (1, 0))), axis=1)
+        img = (c[:, k:] - c[:, :-k]) / k
+    else:
+        img = img[:height, :width]
+    img = img[:height, :width]
+    lo, hi = img.min(), img.max()
+    img = (img - lo) / max(hi - lo, 1e-9) * 255.0
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# SuperGlue
+# ----------------------------------------------------------------------------------------------------------------
+
+
+def _bn_init(gen: torch.Generator, c: int, prefix: str, sd: StateDict) -> None:
+    """Non-trivial eval-mode BatchNorm1d statistics (SURVEY.md section 8c caveat 2)."""
+    sd[f"{prefix}.weight"] = 1.0 + 0.2 * (torch.rand((c,), generator=gen) - 0.5)
+    sd[f"{prefix}.bias"] = 0.2 * (torch.rand((c,), generator=gen) - 0.5)
+    sd[f"{prefix}.running_mean"] = 0.2 * (torch.rand((c,), generator=gen) - 0.5)
+    sd[f"{prefix}.running_var"] = 0.5 + torch.rand((c,), generator=gen)
+    sd[f"{prefix}.num_batches_tracked"] = torch.tensor(1000, dtype=torch.long)
+
+
+def synthetic_superglue_state_dict(
+    seed: int = 4321, num_layers: int = 18, delta_gain: float = 0.25, final_gain: float = 24.0
+) -> StateDict:
+    """Seeded SuperGlue weights (12 023 297 parameters for 18 layers).
+
+    ``delta_gain`` shrinks the last MLP layer of every propagation block so the residual stream stays dominated by
+    the input descriptors; ``final_gain`` scales ``final_proj`` so matched descriptors reach a score that survives the
+    Sinkhorn dustbin (with raw init every keypoint goes to the dustbin).
+    """
+    gen = torch.Generator().manual_seed(seed)
+    sd: StateDict = {}
+    chans = [3, 32, 64, 128, 256, 256]
+    for i in range(1, len(chans)):
+        w, b = _conv_init(gen, chans[i], chans[i - 1], 1, 1)
+        idx = 3 * (i - 1)
+        sd[f"kenc.encoder.{idx}.weight"] = w * (math.sqrt(3.0) if i < len(chans) - 1 else 0.5)
+        sd[f"kenc.encoder.{idx}.bias"] = b if i < len(chans) - 1 else torch.zeros_like(b)
+        if i < len(chans) - 1:
+            _bn_init(gen, chans[i], f"kenc.encoder.{idx + 1}", sd)
+    for l in range(num_layers):
+        p = f"gnn.layers.{l}"
+        w, b = _conv_init(gen, 256, 256, 1, 1)
+        sd[f"{p}.attn.merge.weight"], sd[f"{p}.attn.merge.bias"] = w * 1.5, b
+        for j in range(3):
+            w, b = _conv_init(gen, 256, 256, 1, 1)
+            # q/k gain makes the softmax non-uniform so that attention is a non-trivial function of the inputs
+            sd[f"{p}.attn.proj.{j}.weight"] = w * (6.0 if j < 2 else 1.5)
+            sd[f"{p}.attn.proj.{j}.bias"] = b
+        w, b = _conv_init(gen, 512, 512, 1, 1)
+        sd[f"{p}.mlp.0.weight"], sd[f"{p}.mlp.0.bias"] = w * math.sqrt(3.0), b
+        _bn_init(gen, 512, f"{p}.mlp.1", sd)
+        w, b = _conv_init(gen, 256, 512, 1, 1)
+        sd[f"{p}.mlp.3.weight"], sd[f"{p}.mlp.3.bias"] = w * delta_gain, torch.zeros_like(b)
+    w, b = _conv_init(gen, 256, 256, 1, 1)
+    sd["final_proj.weight"], sd["final_proj.bias"] = w * final_gain, b
+    sd["bin_score"] = torch.tensor(1.0)
+    return {k: v.contiguous() for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# LightGlue
+# ----------------------------------------------------------------------------------------------------------------
+
+
+def synthetic_lightglue_state_dict(
+    seed: int = 9876,
+    num_layers: int = 9,
+    delta_gain: float = 0.25,
+    final_gain: float = 16.0,
+    conf_bias: float = 0.0,
+    conf_gain: float = 1.0,
+    match_bias: float = 2.0,
+    match_gain: float = 4.0,
+) -> StateDict:
+    """Seeded LightGlue(features="superpoint") weights, upstream module names.
+
+    ``conf_bias`` / ``conf_gain`` shape the token-confidence heads and ``match_bias`` / ``match_gain`` the matchability
+    heads so that early stopping and point pruning can be exercised (or suppressed) by tests.
+    """
+    gen = torch.Generator().manual_seed(seed)
+    sd: StateDict = {}
+    sd["posenc.Wr.weight"] = torch.randn((32, 2), generator=gen) * 2.0
+    for l in range(num_layers):
+        p = f"transformers.{l}"
+        w, b = _linear_init(gen, 768, 256)
+        sd[f"{p}.self_attn.Wqkv.weight"], sd[f"{p}.self_attn.Wqkv.bias"] = w * 4.0, b
+        w, b = _linear_init(gen, 256, 256)
+        sd[f"{p}.self_attn.out_proj.weight"], sd[f"{p}.self_attn.out_proj.bias"] = w * 1.5, b
+        w, b = _linear_init(gen, 256, 256)
+        sd[f"{p}.cross_attn.to_qk.weight"], sd[f"{p}.cross_attn.to_qk.bias"] = w * 5.0, b
+        w, b = _linear_init(gen, 256, 256)
+        sd[f"{p}.cross_attn.to_v.weight"], sd[f"{p}.cross_attn.to_v.bias"] = w * 1.5, b
+        w, b = _linear_init(gen, 256, 256)
+        sd[f"{p}.cross_attn.to_out.weight"], sd[f"{p}.cross_attn.to_out.bias"] = w * 1.5, b
+        for blk in ("self_attn", "cross_attn"):
+            w, b = _linear_init(gen, 512, 512)
+            sd[f"{p}.{blk}.ffn.0.weight"], sd[f"{p}.{blk}.ffn.0.bias"] = w * math.sqrt(3.0), b
+            sd[f"{p}.{blk}.ffn.1.weight"] = 1.0 + 0.2 * (torch.rand((512,), generator=gen) - 0.5)
+            sd[f"{p}.{blk}.ffn.1.bias"] = 0.2 * (torch.rand((512,), generator=gen) - 0.5)
+            w, b = _linear_init(gen, 256, 512)
+            sd[f"{p}.{blk}.ffn.3.weight"], sd[f"{p}.{blk}.ffn.3.bias"] = w * delta_gain, b * delta_gain
+        w, b = _linear_init(gen, 1, 256)
+        sd[f"log_assignment.{l}.matchability.weight"] = w * match_gain
+        sd[f"log_assignment.{l}.matchability.bias"] = b + match_bias
+        w, b = _linear_init(gen, 256, 256)
+        sd[f"log_assignment.{l}.final_proj.weight"] = w * final_gain
+        sd[f"log_assignment.{l}.final_proj.bias"] = b
+        if l < num_layers - 1:
+            w, b = _linear_init(gen, 1, 256)
+            sd[f"token_confidence.{l}.token.0.weight"] = w * conf_gain
+            sd[f"token_confidence.{l}.token.0.bias"] = b + conf_bias
+    return {k: v.contiguous() for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Matcher inputs
+# ----------------------------------------------------------------------------------------------------------------
+
+
+def synthetic_pair_features(
+    n0: int,
+    n1: int,
+    shape0: Tuple[int, int] = (1024, 1024),
+    shape1: Tuple[int, int] = (1024, 1024),
+    overlap: float = 0.6,
+    noise: float = 0.15,
+    seed: int = 0,
+):
+    """Two keypoint/descriptor sets where ``overlap * min(n0, n1)`` keypoints of image 1 are shifted, noised copies
+    of keypoints of image 0 (SURVEY.md section 7 "hard parts": permuted + noised copies give non-trivial matches).
+
+    Returns ``(kpts0 [n0,2] f32 (x,y), scores0 [n0] f32, desc0 [n0,256] f32, kpts1, scores1, desc1, gt)`` where
+    ``gt[i]`` is the index in image 1 of keypoint ``i`` of image 0 (or -1).
+    """
+    rng = np.random.default_rng(seed)
+    h0, w0 = shape0
+    h1, w1 = shape1
+
+    def unit(x):
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+    k0 = np.stack([rng.uniform(4, w0 - 5, n0), rng.uniform(4, h0 - 5, n0)], 1).astype(np.float32)
+    k0 = np.round(k0)
+    s0 = rng.uniform(0.006, 0.6, n0).astype(np.float32)
+    d0 = unit(rng.standard_normal((n0, 256)))
+    k1 = np.round(np.stack([rng.uniform(4, w1 - 5, n1), rng.uniform(4, h1 - 5, n1)], 1)).astype(np.float32)
+    s1 = rng.uniform(0.006, 0.6, n1).astype(np.float32)
+    d1 = unit(rng.standard_normal((n1, 256)))
+    m = int(overlap * min(n0, n1))
+    gt = -np.ones(n0, dtype=np.int64)
+    if m > 0:
+        src = rng.permutation(n0)[:m]
+        dst = rng.permutation(n1)[:m]
+        shift = np.array([7.0, -5.0], dtype=np.float32)
+        k1[dst] = np.clip(k0[src] + shift + np.round(rng.normal(0, 1.0, (m, 2))), 4, [w1 - 5, h1 - 5]).astype(np.float32)
+        d1[dst] = unit(d0[src] + noise * unit(rng.standard_normal((m, 256))))
+        s1[dst] = np.clip(s0[src] * rng.uniform(0.8, 1.2, m), 0.0051, 1.0).astype(np.float32)
+        gt[src] = dst
+    return k0, s0, d0, k1, s1, d1, gt

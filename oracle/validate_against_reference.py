@@ -1,0 +1,184 @@
+"""ORACLE tooling: pin the restatements in ``oracle/`` against the reference's own model files and (re)generate the
+golden vectors under ``tests/golden/``.
+
+Runs ONLY in the build container, where ``/root/reference`` is mounted (it does not exist on the GPU box). It
+
+1. imports ``thirdparty/SuperGluePretrainedNetwork/models/{superpoint,superglue}.py`` by file path (they import only
+   torch; the GTSfM wrappers cannot be imported here -- SURVEY.md F10),
+2. replaces ``torch.load`` during construction so the hard-coded weight paths (superpoint.py:136-137,
+   superglue.py:222-224) receive the seeded synthetic ``state_dict``,
+3. forces ``grid_sample(align_corners=True)``,
+4. asserts that the restatements are BIT-EXACT with the reference outputs on the same inputs, and
+5. writes small golden fixtures (inputs are regenerated from seeds; outputs are stored).
+
+Usage:  python oracle/validate_against_reference.py [--write]
+"""
+
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import os
+import sys
+from contextlib import contextmanager
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+
+from gtsfm_amd.utils import synthetic  # noqa: E402
+from oracle import superglue_oracle, superpoint_oracle  # noqa: E402
+
+REFERENCE = Path(os.environ.get("GTSFM_REFERENCE", "/root/reference"))
+MODELS = REFERENCE / "thirdparty" / "SuperGluePretrainedNetwork" / "models"
+GOLDEN = REPO / "tests" / "golden"
+
+# (height, width, seed): includes non-multiple-of-8 sizes (floor pooling, SURVEY.md section 7 "hard parts").
+SUPERPOINT_CASES = [(120, 160, 1), (123, 157, 2), (240, 320, 3)]
+# (n0, n1, shape0, shape1, seed, sinkhorn iterations)
+SUPERGLUE_CASES = [
+    (96, 80, (240, 320), (200, 300), 11, 20),
+    (257, 300, (480, 640), (480, 640), 12, 100),
+    (1, 5, (64, 64), (64, 64), 13, 20),
+]
+SUPERGLUE_LAYERS_GOLDEN = 18
+
+
+def _import_by_path(name: str, path: Path):
+    spec = importlib.util.spec_from_file_location(name, str(path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@contextmanager
+def _patched_load(sd):
+    real = torch.load
+    torch.load = lambda *a, **k: sd
+    try:
+        yield
+    finally:
+        torch.load = real
+
+
+@contextmanager
+def _force_align_corners():
+    real = torch.nn.functional.grid_sample
+
+    def patched(inp, grid, mode="bilinear", padding_mode="zeros", align_corners=None):
+        return real(inp, grid, mode=mode, padding_mode=padding_mode, align_corners=True)
+
+    torch.nn.functional.grid_sample = patched
+    try:
+        yield
+    finally:
+        torch.nn.functional.grid_sample = real
+
+
+def reference_superpoint(sd):
+    mod = _import_by_path("ref_superpoint", MODELS / "superpoint.py")
+    with _patched_load(sd):
+        model = mod.SuperPoint({}).eval()
+    return model
+
+
+def reference_superglue(sd, iters):
+    mod = _import_by_path("ref_superglue", MODELS / "superglue.py")
+    with _patched_load(sd):
+        model = mod.SuperGlue({"weights": "outdoor", "sinkhorn_iterations": iters, "descriptor_dim": 256}).eval()
+    return model
+
+
+def check_superpoint(write: bool) -> None:
+    sd = synthetic.synthetic_superpoint_state_dict()
+    model = reference_superpoint(sd)
+    for h, w, seed in SUPERPOINT_CASES:
+        gray = synthetic.synthetic_gray_image(h, w, seed)
+        img = superpoint_oracle.gray_u8_to_tensor(gray)
+        with torch.no_grad(), _force_align_corners():
+            ref = model({"image": img})
+            ora = superpoint_oracle.superpoint_forward(sd, img, return_intermediates=True)
+        kp, sc, de = ref["keypoints"][0], ref["scores"][0], ref["descriptors"][0]
+        assert torch.equal(kp, ora["keypoints"]), "keypoints differ"
+        assert torch.equal(sc, ora["scores"]), "scores differ"
+        assert torch.equal(de, ora["descriptors"]), "descriptors differ"
+        print(f"superpoint {h}x{w} seed={seed}: K={kp.shape[0]} restatement bit-exact with reference")
+        if write:
+            np.savez_compressed(
+                GOLDEN / f"superpoint_{h}x{w}_s{seed}.npz",
+                height=h, width=w, seed=seed,
+                keypoints=kp.numpy().astype(np.int32),  # integral (x, y)
+                scores=sc.numpy(),
+                descriptors=de.numpy().T.copy(),  # (K, 256), wrapper layout
+                dense_scores_sample=ora["dense_scores"][0, ::7, ::5].numpy().copy(),
+            )
+
+
+def check_superglue(write: bool) -> None:
+    sd = synthetic.synthetic_superglue_state_dict(num_layers=SUPERGLUE_LAYERS_GOLDEN)
+    for n0, n1, shp0, shp1, seed, iters in SUPERGLUE_CASES:
+        model = reference_superglue(sd, iters)
+        k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(n0, n1, shp0, shp1, seed=seed)
+        data = {
+            "keypoints0": torch.from_numpy(k0)[None], "keypoints1": torch.from_numpy(k1)[None],
+            "descriptors0": torch.from_numpy(d0).T[None].contiguous(), "descriptors1": torch.from_numpy(d1).T[None].contiguous(),
+            "scores0": torch.from_numpy(s0)[None], "scores1": torch.from_numpy(s1)[None],
+            "image0": torch.empty((1, 1) + shp0), "image1": torch.empty((1, 1) + shp1),
+        }
+        with torch.no_grad():
+            ref = model(data)
+            ora = superglue_oracle.superglue_forward(
+                sd, data["keypoints0"], data["keypoints1"], data["scores0"], data["scores1"],
+                data["descriptors0"], data["descriptors1"], shp0, shp1, sinkhorn_iterations=iters,
+                return_intermediates=True,
+            )
+        for key in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+            assert torch.equal(ref[key], ora[key]), f"{key} differs"
+        nm = int((ref["matches0"] > -1).sum())
+        print(f"superglue n=({n0},{n1}) iters={iters}: {nm} matches, restatement bit-exact with reference")
+        if write:
+            np.savez_compressed(
+                GOLDEN / f"superglue_{n0}x{n1}_s{seed}_it{iters}.npz",
+                n0=n0, n1=n1, shape0=shp0, shape1=shp1, seed=seed, iters=iters,
+                matches0=ref["matches0"][0].numpy(), matches1=ref["matches1"][0].numpy(),
+                matching_scores0=ref["matching_scores0"][0].numpy(),
+                matching_scores1=ref["matching_scores1"][0].numpy(),
+                ot_sample=ora["ot"][0, ::3, ::3].numpy().copy(),
+            )
+    # empty-input early-out (superglue.py:233-240)
+    model = reference_superglue(sd, 20)
+    data = {
+        "keypoints0": torch.zeros((1, 0, 2)), "keypoints1": torch.zeros((1, 4, 2)),
+        "descriptors0": torch.zeros((1, 256, 0)), "descriptors1": torch.zeros((1, 256, 4)),
+        "scores0": torch.zeros((1, 0)), "scores1": torch.zeros((1, 4)),
+        "image0": torch.empty((1, 1, 8, 8)), "image1": torch.empty((1, 1, 8, 8)),
+    }
+    with torch.no_grad():
+        ref = model(data)
+        ora = superglue_oracle.superglue_forward(
+            sd, data["keypoints0"], data["keypoints1"], data["scores0"], data["scores1"],
+            data["descriptors0"], data["descriptors1"], (8, 8), (8, 8),
+        )
+    for key in ref:
+        assert ref[key].dtype == ora[key].dtype and torch.equal(ref[key], ora[key]), key
+    print("superglue empty-input early-out: identical")
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--write", action="store_true", help="(re)write tests/golden/*.npz")
+    args = ap.parse_args()
+    if not MODELS.exists():
+        raise SystemExit(f"reference model files not found under {MODELS}")
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    GOLDEN.mkdir(parents=True, exist_ok=True)
+    check_superpoint(args.write)
+    check_superglue(args.write)
+    print("OK")
+
+
+if __name__ == "__main__":
+    main()
