@@ -1,0 +1,244 @@
+"""Benchmark of the MI355X deep front-end (BASELINE.json: image-pairs/sec, detect+match @1024 px).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input resident in HBM: ``--images`` seeded
+1024x1024 gray images are detected + described (SuperPoint) and all ``images*(images-1)/2`` exhaustive pairs are
+matched (``--matcher``). Every rank processes its own batch (weak scaling, no data-path collective: images and pairs
+are independent units); weights are packed on rank 0 and broadcast over RCCL. Rank 0 prints
+ONE JSON line with the whole-job rate, the roofline of the dominant kernel (measured live with HIP events on the
+launch stream) and a CPU baseline (the oracle, timed on a bounded sample of the same workload).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+from gtsfm_amd.utils import synthetic  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def superpoint_conv3x3_layers(h: int, w: int):
+    """(cin, cout, h, w, pool) of the nine conv3x3 MFMA launches of one SuperPoint forward (superpoint.py:120-131;
+    convPa|convDa are fused into one 128->512 launch)."""
+    h2, w2, h4, w4, hc, wc = h // 2, w // 2, h // 4, w // 4, h // 8, w // 8
+    return [
+        (64, 64, h, w, 1), (64, 64, h2, w2, 0), (64, 64, h2, w2, 1), (64, 128, h4, w4, 0), (128, 128, h4, w4, 1),
+        (128, 128, hc, wc, 0), (128, 128, hc, wc, 0), (128, 512, hc, wc, 0),
+    ]
+
+
+def superpoint_flops(h: int, w: int) -> float:
+    """sum over the 12 convolutions of 2*k^2*Cin*Cout*H*W (177.85 GFLOP at 1024x1024)."""
+    hc, wc = h // 8, w // 8
+    total = 2 * 9 * 1 * 64 * h * w
+    total += sum(2 * 9 * cin * cout * hh * ww for cin, cout, hh, ww, _ in superpoint_conv3x3_layers(h, w))
+    total += 2 * 256 * 65 * hc * wc + 2 * 256 * 256 * hc * wc
+    return float(total)
+
+
+def measure_conv_roofline(lib, device, batch: int, h: int, w: int, reps: int = 5):
+    """Times the dominant kernel (conv3x3_mfma_kernel) launch by launch with HIP events on the launch stream."""
+    from gtsfm_amd.runtime import lib as L
+
+    stream = torch.cuda.current_stream(device)
+    total_ms, total_flops, launches = 0.0, 0.0, 0
+    for cin, cout, hh, ww, pool in superpoint_conv3x3_layers(h, w):
+        x = torch.randn((batch, hh, ww, cin), device=device)
+        ho, wo = (hh // 2, ww // 2) if pool else (hh, ww)
+        y = torch.empty((batch, ho, wo, cout), device=device)
+        wp = torch.randn(lib.gtsfm_packed_conv3x3_floats(cin, cout), device=device) * 0.05
+        bias = torch.zeros((cout + 63) // 64 * 64, device=device)
+        args = (x.data_ptr(), cin, 0, y.data_ptr(), cout, 0, wp.data_ptr(), bias.data_ptr(), batch, hh, ww, cin, cout, 1, pool,
+                stream.cuda_stream)
+        L.check(lib.gtsfm_conv3x3_f32(*args), "conv3x3")
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            L.check(lib.gtsfm_conv3x3_f32(*args), "conv3x3")
+        e1.record(stream)
+        e1.synchronize()
+        total_ms += e0.elapsed_time(e1) / reps
+        total_flops += 2.0 * 9 * cin * cout * hh * ww * batch
+        launches += 1
+        del x, y, wp
+    achieved = total_flops / (total_ms * 1e-3) / 1e12
+    return {
+        "bound": "mfma",
+        "kernel": "conv3x3_mfma_kernel",
+        "achieved": round(achieved, 2),
+        "peak": FP32_MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+        "traffic": None,
+        "launches_per_step": launches,
+        "avg_launch_ms": round(total_ms / launches, 4),
+        "flops_per_step": total_flops,
+    }
+
+
+def cpu_baseline(h: int, w: int, n_images: int, matcher: str, n_keypoints: int, sinkhorn_iters: int):
+    """The oracle (kind "port": restatement of the reference's torch CPU path, bit-exact with it in the build
+    container) on a bounded sample: ``n_images`` detections and one pair match, on all host cores."""
+    from oracle import superpoint_oracle
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synthetic.synthetic_superpoint_state_dict()
+    t_det = []
+    feats = []
+    for i in range(n_images):
+        gray = synthetic.synthetic_gray_image(h, w, 1000 + i)
+        t0 = time.perf_counter()
+        c, s, d = superpoint_oracle.detect_and_describe(sd, gray, max_keypoints=n_keypoints)
+        t_det.append(time.perf_counter() - t0)
+        feats.append((c, s, d))
+    det_s = float(np.median(t_det))
+    out = {"detect_s_per_image": round(det_s, 3), "cores": cores, "kind": "port"}
+    if matcher == "none":
+        out.update(value=round(1.0 / det_s, 4), unit="images/s", sample=f"{n_images} x SuperPoint {h}x{w} (oracle, fp32)")
+        return out
+    (c0, s0, d0), (c1, s1, d1) = feats[0], feats[1]
+    t0 = time.perf_counter()
+    if matcher == "superglue":
+        from oracle import superglue_oracle
+
+        sg = synthetic.synthetic_superglue_state_dict()
+        superglue_oracle.match(sg, c0, c1, s0, s1, d0, d1, (h, w, 1), (h, w, 1), sinkhorn_iterations=sinkhorn_iters)
+    else:
+        from oracle import lightglue_oracle
+
+        lg = synthetic.synthetic_lightglue_state_dict()
+        lightglue_oracle.match(lg, c0, c1, d0, d1, (h, w, 1), (h, w, 1))
+    match_s = time.perf_counter() - t0
+    # independent-pair cost on the CPU path: 2 detections + 1 match
+    out.update(
+        match_s_per_pair=round(match_s, 3),
+        value=round(1.0 / (2 * det_s + match_s), 4),
+        unit="image-pairs/s",
+        sample=f"{n_images} x SuperPoint {h}x{w} + 1 x {matcher} pair at N={len(c0)},{len(c1)} (oracle, fp32); "
+        "rate = 1 / (2 detect + 1 match)",
+    )
+    return out
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--images", type=int, default=8, help="images per rank per step")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--matcher", choices=["none", "lightglue", "superglue"], default="none")
+    ap.add_argument("--keypoints", type=int, default=2048, help="keypoints kept per image for matching (host cap 5000)")
+    ap.add_argument("--sinkhorn", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X visible to PyTorch-ROCm (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from gtsfm_amd.parallel import broadcast_packed_weights
+    from gtsfm_amd.runtime import lib as L
+    from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine, pack_superpoint_weights
+
+    lib = L.load()
+    packed = None
+    if rank == 0:
+        packed = torch.from_numpy(pack_superpoint_weights(synthetic.synthetic_superpoint_state_dict())).to(device)
+    packed = broadcast_packed_weights(packed, int(lib.gtsfm_sp_packed_weight_floats()), device)
+    engine = SuperPointEngine.from_packed(packed)
+
+    h = w = args.size
+    n = args.images
+    imgs = np.stack([synthetic.synthetic_gray_image(h, w, 100 * rank + i) for i in range(n)])
+    images = torch.from_numpy(imgs).to(device)  # inputs resident in HBM before the timed region
+    capacity = 16384
+
+    def step():
+        return engine.forward(images, capacity=capacity)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        out = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    units_per_step = n * world  # images (matcher none) -- pairs once matching is part of the step
+    value = units_per_step / (ms_per_step * 1e-3)
+
+    if rank == 0:
+        kcount = out["count"].tolist()
+        result = {
+            "metric": "images/sec (SuperPoint detect+describe) @1024px" if args.matcher == "none" else "image-pairs/sec (detect+match) @1024px",
+            "value": round(value, 2),
+            "unit": "images/s" if args.matcher == "none" else "image-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"SuperPoint-only: {n} synthetic {h}x{w} gray images per GPU per step (matcher: {args.matcher})",
+                "images_per_gpu_per_step": n,
+                "keypoints_per_image": [int(min(kcount)), int(max(kcount))],
+                "weights": "seeded synthetic (gtsfm_amd.utils.synthetic)",
+                "parallelism": f"dp{world} (independent images per rank, RCCL weight broadcast)",
+            },
+            "tflops": round(superpoint_flops(h, w) * units_per_step / (ms_per_step * 1e-3) / 1e12, 2),
+        }
+        result["roofline"] = measure_conv_roofline(lib, device, n, h, w)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(h, w, 2, args.matcher, args.keypoints, args.sinkhorn)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,65 @@
+"""Build libgtsfm_amd.so (hand-written HIP kernels + C ABI) for gfx950, in-tree next to the package.
+
+hipcc cross-compiles without a GPU. The shared library is git-ignored but travels to the GPU box with the snapshot.
+Usage: python -m gtsfm_amd.csrc.build [--force]
+"""
+
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent
+PKG = CSRC.parent
+LIB = PKG / "libgtsfm_amd.so"
+OBJ_DIR = CSRC / "build"
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [PKG.parent / "include" / "gtsfm_amd.h"]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    stamp = OBJ_DIR / "digest.txt"
+    digest = _digest()
+    if not force and LIB.exists() and stamp.exists() and stamp.read_text() == digest:
+        return LIB
+    OBJ_DIR.mkdir(exist_ok=True)
+
+    def compile_one(src: Path) -> Path:
+        obj = OBJ_DIR / (src.stem + ".o")
+        cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    stamp.write_text(digest)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

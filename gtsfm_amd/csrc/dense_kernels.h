@@ -1,0 +1,40 @@
+// Launchers and weight packers for the fp32-MFMA dense kernels (see dense_kernels.hip, mfma_tiles.h).
+#pragma once
+
+#include "common.h"
+
+struct ConvParams {
+    const float* in;   // NHWC activations [B][H][W][in_stride], channels in_coff .. in_coff+Cin-1 are read
+    int in_stride, in_coff;
+    float* out;        // NHWC [B][Ho][Wo][out_stride], channels out_coff .. out_coff+Cout-1 are written
+    int out_stride, out_coff;
+    const float* wpack;  // packed weights (pack_conv3x3_weights)
+    const float* bias;   // [ceil(Cout/64)*64]
+    int B, H, W, Cin, Cout;
+    int relu, pool;      // pool: fused 2x2/stride-2 max-pool, Ho = H/2, Wo = W/2 (floor)
+    int tiles_x, tiles_y;  // filled by the launcher
+};
+
+struct GemmParams {
+    const float* A;  // [M][lda], first K columns are read
+    int lda, M, K;
+    const int* m_dev;  // optional: row count read from device memory (<= M)
+    const float* wpack;  // packed W[N][K] (pack_linear_weights / pack_rows)
+    const float* bias;   // [ceil(N/64)*64] or null
+    int N;
+    float* C;  // [M][ldc], columns c_coff .. c_coff+N-1 are written
+    int ldc, c_coff;
+    const float* res;  // optional residual [M][ldres]: C = res + act(alpha * (A W^T + bias))
+    int ldres;
+    float alpha;
+    int relu;
+};
+
+int launch_conv3x3(const ConvParams& p, hipStream_t stream);
+int launch_gemm(const GemmParams& p, hipStream_t stream);
+int launch_pack_rows(const float* B, int ldb, int N, const int* n_dev, int K, float* out, hipStream_t stream);
+
+size_t packed_conv3x3_floats(int cin, int cout);
+size_t packed_linear_floats(int k, int n);
+void pack_conv3x3_weights(const float* w, int cin, int cout, float* out);
+void pack_linear_weights(const float* w, int k_real, int k, int n, float* out);

@@ -1,0 +1,300 @@
+// fp32-MFMA dense kernels for gfx950: 3x3 convolution (NHWC, LDS halo tile, on-the-fly im2col) and GEMM
+// (1x1 convolution / Conv1d(k=1) / nn.Linear) with fused bias / ReLU / 2x2 max-pool / residual epilogues.
+// Replaces the ATen conv2d / conv1d / linear / max_pool2d calls of
+//   thirdparty/SuperGluePretrainedNetwork/models/superpoint.py:148-162,190-191
+//   thirdparty/SuperGluePretrainedNetwork/models/superglue.py:49-60,98-107,110-119,254
+// See mfma_tiles.h for the tiling and the packed weight layout.
+
+#include "dense_kernels.h"
+#include "mfma_tiles.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv3x3, stride 1, zero pad 1, NHWC. Workgroup tile: 8 x 16 output pixels x 64 output channels.
+// LDS: (8+2) x (16+2) halo pixels x 64 input channels of the current 64-channel chunk (row stride 68 floats).
+// ---------------------------------------------------------------------------------------------------------------
+
+#define CV_TH 8
+#define CV_TW 16
+#define CV_HW (CV_TW + 2)
+#define CV_HALO_PIX ((CV_TH + 2) * CV_HW)
+
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int b = bid / p.tiles_y;
+    const int x0 = tx * CV_TW, y0 = ty * CV_TH;
+    const int nb = blockIdx.y;
+    const int nchunks = p.Cin >> 6;
+    const int total_steps = nchunks * 72;
+    const float* __restrict__ wp = p.wpack + (size_t)nb * total_steps * MT_PACK_STEP_FLOATS;
+
+    const int j = lane & 31, kh = lane >> 5;
+    const int cout = nb * 64 + wn * 32 + j;
+    const float bias = p.bias[cout];  // bias array is padded to a multiple of 64
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc0[r] = bias;
+        acc1[r] = bias;
+    }
+
+    const int a_base0 = ((4 * wm + (j >> 4)) * CV_HW + (j & 15)) * MT_LDS_ROW + kh * 4;
+    const int a_base1 = a_base0 + 2 * CV_HW * MT_LDS_ROW;
+    const float* __restrict__ in_b = p.in + (size_t)b * p.H * p.W * p.in_stride + p.in_coff;
+
+    int kstep = 0;
+    f32x4 bcur = mt_load_b(wp, 0, wn, lane);
+    for (int cc = 0; cc < nchunks; ++cc) {
+        if (cc > 0) __syncthreads();
+        // stage the halo tile of this 64-channel chunk: 180 pixels x 16 float4
+        for (int idx = tid; idx < CV_HALO_PIX * 16; idx += 256) {
+            const int pix = idx >> 4, q = idx & 15;
+            const int gy = y0 - 1 + pix / CV_HW, gx = x0 - 1 + pix % CV_HW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                v = *reinterpret_cast<const f32x4*>(in_b + ((size_t)gy * p.W + gx) * p.in_stride + cc * 64 + q * 4);
+            *reinterpret_cast<f32x4*>(&lds[pix * MT_LDS_ROW + q * 4]) = v;
+        }
+        __syncthreads();
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = ((tap / 3) * CV_HW + (tap % 3)) * MT_LDS_ROW;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const int nxt = (kstep + 1 < total_steps) ? kstep + 1 : kstep;
+                const f32x4 bnext = mt_load_b(wp, nxt, wn, lane);
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[a_base0 + toff + c8 * 8]);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[a_base1 + toff + c8 * 8]);
+                mt_step(acc0, acc1, a0, a1, bcur);
+                bcur = bnext;
+                ++kstep;
+            }
+        }
+    }
+
+    const bool cvalid = cout < p.Cout;
+    if (!p.pool) {
+        float* __restrict__ out_b = p.out + (size_t)b * p.H * p.W * p.out_stride + p.out_coff + cout;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt_acc_row(r, lane);
+                const int y = y0 + 4 * wm + 2 * t + (row >> 4), x = x0 + (row & 15);
+                float v = t ? acc1[r] : acc0[r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (cvalid && y < p.H && x < p.W) out_b[((size_t)y * p.W + x) * p.out_stride] = v;
+            }
+        }
+    } else {
+        // fused 2x2/stride-2 max-pool (floor): the 2x2 window of an output pixel is lane-local in the 32x32
+        // accumulator layout (columns pair up in regs r, r+1; the two tile rows in regs r, r+8).
+        const int Ho = p.H >> 1, Wo = p.W >> 1;
+        float* __restrict__ out_b = p.out + (size_t)b * Ho * Wo * p.out_stride + p.out_coff + cout;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int py = (y0 + 4 * wm + 2 * t) >> 1;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int rr = 0; rr < 4; rr += 2) {
+                    const int r = rr + 4 * g;
+                    float v;
+                    if (t == 0)
+                        v = fmaxf(fmaxf(acc0[r], acc0[r + 1]), fmaxf(acc0[r + 8], acc0[r + 9]));
+                    else
+                        v = fmaxf(fmaxf(acc1[r], acc1[r + 1]), fmaxf(acc1[r + 8], acc1[r + 9]));
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    const int px = (x0 + rr + 8 * g + 4 * kh) >> 1;
+                    if (cvalid && py < Ho && px < Wo) out_b[((size_t)py * Wo + px) * p.out_stride] = v;
+                }
+            }
+        }
+    }
+}
+
+int launch_conv3x3(const ConvParams& pin, hipStream_t stream) {
+    ConvParams p = pin;
+    GTSFM_CHECK_ARG(p.Cin % 64 == 0 && p.Cin >= 64, "conv3x3: Cin must be a multiple of 64 (got %d)", p.Cin);
+    GTSFM_CHECK_ARG(p.in_stride % 4 == 0 && p.in_coff % 4 == 0, "conv3x3: input stride/offset must be 16-byte aligned");
+    p.tiles_x = ceil_div(p.W, CV_TW);
+    p.tiles_y = ceil_div(p.H, CV_TH);
+    dim3 grid(p.B * p.tiles_x * p.tiles_y, ceil_div(p.Cout, 64));
+    const size_t lds_bytes = (size_t)CV_HALO_PIX * MT_LDS_ROW * sizeof(float);
+    hipLaunchKernelGGL(conv3x3_mfma_kernel, grid, dim3(256), lds_bytes, stream, p);
+    GTSFM_CHECK_LAUNCH("conv3x3_mfma_kernel");
+    return GTSFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM: C[M, N] (+)= A[M, K] * W[N, K]^T with packed W. Workgroup tile 128 x 64, K staged in 64-deep chunks.
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = p.m_dev ? *p.m_dev : p.M;
+    const int m0 = blockIdx.x * MT_TILE_M;
+    if (m0 >= M) return;
+    const int nb = blockIdx.y;
+    const int total_steps = p.K >> 3;
+    const float* __restrict__ wp = p.wpack + (size_t)nb * total_steps * MT_PACK_STEP_FLOATS;
+
+    const int j = lane & 31, kh = lane >> 5;
+    const int col = nb * 64 + wn * 32 + j;
+    const float bias = p.bias ? p.bias[col] : 0.f;  // padded to a multiple of 64
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc0[r] = bias;
+        acc1[r] = bias;
+    }
+    const int a_base0 = (64 * wm + j) * MT_LDS_ROW + kh * 4;
+    const int a_base1 = a_base0 + 32 * MT_LDS_ROW;
+
+    int kstep = 0;
+    f32x4 bcur = mt_load_b(wp, 0, wn, lane);
+    for (int k0 = 0; k0 < p.K; k0 += 64) {
+        if (k0 > 0) __syncthreads();
+        for (int idx = tid; idx < MT_TILE_M * 16; idx += 256) {
+            const int row = idx >> 4, q = idx & 15;
+            const int gr = m0 + row, gk = k0 + q * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gr < M && gk < p.K) v = *reinterpret_cast<const f32x4*>(p.A + (size_t)gr * p.lda + gk);
+            *reinterpret_cast<f32x4*>(&lds[row * MT_LDS_ROW + q * 4]) = v;
+        }
+        __syncthreads();
+        const int nsteps = min(8, (p.K - k0) >> 3);
+        if (nsteps == 8) {
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const int nxt = (kstep + 1 < total_steps) ? kstep + 1 : kstep;
+                const f32x4 bnext = mt_load_b(wp, nxt, wn, lane);
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[a_base0 + c8 * 8]);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[a_base1 + c8 * 8]);
+                mt_step(acc0, acc1, a0, a1, bcur);
+                bcur = bnext;
+                ++kstep;
+            }
+        } else {
+            for (int c8 = 0; c8 < nsteps; ++c8) {
+                const int nxt = (kstep + 1 < total_steps) ? kstep + 1 : kstep;
+                const f32x4 bnext = mt_load_b(wp, nxt, wn, lane);
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[a_base0 + c8 * 8]);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[a_base1 + c8 * 8]);
+                mt_step(acc0, acc1, a0, a1, bcur);
+                bcur = bnext;
+                ++kstep;
+            }
+        }
+    }
+
+    if (col >= p.N) return;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 64 * wm + 32 * t + mt_acc_row(r, lane);
+            if (row < M) {
+                float v = t ? acc1[r] : acc0[r];
+                if (p.alpha != 1.0f) v *= p.alpha;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.res) v = p.res[(size_t)row * p.ldres + col] + v;
+                p.C[(size_t)row * p.ldc + p.c_coff + col] = v;
+            }
+        }
+    }
+}
+
+int launch_gemm(const GemmParams& p, hipStream_t stream) {
+    GTSFM_CHECK_ARG(p.K % 8 == 0 && p.K >= 8, "gemm: K must be a multiple of 8 (got %d)", p.K);
+    GTSFM_CHECK_ARG(p.lda % 4 == 0, "gemm: lda must be a multiple of 4 (got %d)", p.lda);
+    if (p.M <= 0) return GTSFM_OK;
+    dim3 grid(ceil_div(p.M, MT_TILE_M), ceil_div(p.N, 64));
+    const size_t lds_bytes = (size_t)MT_TILE_M * MT_LDS_ROW * sizeof(float);
+    hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), lds_bytes, stream, p);
+    GTSFM_CHECK_LAUNCH("gemm_mfma_kernel");
+    return GTSFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pack a row-major activation matrix B[N, K] (device) into the packed weight layout, so that products of two
+// activation matrices (score GEMMs: superglue.py:257) run through the same GEMM kernel.
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ void pack_rows_kernel(const float* __restrict__ B, int ldb, int N, const int* n_dev, int K, float* __restrict__ out) {
+    const int Nr = n_dev ? *n_dev : N;
+    const int total_steps = K >> 3;
+    const size_t total = (size_t)ceil_div(N, 64) * total_steps * 128;  // float4 elements
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = idx & 63;
+        const int wn = (idx >> 6) & 1;
+        const size_t rest = idx >> 7;
+        const int kstep = rest % total_steps;
+        const int nb = rest / total_steps;
+        const int n = nb * 64 + wn * 32 + (lane & 31);
+        const int k = kstep * 8 + (lane >> 5) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < Nr) v = *reinterpret_cast<const f32x4*>(B + (size_t)n * ldb + k);
+        reinterpret_cast<f32x4*>(out)[idx] = v;
+    }
+}
+
+int launch_pack_rows(const float* B, int ldb, int N, const int* n_dev, int K, float* out, hipStream_t stream) {
+    GTSFM_CHECK_ARG(K % 8 == 0 && ldb % 4 == 0, "pack_rows: K %% 8 and ldb %% 4 must be 0");
+    if (N <= 0) return GTSFM_OK;
+    const size_t total = (size_t)ceil_div(N, 64) * (K >> 3) * 128;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, stream, B, ldb, N, n_dev, K, out);
+    GTSFM_CHECK_LAUNCH("pack_rows_kernel");
+    return GTSFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Host-side weight packing (done once at load time).
+// ---------------------------------------------------------------------------------------------------------------
+
+size_t packed_conv3x3_floats(int cin, int cout) { return (size_t)ceil_div(cout, 64) * (cin / 64) * 72 * MT_PACK_STEP_FLOATS; }
+size_t packed_linear_floats(int k, int n) { return (size_t)ceil_div(n, 64) * (k / 8) * MT_PACK_STEP_FLOATS; }
+
+// w: [cout][cin][3][3] (torch Conv2d layout). Zero-fills padded output channels.
+void pack_conv3x3_weights(const float* w, int cin, int cout, float* out) {
+    const int nblocks = ceil_div(cout, 64), nchunks = cin / 64;
+    size_t o = 0;
+    for (int nb = 0; nb < nblocks; ++nb)
+        for (int cc = 0; cc < nchunks; ++cc)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int c8 = 0; c8 < 8; ++c8)
+                    for (int wn = 0; wn < 2; ++wn)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 4; ++e) {
+                                const int n = nb * 64 + wn * 32 + (lane & 31);
+                                const int c = cc * 64 + c8 * 8 + (lane >> 5) * 4 + e;
+                                out[o++] = (n < cout) ? w[((size_t)n * cin + c) * 9 + tap] : 0.f;
+                            }
+}
+
+// w: [n][k_real] row-major (torch Linear / Conv1d(k=1) layout); k is the padded depth (multiple of 8).
+void pack_linear_weights(const float* w, int k_real, int k, int n, float* out) {
+    const int nblocks = ceil_div(n, 64), steps = k / 8;
+    size_t o = 0;
+    for (int nb = 0; nb < nblocks; ++nb)
+        for (int s = 0; s < steps; ++s)
+            for (int wn = 0; wn < 2; ++wn)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int nn = nb * 64 + wn * 32 + (lane & 31);
+                        const int kk = s * 8 + (lane >> 5) * 4 + e;
+                        out[o++] = (nn < n && kk < k_real) ? w[(size_t)nn * k_real + kk] : 0.f;
+                    }
+}

@@ -1,0 +1,38 @@
+"""Process base class: ``gtsfm.ui.gtsfm_process.GTSFMProcess`` / ``UiMetadata`` when GTSfM is importable; otherwise a
+stand-in restating the registry contract (``gtsfm/ui/registry.py:15-45``, ``gtsfm/ui/gtsfm_process.py:36-65``): every
+subclass is registered by ``__name__`` at class-definition time and exposes a static ``get_ui_metadata()``."""
+
+from __future__ import annotations
+
+import abc
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+try:  # pragma: no cover
+    from gtsfm.ui.gtsfm_process import GTSFMProcess, UiMetadata  # type: ignore  # noqa: F401
+except Exception:  # noqa: BLE001
+
+    @dataclass(frozen=True, order=True)
+    class UiMetadata:  # type: ignore[no-redef]
+        display_name: str
+        input_products: Tuple[str, ...]
+        output_products: Tuple[str, ...]
+        parent_plate: Optional[str] = None
+
+    class _Registry(abc.ABCMeta):
+        REGISTRY: Dict[str, type] = {}
+
+        def __new__(mcs, name, bases, attrs):
+            cls = super().__new__(mcs, name, bases, attrs)
+            mcs.REGISTRY[cls.__name__] = cls
+            return cls
+
+        @classmethod
+        def get_registry(mcs) -> Dict[str, type]:
+            return dict(mcs.REGISTRY)
+
+    class GTSFMProcess(metaclass=_Registry):  # type: ignore[no-redef]
+        @staticmethod
+        @abc.abstractmethod
+        def get_ui_metadata() -> UiMetadata:
+            ...

@@ -1,0 +1,132 @@
+"""Multi-GPU plumbing for the deep front-end: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in CPU tests).
+
+The path shards with no data-path collective: detection is independent per image, matching is
+independent per pair -- the reference submits one Dask task per image and per pair and scatters the model object once
+(``gtsfm/frontend/correspondence_generator/det_desc_correspondence_generator.py:65-81``). The collectives here are
+therefore init / result plumbing only, all MB-scale:
+
+* ``broadcast_packed_weights`` -- rank 0 packs a checkpoint once, everyone receives the packed blob (5-50 MB)
+* ``partition_images`` / ``partition_pairs`` -- deterministic block-cyclic ownership, computed locally on every rank
+* ``gather_features`` -- all_gather of padded per-image feature blocks between the detect and match phases
+* ``gather_matches`` -- variable-length (K,2) match arrays back to every rank (counts + padded all_gather)
+"""
+
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def world_info() -> Tuple[int, int]:
+    d = _dist()
+    return (d.get_rank(), d.get_world_size()) if d else (0, 1)
+
+
+def broadcast_packed_weights(packed: Optional[torch.Tensor], numel: int, device: torch.device, src: int = 0) -> torch.Tensor:
+    """Rank ``src`` passes its packed fp32 blob, the others pass None; returns the blob on ``device`` everywhere."""
+    d = _dist()
+    if d is None:
+        assert packed is not None
+        return packed
+    if d.get_rank() == src:
+        assert packed is not None and packed.numel() == numel
+        buf = packed.to(device).contiguous()
+    else:
+        buf = torch.empty(numel, dtype=torch.float32, device=device)
+    d.broadcast(buf, src=src)
+    return buf
+
+
+def partition_images(num_images: int, rank: int, world: int) -> List[int]:
+    """Rank r owns images {i : i mod world == r}."""
+    return list(range(rank, num_images, world))
+
+
+def partition_pairs(pairs: Sequence[Tuple[int, int]], rank: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous blocks of the (sorted) pair list: rank r owns pairs [r*P/world, (r+1)*P/world)."""
+    pairs = sorted(pairs)
+    p = len(pairs)
+    lo, hi = (rank * p) // world, ((rank + 1) * p) // world
+    return list(pairs[lo:hi])
+
+
+def exhaustive_pairs(num_images: int) -> List[Tuple[int, int]]:
+    return [(i, j) for i in range(num_images) for j in range(i + 1, num_images)]
+
+
+def gather_features(
+    local: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], num_images: int, max_keypoints: int, device: torch.device
+) -> Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+    """All-gather per-image features (xy [K,2], scores [K], descriptors [K,256]) detected by their owning ranks.
+
+    Each rank contributes a padded block [slots][max_keypoints][259] + counts; slots = ceil(num_images / world)."""
+    d = _dist()
+    if d is None:
+        return dict(local)
+    rank, world = d.get_rank(), d.get_world_size()
+    slots = -(-num_images // world)
+    block = torch.zeros((slots, max_keypoints, 259), dtype=torch.float32, device=device)
+    counts = torch.zeros((slots,), dtype=torch.int32, device=device)
+    for s, i in enumerate(partition_images(num_images, rank, world)):
+        xy, sc, de = local[i]
+        k = xy.shape[0]
+        assert k <= max_keypoints
+        block[s, :k, 0:2], block[s, :k, 2], block[s, :k, 3:] = xy, sc, de
+        counts[s] = k
+    blocks = [torch.empty_like(block) for _ in range(world)]
+    cnts = [torch.empty_like(counts) for _ in range(world)]
+    d.all_gather(blocks, block)
+    d.all_gather(cnts, counts)
+    out: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+    for r in range(world):
+        for s, i in enumerate(partition_images(num_images, r, world)):
+            k = int(cnts[r][s])
+            b = blocks[r][s, :k]
+            out[i] = (b[:, 0:2].contiguous(), b[:, 2].contiguous(), b[:, 3:].contiguous())
+    return out
+
+
+def gather_matches(local: Dict[Tuple[int, int], np.ndarray], device: torch.device) -> Dict[Tuple[int, int], np.ndarray]:
+    """Variable-length (K,2) match arrays of every rank's pairs, returned on every rank (all_gatherv emulation:
+    all_gather of sizes, then of one padded int64 buffer per rank: rows [i1, i2, idx1, idx2])."""
+    d = _dist()
+    if d is None:
+        return dict(local)
+    world = d.get_world_size()
+    rows = [np.concatenate([np.full((m.shape[0], 2), p, dtype=np.int64), m.astype(np.int64)], axis=1) for p, m in local.items()]
+    empties = [p for p, m in local.items() if m.shape[0] == 0]
+    flat = np.concatenate(rows, axis=0) if rows else np.zeros((0, 4), dtype=np.int64)
+    meta = torch.tensor([flat.shape[0], len(empties)], dtype=torch.int64, device=device)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    d.all_gather(metas, meta)
+    max_rows = max(int(m[0]) for m in metas)
+    max_empty = max(int(m[1]) for m in metas)
+    buf = torch.zeros((max_rows + max_empty, 4), dtype=torch.int64, device=device)
+    if flat.shape[0]:
+        buf[: flat.shape[0]] = torch.from_numpy(flat).to(device)
+    for e, p in enumerate(empties):
+        buf[max_rows + e, 0], buf[max_rows + e, 1] = p
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    d.all_gather(bufs, buf)
+    out: Dict[Tuple[int, int], List[np.ndarray]] = {}
+    for r in range(world):
+        nrows, nempty = int(metas[r][0]), int(metas[r][1])
+        b = bufs[r].cpu().numpy()
+        for row in b[max_rows : max_rows + nempty]:
+            out.setdefault((int(row[0]), int(row[1])), [])
+        data = b[:nrows]
+        if nrows:
+            keys = data[:, 0] * (1 << 32) + data[:, 1]
+            for key in np.unique(keys):
+                sel = data[keys == key]
+                out.setdefault((int(sel[0, 0]), int(sel[0, 1])), []).append(sel[:, 2:])
+    return {p: (np.concatenate(v, axis=0) if v else np.zeros((0, 2), dtype=np.int64)) for p, v in out.items()}

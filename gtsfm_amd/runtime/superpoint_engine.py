@@ -1,0 +1,143 @@
+"""Host side of the SuperPoint HIP path: weight packing/upload, workspace management, kernel enqueue.
+
+PyTorch is used for device memory and streams only; all arithmetic runs in libgtsfm_amd.so
+(``gtsfm_sp_forward``, replacing ``thirdparty/SuperGluePretrainedNetwork/models/superpoint.py:145-202``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional
+
+import numpy as np
+import torch
+
+from gtsfm_amd.runtime import lib as _lib
+
+# checkpoint order of superpoint_v1.pth (superpoint.py:119-134)
+SUPERPOINT_KEYS = [
+    f"{name}.{kind}"
+    for name in (
+        "conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convPb", "convDa",
+        "convDb",
+    )
+    for kind in ("weight", "bias")
+]
+
+DEFAULT_NMS_RADIUS = 4  # superpoint.py:111-115 default_config
+DEFAULT_KEYPOINT_THRESHOLD = 0.005
+DEFAULT_REMOVE_BORDERS = 4
+
+
+def require_gpu(device: Optional[torch.device] = None) -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("gtsfm_amd requires an AMD GPU visible to PyTorch-ROCm; there is no CPU fallback.")
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+def pack_superpoint_weights(state_dict: Mapping[str, torch.Tensor]) -> np.ndarray:
+    """state_dict (reference checkpoint names/layouts) -> packed fp32 blob (host)."""
+    lib = _lib.load()
+    missing = [k for k in SUPERPOINT_KEYS if k not in state_dict]
+    if missing:
+        raise KeyError(f"SuperPoint state_dict is missing {missing}")
+    tensors = [np.ascontiguousarray(state_dict[k].detach().cpu().numpy().astype(np.float32)) for k in SUPERPOINT_KEYS]
+    arr = (C.c_void_p * len(tensors))(*[t.ctypes.data for t in tensors])
+    out = np.empty(lib.gtsfm_sp_packed_weight_floats(), dtype=np.float32)
+    _lib.check(lib.gtsfm_sp_pack_weights(arr, out.ctypes.data), "gtsfm_sp_pack_weights")
+    return out
+
+
+class SuperPointEngine:
+    """Device-resident SuperPoint: packed weights in HBM + cached workspaces."""
+
+    def __init__(self, state_dict: Mapping[str, torch.Tensor], device: Optional[torch.device] = None):
+        self.device = require_gpu(device)
+        self._lib = _lib.load()
+        self.weights = torch.from_numpy(pack_superpoint_weights(state_dict)).to(self.device)
+        self._workspaces: Dict[tuple, torch.Tensor] = {}
+
+    @classmethod
+    def from_packed(cls, packed: torch.Tensor) -> "SuperPointEngine":
+        """Build from an already-packed device blob (e.g. received by an RCCL broadcast)."""
+        self = cls.__new__(cls)
+        self.device = packed.device
+        self._lib = _lib.load()
+        self.weights = packed
+        self._workspaces = {}
+        return self
+
+    def _workspace(self, b: int, h: int, w: int) -> torch.Tensor:
+        key = (b, h, w)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            nbytes = self._lib.gtsfm_sp_workspace_bytes(b, h, w)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            if len(self._workspaces) > 4:
+                self._workspaces.clear()
+            self._workspaces[key] = ws
+        return ws
+
+    @staticmethod
+    def default_capacity(h: int, w: int, nms_radius: int) -> int:
+        h8, w8 = (h // 8) * 8, (w // 8) * 8
+        r = nms_radius + 1
+        return max(64, -(-h8 // r) * -(-w8 // r) + 64)
+
+    def forward(
+        self,
+        images: torch.Tensor,
+        capacity: Optional[int] = None,
+        keypoint_threshold: float = DEFAULT_KEYPOINT_THRESHOLD,
+        nms_radius: int = DEFAULT_NMS_RADIUS,
+        remove_borders: int = DEFAULT_REMOVE_BORDERS,
+        return_score_maps: bool = False,
+    ) -> Dict[str, torch.Tensor]:
+        """images: device tensor [B,H,W], uint8 or float32 in [0,1]. Returns device tensors:
+        count [B] int32, count_raw [B] int32, xy [B,cap,2], scores [B,cap], descriptors [B,cap,256]."""
+        assert images.dim() == 3 and images.is_cuda and images.is_contiguous()
+        assert images.dtype in (torch.uint8, torch.float32)
+        b, h, w = images.shape
+        cap = capacity or self.default_capacity(h, w, nms_radius)
+        dev = images.device
+        count = torch.empty(b, dtype=torch.int32, device=dev)
+        count_raw = torch.empty(b, dtype=torch.int32, device=dev)
+        xy = torch.empty((b, cap, 2), dtype=torch.float32, device=dev)
+        scores = torch.empty((b, cap), dtype=torch.float32, device=dev)
+        desc = torch.empty((b, cap, 256), dtype=torch.float32, device=dev)
+        dense = nms = None
+        if return_score_maps:
+            h8, w8 = (h // 8) * 8, (w // 8) * 8
+            dense = torch.empty((b, h8, w8), dtype=torch.float32, device=dev)
+            nms = torch.empty((b, h8, w8), dtype=torch.float32, device=dev)
+        ws = self._workspace(b, h, w)
+        rc = self._lib.gtsfm_sp_forward(
+            self.weights.data_ptr(), images.data_ptr(), int(images.dtype == torch.uint8), b, h, w,
+            float(keypoint_threshold), int(nms_radius), int(remove_borders), cap, ws.data_ptr(), ws.numel(),
+            count.data_ptr(), count_raw.data_ptr(), xy.data_ptr(), scores.data_ptr(), desc.data_ptr(),
+            _lib.ptr(dense), _lib.ptr(nms), torch.cuda.current_stream(dev).cuda_stream,
+        )
+        _lib.check(rc, "gtsfm_sp_forward")
+        out = {"count": count, "count_raw": count_raw, "xy": xy, "scores": scores, "descriptors": desc}
+        if return_score_maps:
+            out["dense_scores"], out["nms_scores"] = dense, nms
+        return out
+
+    def detect(self, gray: np.ndarray, **kwargs):
+        """Single host image (H,W) uint8 or float32 -> numpy (coordinates [K,2] f32 (x,y), scores [K], descriptors
+        [K,256]) in the model's row-major order, i.e. what superpoint.py:198-202 returns before the GTSfM wrapper's
+        host-side filtering."""
+        assert gray.ndim == 2
+        img = torch.from_numpy(np.ascontiguousarray(gray)).to(self.device)[None]
+        out = self.forward(img, **kwargs)
+        k_raw = int(out["count_raw"][0].item())
+        cap = out["xy"].shape[1]
+        if k_raw > cap:  # ties can exceed the NMS packing bound; rerun with an exact capacity
+            kwargs = dict(kwargs, capacity=k_raw)
+            out = self.forward(img, **kwargs)
+        k = int(out["count"][0].item())
+        return (
+            out["xy"][0, :k].cpu().numpy(),
+            out["scores"][0, :k].cpu().numpy(),
+            out["descriptors"][0, :k].cpu().numpy(),
+        )

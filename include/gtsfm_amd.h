@@ -1,0 +1,130 @@
+/*
+ * gtsfm_amd.h -- C ABI of libgtsfm_amd.so: the MI355X (gfx950) deep front-end of GTSfM.
+ *
+ * This is the drop-in boundary for ONE hot path of borglab/gtsfm: the SuperPoint detector/descriptor and the
+ * SuperGlue / LightGlue matchers behind gtsfm/frontend's DetectorDescriptorBase / MatcherBase plugins. The reference
+ * has no native code on this path (it calls ATen ops from Python); each entry point below names the reference
+ * Python it replaces (paths relative to the reference repository root, abbreviated
+ *   SP = thirdparty/SuperGluePretrainedNetwork/models/superpoint.py
+ *   SG = thirdparty/SuperGluePretrainedNetwork/models/superglue.py
+ *   LG = thirdparty/LightGlue/lightglue/lightglue.py (un-vendored submodule; call sites in
+ *        gtsfm/frontend/matcher/lightglue_matcher.py:37-110)).
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only; no torch types. "_dev" pointers are device (HBM) addresses, e.g.
+ *     torch.Tensor.data_ptr(); "_host" pointers are host addresses. `stream` is a hipStream_t passed as void*.
+ *   - every function returns 0 on success, a negative GTSFM_ERR_* code otherwise, and never throws across the ABI;
+ *     gtsfm_last_error() returns a thread-local message for the last failure.
+ *   - no hidden device allocations: callers pass workspaces sized by the *_workspace_bytes() queries.
+ *   - no global mutable state besides the thread-local error string: any number of callers (one per GPU / process)
+ *     may coexist. Kernels are enqueued on `stream` and are asynchronous with respect to the host.
+ *   - activations are fp32, channels-last (NHWC for images, [tokens][channels] for keypoint sets).
+ */
+#ifndef GTSFM_AMD_H
+#define GTSFM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTSFM_OK 0
+#define GTSFM_ERR_INVALID -1
+#define GTSFM_ERR_HIP -2
+#define GTSFM_ERR_WORKSPACE -3
+
+/* ABI version of this header; bumped on incompatible changes. */
+int gtsfm_abi_version(void);
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char* gtsfm_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Generic fp32 dense ops (exact-fp32 MFMA). Exposed so that callers and parity tests can exercise each kernel
+ * in isolation against the reference's ATen op.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Packed-weight sizes (floats) and host-side packers.
+ * conv3x3: w_host is torch Conv2d layout [cout][cin][3][3], cin % 64 == 0.
+ * linear : w_host is [n][k_real] row-major (nn.Linear / Conv1d(k=1)); k_pad = k_real rounded up to 8.
+ * bias (if any) must be passed to the ops as a device array padded with zeros to a multiple of 64 entries. */
+size_t gtsfm_packed_conv3x3_floats(int cin, int cout);
+size_t gtsfm_packed_linear_floats(int k_pad, int n);
+int gtsfm_pack_conv3x3(const float* w_host, int cin, int cout, float* packed_host);
+int gtsfm_pack_linear(const float* w_host, int k_real, int k_pad, int n, float* packed_host);
+
+/* y = [maxpool2x2](relu?(conv3x3(x) + bias)), stride 1, zero pad 1, NHWC.            replaces SP:148-161,190
+ * in : [batch][h][w][in_stride], channels in_coff .. in_coff+cin-1
+ * out: [batch][ho][wo][out_stride], channels out_coff .. out_coff+cout-1; (ho,wo) = (h,w) or (h/2,w/2) if pool */
+int gtsfm_conv3x3_f32(const float* in_dev, int in_stride, int in_coff, float* out_dev, int out_stride, int out_coff,
+                      const float* packed_w_dev, const float* bias_dev, int batch, int h, int w, int cin, int cout,
+                      int relu, int pool, void* stream);
+
+/* C[:, c_coff:c_coff+n] = (res +) relu?(alpha * (A[:, :k] W^T + bias))              replaces SP:162,191, SG:49-60,
+ * A: [m][lda]; C: [m][ldc]; res (optional): [m][ldres]; m_dev (optional): row count in device memory (<= m).
+ * nn.Linear / Conv1d(kernel_size=1) / Conv2d(kernel_size=1).                                     98-119,254 */
+int gtsfm_linear_f32(const float* a_dev, int lda, int m, const int32_t* m_dev, int k, const float* packed_w_dev,
+                     const float* bias_dev, int n, float* c_dev, int ldc, int c_coff, const float* res_dev, int ldres,
+                     float alpha, int relu, void* stream);
+
+/* Pack a device activation matrix B[n][k] (row stride ldb) as the "weight" operand of gtsfm_linear_f32, so that
+ * A B^T products of two activation matrices (score matrices, SG:257) use the same kernel. */
+int gtsfm_pack_rows_f32(const float* b_dev, int ldb, int n, const int32_t* n_dev, int k, float* packed_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * SuperPoint
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Number of floats of the packed SuperPoint weight blob, and the packer. `tensors_host` are the 24 state_dict
+ * tensors in checkpoint order: conv1a.weight, conv1a.bias, conv1b.weight, ..., convDb.weight, convDb.bias
+ * (SP:119-134; torch layouts). */
+size_t gtsfm_sp_packed_weight_floats(void);
+int gtsfm_sp_pack_weights(const float* const* tensors_host, float* packed_host);
+
+/* Bytes of device workspace gtsfm_sp_forward needs for `batch` images of height x width. */
+size_t gtsfm_sp_workspace_bytes(int batch, int height, int width);
+
+/* SuperPoint.forward for a batch of equally-sized gray images.                              replaces SP:145-202
+ * image_dev       : [batch][height][width], fp32 in [0,1] (image_is_u8 = 0) or uint8 (image_is_u8 = 1; converted as
+ *                   astype(float32) / 255.0 like gtsfm/frontend/detector_descriptor/superpoint.py:73-75)
+ * capacity        : rows available per image in the output arrays; keypoints beyond it are dropped (row-major
+ *                   order), kp_count_raw_dev still reports the true count
+ * kp_count_dev    : [batch] int32, min(count, capacity)
+ * kp_count_raw_dev: [batch] int32, true keypoint count (may be NULL)
+ * kp_xy_dev       : [batch][capacity][2] fp32 (x, y) pixel coordinates, row-major (y, x) detection order = the order
+ *                   of torch.nonzero (SP:170-173,187)
+ * kp_score_dev    : [batch][capacity] fp32
+ * desc_dev        : [batch][capacity][256] fp32, row i <-> keypoint i (the transposed layout the wrapper builds at
+ *                   gtsfm/frontend/detector_descriptor/superpoint.py:84)
+ * Optional taps for parity tests (NULL to skip): dense_scores_dev [batch][8*(h/8)][8*(w/8)] (pre-NMS, SP:163-166),
+ * nms_scores_dev same shape (SP:167). */
+int gtsfm_sp_forward(const float* packed_weights_dev, const void* image_dev, int image_is_u8, int batch, int height,
+                     int width, float keypoint_threshold, int nms_radius, int remove_borders, int capacity,
+                     void* workspace_dev, size_t workspace_bytes, int32_t* kp_count_dev, int32_t* kp_count_raw_dev,
+                     float* kp_xy_dev, float* kp_score_dev, float* desc_dev, float* dense_scores_dev,
+                     float* nms_scores_dev, void* stream);
+
+/* The individual SuperPoint stages (same kernels gtsfm_sp_forward launches), for stage-wise parity tests. */
+
+/* softmax over 65 logits per cell, drop dustbin, depth-to-space 8x8.                           replaces SP:163-166
+ * logits: [batch][hc][wc][ld] (ld >= 65); scores: [batch][8*hc][8*wc] */
+int gtsfm_sp_softmax_d2s(const float* logits_dev, int ld, int batch, int hc, int wc, float* scores_dev, void* stream);
+/* simple_nms. scratch: 2*n bytes + n floats where n = batch*h*w (gtsfm_sp_nms_scratch_bytes).    replaces SP:47-62 */
+size_t gtsfm_sp_nms_scratch_bytes(int batch, int h, int w);
+int gtsfm_sp_simple_nms(const float* scores_dev, int batch, int h, int w, int radius, void* scratch_dev, float* out_dev,
+                        void* stream);
+/* nonzero(score > thr) + remove_borders + flip. scratch: 2*batch*h int32.            replaces SP:170-178,187 */
+int gtsfm_sp_extract_keypoints(const float* nms_dev, int batch, int h, int w, float threshold, int border, int capacity,
+                               int32_t* scratch_dev, int32_t* kp_count_dev, int32_t* kp_count_raw_dev, float* kp_xy_dev,
+                               float* kp_score_dev, void* stream);
+/* L2-normalise dense descriptors, bilinear sample (align_corners=True), L2-normalise.   replaces SP:80-92,192-196
+ * dense: [batch][hc*wc][ld] raw convDb output (256 channels). */
+int gtsfm_sp_sample_descriptors(const float* dense_dev, int ld, int batch, int hc, int wc, const float* kp_xy_dev,
+                                const int32_t* kp_count_dev, int capacity, float* desc_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* GTSFM_AMD_H */

@@ -1,0 +1,82 @@
+"""CPU: the oracle restatements reproduce the golden vectors generated from the reference's own model files
+(``oracle/validate_against_reference.py --write``, which also asserts bit-exactness against the reference)."""
+
+import numpy as np
+import pytest
+import torch
+
+from gtsfm_amd.utils import synthetic
+from oracle import superglue_oracle, superpoint_oracle
+from tests.conftest import GOLDEN
+
+SP_FILES = sorted(GOLDEN.glob("superpoint_*.npz"))
+SG_FILES = sorted(GOLDEN.glob("superglue_*.npz"))
+
+
+def test_golden_fixtures_present():
+    assert len(SP_FILES) >= 3 and len(SG_FILES) >= 3
+
+
+@pytest.mark.parametrize("path", SP_FILES, ids=lambda p: p.stem)
+def test_superpoint_oracle_matches_golden(path):
+    g = np.load(path)
+    sd = synthetic.synthetic_superpoint_state_dict()
+    gray = synthetic.synthetic_gray_image(int(g["height"]), int(g["width"]), int(g["seed"]))
+    with torch.no_grad():
+        out = superpoint_oracle.superpoint_forward(sd, superpoint_oracle.gray_u8_to_tensor(gray), return_intermediates=True)
+    # keypoints / indices: exact. Floating point: the fixtures were produced by the same ATen kernels, but CPU ISA
+    # dispatch may differ between machines, so allow fp32 round-off on values.
+    np.testing.assert_array_equal(out["keypoints"].numpy().astype(np.int32), g["keypoints"])
+    np.testing.assert_allclose(out["scores"].numpy(), g["scores"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out["descriptors"].numpy().T, g["descriptors"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out["dense_scores"][0, ::7, ::5].numpy(), g["dense_scores_sample"], rtol=0, atol=1e-6)
+
+
+def test_superpoint_oracle_fp64_agrees():
+    """The float64 variant (tie-breaker for fp32 disagreements) finds the same keypoints on a golden case."""
+    g = np.load(SP_FILES[0])
+    sd = synthetic.synthetic_superpoint_state_dict()
+    gray = synthetic.synthetic_gray_image(int(g["height"]), int(g["width"]), int(g["seed"]))
+    with torch.no_grad():
+        out = superpoint_oracle.superpoint_forward(sd, superpoint_oracle.gray_u8_to_tensor(gray, torch.float64))
+    np.testing.assert_array_equal(out["keypoints"].numpy().astype(np.int32), g["keypoints"])
+    np.testing.assert_allclose(out["descriptors"].numpy().T, g["descriptors"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("path", SG_FILES, ids=lambda p: p.stem)
+def test_superglue_oracle_matches_golden(path):
+    g = np.load(path)
+    sd = synthetic.synthetic_superglue_state_dict()
+    shp0, shp1 = tuple(int(v) for v in g["shape0"]), tuple(int(v) for v in g["shape1"])
+    k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(int(g["n0"]), int(g["n1"]), shp0, shp1, seed=int(g["seed"]))
+    T = torch.from_numpy
+    with torch.no_grad():
+        out = superglue_oracle.superglue_forward(
+            sd, T(k0)[None], T(k1)[None], T(s0)[None], T(s1)[None], T(d0).T[None].contiguous(), T(d1).T[None].contiguous(),
+            shp0, shp1, sinkhorn_iterations=int(g["iters"]), return_intermediates=True,
+        )
+    np.testing.assert_array_equal(out["matches0"][0].numpy(), g["matches0"])
+    np.testing.assert_array_equal(out["matches1"][0].numpy(), g["matches1"])
+    np.testing.assert_allclose(out["matching_scores0"][0].numpy(), g["matching_scores0"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["ot"][0, ::3, ::3].numpy(), g["ot_sample"], rtol=0, atol=2e-4)
+
+
+def test_superglue_wrapper_marshalling_dtype():
+    """gtsfm/frontend/matcher/superglue_matcher.py:104-113: (K,2) uint32, ordered by image-1 keypoint index."""
+    sd = synthetic.synthetic_superglue_state_dict(num_layers=2)
+    k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(40, 30, (100, 120), (100, 120), seed=1)
+    m = superglue_oracle.match(sd, k0, k1, s0, s1, d0, d1, (100, 120, 3), (100, 120, 3))
+    assert m.dtype == np.uint32 and m.ndim == 2 and m.shape[1] == 2
+    assert np.all(np.diff(m[:, 0].astype(np.int64)) > 0)
+    assert len(set(m[:, 1].tolist())) == m.shape[0]
+
+
+def test_superglue_empty_input_early_out():
+    """superglue.py:233-240."""
+    sd = synthetic.synthetic_superglue_state_dict(num_layers=2)
+    out = superglue_oracle.superglue_forward(
+        sd, torch.zeros((1, 0, 2)), torch.zeros((1, 3, 2)), torch.zeros((1, 0)), torch.zeros((1, 3)),
+        torch.zeros((1, 256, 0)), torch.zeros((1, 256, 3)), (8, 8), (8, 8),
+    )
+    assert out["matches0"].shape == (1, 0) and out["matches0"].dtype == torch.int
+    assert torch.equal(out["matches1"], torch.full((1, 3), -1, dtype=torch.int))

@@ -1,0 +1,374 @@
+"""GPU parity tests of the SuperPoint HIP path against the oracle and the golden vectors, through the C ABI.
+
+Tolerances (BASELINE.json north_star): keypoints / indices bit-exact; descriptors and scores within 1e-4 fp32
+(observed: ~3e-7 descriptors, ~6e-6 scores). Comparison-only kernels (simple-NMS, keypoint extraction) are fed the
+oracle's upstream tensor and must be bit-exact.
+"""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gtsfm_amd.utils import synthetic
+from oracle import superpoint_oracle as spo
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+DESC_TOL = 1e-4
+SCORE_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synthetic.synthetic_superpoint_state_dict()
+
+
+@pytest.fixture(scope="module")
+def engine(gpu_device, sd):
+    from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+
+    return SuperPointEngine(sd, gpu_device)
+
+
+@pytest.fixture(scope="module")
+def lib(built_library):
+    from gtsfm_amd.runtime import lib as L
+
+    return L.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(lib, rc):
+    assert rc == 0, lib.gtsfm_last_error().decode()
+
+
+def _pack_conv(lib, w, dev):
+    cout, cin = w.shape[:2]
+    out = np.empty(lib.gtsfm_packed_conv3x3_floats(cin, cout), np.float32)
+    wc = np.ascontiguousarray(w.numpy())
+    _check(lib, lib.gtsfm_pack_conv3x3(wc.ctypes.data, cin, cout, out.ctypes.data))
+    return torch.from_numpy(out).to(dev)
+
+
+def _pack_linear(lib, w, dev, k_pad=None):
+    n, k = w.shape
+    k_pad = k_pad or (k + 7) // 8 * 8
+    out = np.empty(lib.gtsfm_packed_linear_floats(k_pad, n), np.float32)
+    wc = np.ascontiguousarray(w.numpy())
+    _check(lib, lib.gtsfm_pack_linear(wc.ctypes.data, k, k_pad, n, out.ctypes.data))
+    return torch.from_numpy(out).to(dev)
+
+
+def _pad64(b, dev):
+    o = torch.zeros((b.numel() + 63) // 64 * 64)
+    o[: b.numel()] = b
+    return o.to(dev)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# stage-wise parity
+# ------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize(
+    "name,batch,h,w,pool",
+    [("conv1b", 2, 37, 53, 0), ("conv1b", 2, 37, 53, 1), ("conv2a", 1, 8, 16, 0), ("conv3a", 1, 24, 40, 0),
+     ("conv3b", 2, 24, 41, 1), ("convPa", 1, 16, 16, 0), ("conv4a", 3, 5, 3, 0), ("conv1b", 1, 1, 1, 0)],
+)
+def test_conv3x3_matches_aten(lib, gpu_device, sd, name, batch, h, w, pool):
+    """conv3x3 + bias + ReLU (+ fused 2x2 max-pool, floor) vs F.conv2d / F.max_pool2d (superpoint.py:148-161)."""
+    wt, bs = sd[f"{name}.weight"], sd[f"{name}.bias"]
+    cout, cin = wt.shape[:2]
+    gen = torch.Generator().manual_seed(h * 1000 + w)
+    x = torch.randn((batch, cin, h, w), generator=gen)
+    ref = F.relu(F.conv2d(x, wt, bs, padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(gpu_device)
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    out = torch.full((batch, ho, wo, cout), float("nan"), device=gpu_device)
+    wp, bp = _pack_conv(lib, wt, gpu_device), _pad64(bs, gpu_device)
+    _check(lib, lib.gtsfm_conv3x3_f32(xd.data_ptr(), cin, 0, out.data_ptr(), cout, 0, wp.data_ptr(), bp.data_ptr(), batch,
+                                      h, w, cin, cout, 1, pool, _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert not torch.isnan(got).any()
+    assert float((got - ref).abs().max()) < 5e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv3x3_strided_channel_views(lib, gpu_device, sd):
+    """Reads a channel window of a wider NHWC buffer and writes into a channel window of another."""
+    wt, bs = sd["conv2a.weight"], sd["conv2a.bias"]
+    x = torch.randn((1, 64, 9, 20))
+    ref = F.conv2d(x, wt, bs, padding=1)
+    wide = torch.randn((1, 9, 20, 192))
+    wide[..., 64:128] = x.permute(0, 2, 3, 1)
+    out = torch.full((1, 9, 20, 128), 7.0, device=gpu_device)
+    wp, bp = _pack_conv(lib, wt, gpu_device), _pad64(bs, gpu_device)
+    wd = wide.to(gpu_device)
+    _check(lib, lib.gtsfm_conv3x3_f32(wd.data_ptr(), 192, 64, out.data_ptr(), 128, 64, wp.data_ptr(), bp.data_ptr(), 1, 9, 20,
+                                      64, 64, 0, 0, _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert torch.all(got[..., :64] == 7.0)
+    assert float((got[..., 64:].permute(0, 3, 1, 2) - ref).abs().max()) < 5e-5
+
+
+@pytest.mark.parametrize("m,k,n,relu,res", [(300, 256, 65, 0, 0), (129, 256, 256, 1, 0), (1, 512, 256, 0, 1), (700, 32, 64, 1, 1),
+                                            (64, 8, 32, 0, 0)])
+def test_linear_matches_aten(lib, gpu_device, m, k, n, relu, res):
+    """1x1 conv / Conv1d(k=1) / Linear (superpoint.py:162,191; superglue.py:49-60) incl. residual epilogue."""
+    gen = torch.Generator().manual_seed(m + k + n)
+    a = torch.randn((m, k), generator=gen)
+    w = torch.randn((n, k), generator=gen) / k**0.5
+    b = torch.randn((n,), generator=gen)
+    r = torch.randn((m, n), generator=gen)
+    ref = F.linear(a, w, b) * 0.5
+    if relu:
+        ref = F.relu(ref)
+    if res:
+        ref = r + ref
+    ad, rd = a.to(gpu_device), r.to(gpu_device)
+    out = torch.full((m, n + 3), -5.0, device=gpu_device)
+    wp, bp = _pack_linear(lib, w, gpu_device), _pad64(b, gpu_device)
+    # alpha scales (A W^T + bias)
+    _check(lib, lib.gtsfm_linear_f32(ad.data_ptr(), k, m, None, k, wp.data_ptr(), bp.data_ptr(), n, out.data_ptr(), n + 3, 2,
+                                     rd.data_ptr() if res else None, n, 0.5, relu, _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert torch.all(got[:, :2] == -5.0) and torch.all(got[:, n + 2 :] == -5.0)
+    assert float((got[:, 2 : n + 2] - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_linear_with_packed_activation_operand(lib, gpu_device):
+    """A B^T of two activation matrices through pack_rows (score GEMM, superglue.py:257-258)."""
+    a, b = torch.randn((150, 256)), torch.randn((90, 256))
+    ref = (a @ b.T) / 16.0
+    ad, bd = a.to(gpu_device), b.to(gpu_device)
+    packed = torch.empty(lib.gtsfm_packed_linear_floats(256, 90), dtype=torch.float32, device=gpu_device)
+    _check(lib, lib.gtsfm_pack_rows_f32(bd.data_ptr(), 256, 90, None, 256, packed.data_ptr(), _stream()))
+    out = torch.empty((150, 90), device=gpu_device)
+    _check(lib, lib.gtsfm_linear_f32(ad.data_ptr(), 256, 150, None, 256, packed.data_ptr(), None, 90, out.data_ptr(), 90, 0, None,
+                                     0, 1.0 / 16.0, 0, _stream()))
+    torch.cuda.synchronize()
+    assert float((out.cpu() - ref).abs().max()) < 2e-5
+
+
+def test_softmax_depth_to_space(lib, gpu_device):
+    """superpoint.py:163-166."""
+    logits = torch.randn((2, 7, 9, 65)) * 4
+    s = F.softmax(logits.permute(0, 3, 1, 2), 1)[:, :-1]
+    b, _, h, w = s.shape
+    ref = s.permute(0, 2, 3, 1).reshape(b, h, w, 8, 8).permute(0, 1, 3, 2, 4).reshape(b, h * 8, w * 8)
+    ld = logits.to(gpu_device)
+    out = torch.empty((2, 56, 72), device=gpu_device)
+    _check(lib, lib.gtsfm_sp_softmax_d2s(ld.data_ptr(), 65, 2, 7, 9, out.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    assert float((out.cpu() - ref).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("h,w,radius", [(64, 96, 4), (33, 70, 4), (40, 40, 0), (50, 31, 2), (9, 9, 4), (130, 67, 8)])
+def test_simple_nms_bit_exact(lib, gpu_device, h, w, radius):
+    """superpoint.py:47-62: comparison-only -> bit-exact, incl. ties (quantised scores) and non-tile sizes."""
+    gen = torch.Generator().manual_seed(h * w + radius)
+    scores = torch.rand((2, h, w), generator=gen)
+    scores[1] = torch.round(scores[1] * 8) / 8  # many exact ties
+    ref = spo.simple_nms(scores, radius)
+    sdv = scores.to(gpu_device)
+    scratch = torch.empty(lib.gtsfm_sp_nms_scratch_bytes(2, h, w), dtype=torch.uint8, device=gpu_device)
+    out = torch.empty_like(sdv)
+    _check(lib, lib.gtsfm_sp_simple_nms(sdv.data_ptr(), 2, h, w, radius, scratch.data_ptr(), out.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("h,w,border,capacity", [(40, 72, 4, 4096), (40, 72, 4, 17), (16, 16, 0, 512), (8, 200, 4, 512), (1100, 70, 3, 9000)])
+def test_extract_keypoints_bit_exact(lib, gpu_device, h, w, border, capacity):
+    """superpoint.py:170-178,187: row-major nonzero order, border removal, (x, y) float flip; capacity clamp."""
+    gen = torch.Generator().manual_seed(h + w)
+    nms = torch.rand((3, h, w), generator=gen)
+    nms[nms < 0.9] = 0.0
+    nms[2] = 0.0  # an image with no keypoints
+    thr = 0.92
+    scratch = torch.empty((3 * h * 2 + 3,), dtype=torch.int32, device=gpu_device)
+    count = torch.empty(3, dtype=torch.int32, device=gpu_device)
+    raw = torch.empty(3, dtype=torch.int32, device=gpu_device)
+    xy = torch.zeros((3, capacity, 2), device=gpu_device)
+    sc = torch.zeros((3, capacity), device=gpu_device)
+    nd = nms.to(gpu_device)
+    _check(lib, lib.gtsfm_sp_extract_keypoints(nd.data_ptr(), 3, h, w, thr, border, capacity, scratch.data_ptr(), count.data_ptr(),
+                                               raw.data_ptr(), xy.data_ptr(), sc.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    for b in range(3):
+        kp = torch.nonzero(nms[b] > thr)
+        s = nms[b][tuple(kp.t())]
+        kp, s = spo.remove_borders(kp, s, border, h, w)
+        kp = torch.flip(kp, [1]).float()
+        assert int(raw[b]) == kp.shape[0]
+        k = min(kp.shape[0], capacity)
+        assert int(count[b]) == k
+        assert torch.equal(xy[b, :k].cpu(), kp[:k]) and torch.equal(sc[b, :k].cpu(), s[:k])
+
+
+def test_sample_descriptors(lib, gpu_device):
+    """superpoint.py:80-92,192,195-196 with align_corners=True; corner cells and border keypoints included."""
+    hc, wc = 9, 13
+    dense = torch.randn((2, 256, hc, wc))
+    kp = torch.stack([torch.randint(0, wc * 8, (2, 300)).float(), torch.randint(0, hc * 8, (2, 300)).float()], -1)
+    kp[0, 0] = torch.tensor([0.0, 0.0])
+    kp[0, 1] = torch.tensor([wc * 8 - 1.0, hc * 8 - 1.0])
+    count = torch.tensor([300, 123], dtype=torch.int32)
+    dd = dense.permute(0, 2, 3, 1).reshape(2, hc * wc, 256).contiguous().to(gpu_device)
+    out = torch.full((2, 300, 256), float("nan"), device=gpu_device)
+    kd, cd = kp.to(gpu_device), count.to(gpu_device)
+    _check(lib, lib.gtsfm_sp_sample_descriptors(dd.data_ptr(), 256, 2, hc, wc, kd.data_ptr(), cd.data_ptr(), 300, out.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    for b in range(2):
+        ref = spo.sample_descriptors(kp[b : b + 1], F.normalize(dense[b : b + 1], p=2, dim=1), 8)[0].T
+        k = int(count[b])
+        assert float((out[b, :k].cpu() - ref[:k]).abs().max()) < 2e-6
+        assert torch.isnan(out[b, k:]).all()  # rows beyond the count are untouched
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# end to end
+# ------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("path", sorted(GOLDEN.glob("superpoint_*.npz")), ids=lambda p: p.stem)
+def test_end_to_end_matches_golden(engine, path):
+    """Whole model vs the golden vectors produced by the reference's own superpoint.py."""
+    g = np.load(path)
+    gray = synthetic.synthetic_gray_image(int(g["height"]), int(g["width"]), int(g["seed"]))
+    xy, sc, de = engine.detect(gray)
+    np.testing.assert_array_equal(xy.astype(np.int32), g["keypoints"])  # bit-exact keypoints, row-major order
+    assert xy.dtype == np.float32 and np.array_equal(xy, g["keypoints"].astype(np.float32))
+    np.testing.assert_allclose(sc, g["scores"], rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(de, g["descriptors"], rtol=0, atol=DESC_TOL)
+
+
+@pytest.mark.parametrize("h,w,seed", [(480, 640, 21), (203, 331, 22), (64, 64, 23)])
+def test_end_to_end_matches_oracle(engine, sd, h, w, seed):
+    """Config-2-shaped image (480x640) and ragged sizes vs the oracle, incl. dense score / NMS maps."""
+    gray = synthetic.synthetic_gray_image(h, w, seed)
+    out = engine.forward(torch.from_numpy(gray).to(engine.device)[None], return_score_maps=True)
+    with torch.no_grad():
+        ora = spo.superpoint_forward(sd, spo.gray_u8_to_tensor(gray), return_intermediates=True)
+    k = int(out["count"][0])
+    assert k == ora["keypoints"].shape[0] == int(out["count_raw"][0])
+    assert torch.equal(out["xy"][0, :k].cpu(), ora["keypoints"])
+    assert float((out["dense_scores"][0].cpu() - ora["dense_scores"][0]).abs().max()) < SCORE_TOL
+    assert torch.equal(out["nms_scores"][0].cpu() > 0, ora["nms_scores"][0] > 0)
+    assert float((out["scores"][0, :k].cpu() - ora["scores"]).abs().max()) < SCORE_TOL
+    assert float((out["descriptors"][0, :k].cpu() - ora["descriptors"].T).abs().max()) < DESC_TOL
+
+
+def test_batch_equals_single_and_u8_equals_float(engine):
+    """Batched launch == per-image launches (bit-exact); uint8 input == astype(float32)/255 input (bit-exact)."""
+    imgs = np.stack([synthetic.synthetic_gray_image(96, 136, s) for s in (31, 32, 33)])
+    dev = engine.device
+    batched = engine.forward(torch.from_numpy(imgs).to(dev))
+    as_float = engine.forward(torch.from_numpy(imgs.astype(np.float32) / 255.0).to(dev))
+    for key in ("count", "xy", "scores"):
+        assert torch.equal(batched[key], as_float[key]) or key != "count"
+    for i in range(3):
+        single = engine.forward(torch.from_numpy(imgs[i : i + 1]).to(dev))
+        k = int(single["count"][0])
+        assert k == int(batched["count"][i]) == int(as_float["count"][i]) and k > 0
+        for key in ("xy", "scores", "descriptors"):
+            assert torch.equal(single[key][0, :k], batched[key][i, :k])
+            assert torch.equal(single[key][0, :k], as_float[key][i, :k])
+
+
+def test_edge_cases(engine):
+    dev = engine.device
+    # smaller than one 8x8 cell -> no keypoints
+    out = engine.forward(torch.zeros((2, 7, 5), dtype=torch.uint8, device=dev))
+    assert out["count"].tolist() == [0, 0]
+    # capacity overflow: clamped count, true count reported, first rows identical
+    gray = synthetic.synthetic_gray_image(160, 160, 41)
+    full = engine.forward(torch.from_numpy(gray).to(dev)[None])
+    k = int(full["count"][0])
+    assert k > 20
+    small = engine.forward(torch.from_numpy(gray).to(dev)[None], capacity=16)
+    assert int(small["count"][0]) == 16 and int(small["count_raw"][0]) == k
+    assert torch.equal(small["xy"][0], full["xy"][0, :16]) and torch.equal(small["descriptors"][0], full["descriptors"][0, :16])
+    # workspace-size validation goes through the error string
+    from gtsfm_amd.runtime import lib as L
+
+    lib = L.load()
+    img = torch.from_numpy(gray).to(dev)[None]
+    tiny = torch.empty(1024, dtype=torch.uint8, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    buf = torch.empty((1, 16, 256), device=dev)
+    rc = lib.gtsfm_sp_forward(engine.weights.data_ptr(), img.data_ptr(), 1, 1, 160, 160, 0.005, 4, 4, 16, tiny.data_ptr(), tiny.numel(),
+                              cnt.data_ptr(), None, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), None, None, _stream())
+    assert rc == -3 and b"workspace" in lib.gtsfm_last_error()
+
+
+def test_full_size_properties(engine):
+    """BASELINE config-3 image size (1024x1024): size-independent properties of the detector output --
+    determinism, row-major sortedness, border removal, NMS separation, unit-norm descriptors, threshold."""
+    gray = synthetic.synthetic_gray_image(1024, 1024, 7)
+    img = torch.from_numpy(gray).to(engine.device)[None]
+    a = engine.forward(img)
+    b = engine.forward(img)
+    k = int(a["count"][0])
+    assert k == int(b["count"][0]) and 1000 < k < 20000
+    for key in ("xy", "scores", "descriptors"):
+        assert torch.equal(a[key][0, :k], b[key][0, :k])  # deterministic (tests/repro_tests analogue)
+    xy = a["xy"][0, :k].cpu().numpy().astype(np.int64)
+    lin = xy[:, 1] * 1024 + xy[:, 0]
+    assert np.all(np.diff(lin) > 0)  # torch.nonzero order
+    assert xy.min() >= 4 and xy[:, 0].max() < 1020 and xy[:, 1].max() < 1020  # remove_borders(4)
+    assert float(a["scores"][0, :k].min()) > 0.005
+    norms = a["descriptors"][0, :k].norm(dim=1).cpu().numpy()
+    np.testing.assert_allclose(norms, 1.0, atol=1e-5)
+    # NMS radius 4: no two survivors within Chebyshev distance 4 unless their scores tie exactly
+    grid = -np.ones((1024, 1024), dtype=np.int64)
+    grid[xy[:, 1], xy[:, 0]] = np.arange(k)
+    sc = a["scores"][0, :k].cpu().numpy()
+    for dy in range(0, 5):
+        for dx in range(-4, 5):
+            if dy == 0 and dx <= 0:
+                continue
+            y2, x2 = xy[:, 1] + dy, xy[:, 0] + dx
+            ok = (y2 < 1024) & (x2 >= 0) & (x2 < 1024)
+            nb = grid[y2[ok], x2[ok]]
+            hit = nb >= 0
+            assert np.all(sc[np.flatnonzero(ok)[hit]] == sc[nb[hit]])
+
+
+def test_plugin_matches_oracle_wrapper(gpu_device, sd, tmp_path):
+    """SuperPointDetectorDescriptor.detect_and_describe vs the restated reference wrapper
+    (gtsfm/frontend/detector_descriptor/superpoint.py:63-93), incl. mask filtering and top-k selection, plus the
+    reference's API-contract checks (tests/frontend/detector_descriptor/test_detector_descriptor_base.py:29-42)."""
+    from gtsfm_amd.common.image import Image
+    from gtsfm_amd.frontend.detector_descriptor.superpoint import SuperPointDetectorDescriptor
+
+    path = tmp_path / "superpoint_v1.pth"
+    torch.save(sd, str(path))
+    gray = synthetic.synthetic_gray_image(240, 320, 3)
+    rgb = np.stack([gray, gray, gray], -1)  # gray-valued RGB: the fixed-point gray conversion is the identity
+    mask = np.zeros((240, 320), dtype=np.uint8)
+    mask[20:200, 30:300] = 1
+    for max_kp, use_mask in [(5000, False), (200, False), (150, True)]:
+        det = SuperPointDetectorDescriptor(max_keypoints=max_kp, weights_path=path)
+        kps, desc = det.detect_and_describe(Image(value_array=rgb, mask=mask if use_mask else None))
+        rc, rs, rd = spo.detect_and_describe(sd, gray, max_keypoints=max_kp, mask=mask if use_mask else None)
+        assert len(kps) <= max_kp and len(kps) == desc.shape[0] == len(rc)
+        assert kps.coordinates.dtype == np.float32 and desc.dtype == np.float32 and kps.scales is None
+        assert (kps.coordinates[:, 0] >= 0).all() and (kps.coordinates[:, 0] < 320).all()
+        assert (kps.coordinates[:, 1] >= 0).all() and (kps.coordinates[:, 1] < 240).all()
+        # same selection as the reference wrapper (argpartition order is implementation-defined: compare as sets,
+        # then row by row after sorting both by pixel index)
+        oa = np.lexsort((kps.coordinates[:, 0], kps.coordinates[:, 1]))
+        ob = np.lexsort((rc[:, 0], rc[:, 1]))
+        np.testing.assert_array_equal(kps.coordinates[oa], rc[ob])
+        np.testing.assert_allclose(kps.responses[oa], rs[ob], rtol=0, atol=SCORE_TOL)
+        np.testing.assert_allclose(desc[oa], rd[ob], rtol=0, atol=DESC_TOL)
