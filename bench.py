@@ -98,7 +98,7 @@ def cpu_baseline(h: int, w: int, n_images: int, matcher: str, n_keypoints: int, 
     container) on a bounded sample: ``n_images`` detections and one pair match, on all host cores."""
     from oracle import superpoint_oracle
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, int(os.environ.get("GTSFM_CPU_BASELINE_THREADS", "16")))
     torch.set_num_threads(cores)
     sd = synthetic.synthetic_superpoint_state_dict()
     t_det = []

@@ -78,6 +78,10 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} not found: the HIP extension has not been built. Run `python -m gtsfm_amd.csrc.build` "
                 "(or __graft_entry__.build()). gtsfm_amd has no CPU / PyTorch fallback."
             )
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; import it first so that this library binds to the SAME HIP
+        # runtime instance (one device context, shared streams) instead of pulling in /opt/rocm's copy.
+        import torch  # noqa: F401
+
         lib = C.CDLL(str(LIB_PATH))
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)
