@@ -1,0 +1,153 @@
+// Multi-head softmax attention on exact-fp32 MFMA for gfx950 (flash-style: the N x M probability tensor is never
+// materialised). One kernel serves
+//   SuperGlue self/cross attention    thirdparty/SuperGluePretrainedNetwork/models/superglue.py:85-89,98-106
+//   LightGlue self attention (after rotary) and both directions of its bidirectional cross attention
+// Inputs are token-major [tokens][channels] with head h occupying channels [64h, 64h+64) (SuperGlue's
+// "head = fast axis" layout is removed by permuting the projection weights at load time).
+//
+// Tiling (head_dim = 64): workgroup = 4 waves = 128 queries of one head of one problem; each wave owns 32 queries and
+// walks the keys in tiles of 64 staged through LDS (K as [key][d], V transposed as [d][key], row stride 68 floats).
+// The score tile is computed TRANSPOSED, S^T[key][q] = K Q^T, so that a query is a lane: the softmax row reductions
+// are in-register (+ one cross-half shuffle), and the exponentiated accumulator registers are directly the B operand
+// of the second product O^T[d][q] += V^T[d][key] P^T[key][q] -- no LDS round trip for P, no layout shuffles.
+// Per 64-key tile and wave: 64 + 64 v_mfma_f32_32x32x2_f32.
+
+#include "attention_kernels.h"
+#include "mfma_tiles.h"
+
+#define AT_KT 64       // keys per tile
+#define AT_QW 32       // queries per wave
+#define AT_QB 128      // queries per workgroup
+#define AT_ROW 68      // LDS row stride (floats)
+
+__global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float Ks[AT_KT * AT_ROW];
+    __shared__ __attribute__((aligned(16))) float Vt[64 * AT_ROW];
+    const AttnProblem pr = p.problems[blockIdx.z];
+    const int nq = p.counts[pr.q_cnt_idx], nk = p.counts[pr.k_cnt_idx];
+    const int q0 = blockIdx.x * AT_QB;
+    if (q0 >= nq) return;
+    const int h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kh = lane >> 5;
+    const int qrow = q0 + wave * AT_QW + j;
+    const bool qvalid = qrow < nq;
+
+    // Q fragment (B operand of S^T = K Q^T): lane (q = j, kh) holds Q[q][8t + 4kh .. +3], t = 0..7
+    f32x4 qreg[8];
+    {
+        const float* qp = p.q + (size_t)(pr.q_off + (qvalid ? qrow : 0)) * p.ldq + h * 64 + kh * 4;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(qp + t * 8);
+            if (!qvalid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            qreg[t] = v;
+        }
+    }
+    f32x16 o0, o1;  // O^T: rows d 0..31 / 32..63, column q
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    float m = -__builtin_inff(), l = 0.f;
+
+    const float* kbase = p.k + (size_t)pr.k_off * p.ldk + h * 64;
+    const float* vbase = p.v + (size_t)pr.k_off * p.ldv + h * 64;
+
+    for (int k0 = 0; k0 < nk; k0 += AT_KT) {
+        __syncthreads();
+        // stage K tile [key][d]: 64 rows x 16 float4
+        for (int idx = tid; idx < AT_KT * 16; idx += 256) {
+            const int row = idx >> 4, q4 = idx & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + row < nk) v = *reinterpret_cast<const f32x4*>(kbase + (size_t)(k0 + row) * p.ldk + q4 * 4);
+            *reinterpret_cast<f32x4*>(&Ks[row * AT_ROW + q4 * 4]) = v;
+        }
+        // stage V tile transposed [d][key]: item = (d, group of 4 keys); global reads coalesced along d
+        for (int idx = tid; idx < 64 * 16; idx += 256) {
+            const int d = idx & 63, kg = idx >> 6;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = k0 + kg * 4 + e;
+                v[e] = (key < nk) ? vbase[(size_t)key * p.ldv + d] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(&Vt[d * AT_ROW + kg * 4]) = v;
+        }
+        __syncthreads();
+
+        // S^T = K Q^T  (two 32-key tiles)
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Ks[j * AT_ROW + t * 8 + kh * 4]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Ks[(32 + j) * AT_ROW + t * 8 + kh * 4]);
+            mt_step(s0, s1, a0, a1, qreg[t]);
+        }
+        // scale, mask, online softmax (per query = per lane; the two lane halves hold different keys of the same query)
+        float mloc = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            s0[r] = (key < nk) ? s0[r] * p.scale : -__builtin_inff();
+            s1[r] = (key + 32 < nk) ? s1[r] * p.scale : -__builtin_inff();
+            mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(m, mloc);  // finite: key k0 is always valid
+        const float alpha = expf(m - mnew);
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = expf(s0[r] - mnew);
+            s1[r] = expf(s1[r] - mnew);
+            lsum += s0[r] + s1[r];
+        }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l = l * alpha + lsum;
+        m = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= alpha;
+            o1[r] *= alpha;
+        }
+        // O^T += V^T P^T : accumulator register r of S^T tile T holds key 32T + (r&3) + 8(r>>2) + 4kh -> it IS the B
+        // operand of k-step r; the A operand reads the matching 4 consecutive keys of V^T with one ds_read_b128.
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Vt[j * AT_ROW + 8 * g + 4 * kh]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Vt[(32 + j) * AT_ROW + 8 * g + 4 * kh]);
+            const f32x4 b = {s0[4 * g], s0[4 * g + 1], s0[4 * g + 2], s0[4 * g + 3]};
+            mt_step(o0, o1, a0, a1, b);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Vt[j * AT_ROW + 32 + 8 * g + 4 * kh]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Vt[(32 + j) * AT_ROW + 32 + 8 * g + 4 * kh]);
+            const f32x4 b = {s1[4 * g], s1[4 * g + 1], s1[4 * g + 2], s1[4 * g + 3]};
+            mt_step(o0, o1, a0, a1, b);
+        }
+    }
+
+    if (!qvalid) return;
+    const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+    float* op = p.out + (size_t)(pr.q_off + qrow) * p.ldo + h * 64 + kh * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v0 = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+        const f32x4 v1 = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+        *reinterpret_cast<f32x4*>(op + 8 * g) = v0;
+        *reinterpret_cast<f32x4*>(op + 32 + 8 * g) = v1;
+    }
+}
+
+int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t stream) {
+    GTSFM_CHECK_ARG(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldo % 4 == 0, "attention: leading dimensions must be multiples of 4");
+    GTSFM_CHECK_ARG(p.heads > 0, "attention: heads must be positive");
+    if (nproblems <= 0 || max_q <= 0) return GTSFM_OK;
+    dim3 grid(ceil_div(max_q, AT_QB), p.heads, nproblems);
+    hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(256), 0, stream, p);
+    GTSFM_CHECK_LAUNCH("attention_mfma_kernel");
+    return GTSFM_OK;
+}

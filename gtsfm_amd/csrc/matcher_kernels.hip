@@ -1,0 +1,495 @@
+// Matcher kernels that are not GEMMs: keypoint encoding inputs, rotary embedding, LayerNorm+GELU, log-space Sinkhorn,
+// LightGlue's double-softmax assignment, mutual-nearest-neighbour match extraction, point pruning.
+// Replaces the ATen op sequences of
+//   thirdparty/SuperGluePretrainedNetwork/models/superglue.py:63-70 (normalize_keypoints), :141-170 (optimal
+//   transport), :266-276 (match extraction)
+// and of upstream cvg/LightGlue lightglue.py (normalize_keypoints, LearnableFourierPositionalEncoding,
+// apply_cached_rotary_emb, the FFN's LayerNorm+GELU, sigmoid_log_double_softmax, filter_matches, pruning).
+// These are HBM/L2-bound sweeps: coalesced rows, wave-shuffle reductions, one pass over the score matrix per
+// Sinkhorn iteration. Built with -ffp-contract=off.
+
+#include "matcher_kernels.h"
+
+__device__ __forceinline__ float neg_inf() { return -__builtin_inff(); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Keypoint inputs
+// ---------------------------------------------------------------------------------------------------------------
+
+// SuperGlue: enc_in[t] = [(x - W/2) / (0.7 max(W,H)), (y - H/2) / (0.7 max(W,H)), score, 0, 0, 0, 0, 0]
+__global__ void sg_encode_input_kernel(const float* __restrict__ kpts, const float* __restrict__ scores, const SeqDesc* __restrict__ seqs,
+                                       const int* __restrict__ counts, int nseq, float* __restrict__ enc_in) {
+    const int s = blockIdx.y;
+    const SeqDesc sq = seqs[s];
+    const int n = counts[sq.cnt_idx];
+    const float w = (float)sq.W, h = (float)sq.H;
+    const float cx = w / 2.0f, cy = h / 2.0f;
+    const float scaling = fmaxf(w, h) * 0.7f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const size_t t = (size_t)sq.row_off + i;
+        float* o = enc_in + t * 8;
+        o[0] = (kpts[t * 2 + 0] - cx) / scaling;
+        o[1] = (kpts[t * 2 + 1] - cy) / scaling;
+        o[2] = scores[t];
+        o[3] = o[4] = o[5] = o[6] = o[7] = 0.f;
+    }
+}
+
+// LightGlue: normalised keypoints (k - size/2) / (max(size)/2) -> Fourier features cos/sin(Wr k): enc[t] = [cos(32) | sin(32)]
+__global__ void lg_posenc_kernel(const float* __restrict__ kpts, const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
+                                 const float* __restrict__ Wr /*[32][2]*/, float* __restrict__ enc /*[T][64]*/) {
+    const int s = blockIdx.y;
+    const SeqDesc sq = seqs[s];
+    const int n = counts[sq.cnt_idx];
+    const float w = (float)sq.W, h = (float)sq.H;
+    const float sx = w / 2.0f, sy = h / 2.0f;
+    const float scale = fmaxf(w, h) / 2.0f;
+    const int f = threadIdx.x & 31;
+    const float w0 = Wr[f * 2 + 0], w1 = Wr[f * 2 + 1];
+    for (int i = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5); i < n; i += gridDim.x * (blockDim.x >> 5)) {
+        const size_t t = (size_t)sq.row_off + i;
+        const float x = (kpts[t * 2 + 0] - sx) / scale;
+        const float y = (kpts[t * 2 + 1] - sy) / scale;
+        const float pr = x * w0 + y * w1;  // F.linear without bias: sum over 2 inputs
+        enc[t * 64 + f] = cosf(pr);
+        enc[t * 64 + 32 + f] = sinf(pr);
+    }
+}
+
+// Rotary embedding on the q and k parts of a packed [T][ld] buffer (head-major, 4 heads x 64):
+//   out[2f] = t[2f] cos_f - t[2f+1] sin_f ; out[2f+1] = t[2f+1] cos_f + t[2f] sin_f     (same freqs for every head)
+__global__ void lg_rotary_kernel(float* __restrict__ qkv, int ld, int ncols /*512: q and k*/, const float* __restrict__ enc,
+                                 const SeqDesc* __restrict__ seqs, const int* __restrict__ counts) {
+    const int s = blockIdx.y;
+    const SeqDesc sq = seqs[s];
+    const int n = counts[sq.cnt_idx];
+    const int pairs_per_row = ncols >> 1;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * pairs_per_row; idx += gridDim.x * blockDim.x) {
+        const int i = idx / pairs_per_row, pp = idx % pairs_per_row;
+        const int f = pp & 31;  // frequency index within the head
+        const size_t t = (size_t)sq.row_off + i;
+        float* x = qkv + t * ld + pp * 2;
+        const float c = enc[t * 64 + f], sn = enc[t * 64 + 32 + f];
+        const float x1 = x[0], x2 = x[1];
+        x[0] = (x1 * c) + ((-x2) * sn);
+        x[1] = (x2 * c) + (x1 * sn);
+    }
+}
+
+// y = GELU(LayerNorm(x)) over rows of 512 (eps 1e-5, affine), in place. One wave per row, 8 elements per lane.
+__global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__ x, int ld, int rows, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* p = x + (size_t)row * ld + lane * 8;
+    f32x4 a = *reinterpret_cast<f32x4*>(p), b = *reinterpret_cast<f32x4*>(p + 4);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += v[e];
+    const float mean = wave_sum(sum) / 512.0f;
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float d = v[e] - mean;
+        sq += d * d;
+    }
+    const float var = wave_sum(sq) / 512.0f;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float y = (v[e] - mean) * rstd * gamma[lane * 8 + e] + beta[lane * 8 + e];
+        v[e] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+    }
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+// out[t] = act(dot(x[t, :256], w) + b): token-confidence and matchability heads (Linear(256, 1)). One wave per token.
+// act: 0 = identity, 1 = sigmoid
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, int ld, int rows, const float* __restrict__ w, float b,
+                                                     int act, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)row * ld + lane * 4);
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(w + lane * 4);
+    float s = a.x * ww.x + a.y * ww.y + a.z * ww.z + a.w * ww.w;
+    s = wave_sum(s) + b;
+    if (act == 1) s = 1.0f / (1.0f + expf(-s));
+    if (lane == 0) out[row] = s;
+}
+
+int launch_sg_encode_input(const float* kpts, const float* scores, const SeqDesc* seqs, const int* counts, int nseq, int max_n,
+                           float* enc_in, hipStream_t stream) {
+    if (nseq <= 0 || max_n <= 0) return GTSFM_OK;
+    hipLaunchKernelGGL(sg_encode_input_kernel, dim3(ceil_div(max_n, 256), nseq), dim3(256), 0, stream, kpts, scores, seqs, counts, nseq, enc_in);
+    GTSFM_CHECK_LAUNCH("sg_encode_input_kernel");
+    return GTSFM_OK;
+}
+
+int launch_lg_posenc(const float* kpts, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* Wr, float* enc,
+                     hipStream_t stream) {
+    if (nseq <= 0 || max_n <= 0) return GTSFM_OK;
+    hipLaunchKernelGGL(lg_posenc_kernel, dim3(ceil_div(max_n, 8), nseq), dim3(256), 0, stream, kpts, seqs, counts, Wr, enc);
+    GTSFM_CHECK_LAUNCH("lg_posenc_kernel");
+    return GTSFM_OK;
+}
+
+int launch_lg_rotary(float* qkv, int ld, int ncols, const float* enc, const SeqDesc* seqs, const int* counts, int nseq, int max_n,
+                     hipStream_t stream) {
+    if (nseq <= 0 || max_n <= 0) return GTSFM_OK;
+    const int blocks = ceil_div(max_n * (ncols / 2), 256);
+    hipLaunchKernelGGL(lg_rotary_kernel, dim3(blocks < 2048 ? blocks : 2048, nseq), dim3(256), 0, stream, qkv, ld, ncols, enc, seqs, counts);
+    GTSFM_CHECK_LAUNCH("lg_rotary_kernel");
+    return GTSFM_OK;
+}
+
+int launch_layernorm_gelu(float* x, int ld, int rows, const float* gamma, const float* beta, hipStream_t stream) {
+    if (rows <= 0) return GTSFM_OK;
+    hipLaunchKernelGGL(layernorm_gelu_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, x, ld, rows, gamma, beta);
+    GTSFM_CHECK_LAUNCH("layernorm_gelu_kernel");
+    return GTSFM_OK;
+}
+
+int launch_rowdot(const float* x, int ld, int rows, const float* w, float b, int act, float* out, hipStream_t stream) {
+    if (rows <= 0) return GTSFM_OK;
+    hipLaunchKernelGGL(rowdot_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, x, ld, rows, w, b, act, out);
+    GTSFM_CHECK_LAUNCH("rowdot_kernel");
+    return GTSFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Score-matrix sweeps. Per pair p the matrix Z lives at zbuf + z_off, (m + EXT) x (n + EXT) with row stride ld,
+// where EXT = 1 for SuperGlue (dustbin row/column, superglue.py:150-170) and 0 for LightGlue. Row vectors (u, row
+// log-sum-exp, ...) are indexed by vec0 + i, column vectors by vec1 + j with vecS = row_off(seq) + seq index.
+//
+// One Sinkhorn iteration (superglue.py:141-147) reads Z ONCE:
+//   rows kernel : a workgroup owns 16 rows; phase A: u_i = log_mu_i - logsumexp_j(Z_ij + v_j) (wave per row, two-pass);
+//                 phase B: column partials (max, sum) of Z_ij + u_i over its 16 rows (L1/L2-hot re-read)
+//   cols kernel : v_j = log_nu_j - logsumexp over the row-block partials
+// LightGlue's double softmax uses the same two kernels once with u = v = 0 and plain log-sum-exp outputs.
+// ---------------------------------------------------------------------------------------------------------------
+
+#define SK_ROWS 16
+
+template <bool SG>
+__global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+                                                       const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
+                                                       float* __restrict__ rowvec, const float* __restrict__ colvec,
+                                                       float* __restrict__ partials) {
+    __shared__ float u_s[SK_ROWS];
+    const int p = blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int rows = m + (SG ? 1 : 0), cols = n + (SG ? 1 : 0);
+    const int r0 = blockIdx.x * SK_ROWS;
+    if (r0 >= rows) return;
+    const float* Z = zbuf + pd.z_off;
+    const int vec0 = s0.row_off + 2 * p, vec1 = s1.row_off + 2 * p + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float norm = SG ? -logf((float)m + (float)n) : 0.f;
+    // phase A: each wave reduces 4 rows
+    for (int rr = wave; rr < SK_ROWS; rr += 4) {
+        const int i = r0 + rr;
+        float ui = 0.f;
+        if (i < rows) {
+            const float* zr = Z + (size_t)i * pd.ld;
+            float mx = neg_inf();
+            for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, SG ? zr[j] + colvec[vec1 + j] : zr[j]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int j = lane; j < cols; j += 64) sum += expf((SG ? zr[j] + colvec[vec1 + j] : zr[j]) - mx);
+            sum = wave_sum(sum);
+            const float lse = logf(sum) + mx;
+            if (SG) {
+                const float log_mu = (i < m) ? norm : logf((float)n) + norm;
+                ui = log_mu - lse;
+            } else {
+                ui = lse;
+            }
+            if (lane == 0) rowvec[vec0 + i] = ui;
+        }
+        if (lane == 0) u_s[rr] = ui;
+    }
+    __syncthreads();
+    // phase B: column partials over this block's rows
+    const int nr = min(SK_ROWS, rows - r0);
+    float* part = partials + pd.part_off + (size_t)blockIdx.x * pd.ld * 2;
+    for (int j = threadIdx.x; j < cols; j += 256) {
+        float mx = neg_inf();
+        float vals[SK_ROWS];
+#pragma unroll
+        for (int rr = 0; rr < SK_ROWS; ++rr) {
+            float v = neg_inf();
+            if (rr < nr) v = SG ? Z[(size_t)(r0 + rr) * pd.ld + j] + u_s[rr] : Z[(size_t)(r0 + rr) * pd.ld + j];
+            vals[rr] = v;
+            mx = fmaxf(mx, v);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < SK_ROWS; ++rr) sum += (rr < nr) ? expf(vals[rr] - mx) : 0.f;
+        part[(size_t)j * 2 + 0] = mx;
+        part[(size_t)j * 2 + 1] = sum;
+    }
+}
+
+template <bool SG>
+__global__ __launch_bounds__(256) void lse_cols_kernel(const PairDesc* __restrict__ pairs, const SeqDesc* __restrict__ seqs,
+                                                       const int* __restrict__ counts, const float* __restrict__ partials,
+                                                       float* __restrict__ colvec) {
+    const int p = blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int rows = m + (SG ? 1 : 0), cols = n + (SG ? 1 : 0);
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    const int nblk = ceil_div(rows, SK_ROWS);
+    const float* part = partials + pd.part_off + (size_t)j * 2;
+    float mx = neg_inf(), sum = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        const float pm = part[(size_t)b * pd.ld * 2 + 0], ps = part[(size_t)b * pd.ld * 2 + 1];
+        const float nm = fmaxf(mx, pm);
+        sum = sum * expf(mx - nm) + ps * expf(pm - nm);
+        mx = nm;
+    }
+    const float lse = logf(sum) + mx;
+    const int vec1 = s1.row_off + 2 * p + 1;
+    if (SG) {
+        const float norm = -logf((float)m + (float)n);
+        const float log_nu = (j < n) ? norm : logf((float)m) + norm;
+        colvec[vec1 + j] = log_nu - lse;
+    } else {
+        colvec[vec1 + j] = lse;
+    }
+}
+
+// SuperGlue couplings: dustbin row / column = bin_score, v = 0 (superglue.py:156-160,143)
+__global__ void sg_fill_bins_kernel(float* __restrict__ zbuf, const PairDesc* __restrict__ pairs, const SeqDesc* __restrict__ seqs,
+                                    const int* __restrict__ counts, float alpha, float* __restrict__ colvec) {
+    const int p = blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    float* Z = zbuf + pd.z_off;
+    const int vec1 = s1.row_off + 2 * p + 1;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= max(m, n); t += gridDim.x * blockDim.x) {
+        if (t <= m) Z[(size_t)t * pd.ld + n] = alpha;
+        if (t <= n) {
+            Z[(size_t)m * pd.ld + t] = alpha;
+            colvec[vec1 + t] = 0.f;
+        }
+    }
+}
+
+// Element value of the final assignment matrix.
+//   SG: ((Z + u_i) + v_j) - norm                                   (superglue.py:147,169)
+//   LG: ((sim - rowlse_i) + (sim - collse_j)) + (c0_i + c1_j)      (sigmoid_log_double_softmax)
+template <bool SG>
+__device__ __forceinline__ float assign_value(float z, float a_i, float b_j, float norm, float c_i, float c_j) {
+    if (SG) return ((z + a_i) + b_j) - norm;
+    return ((z - a_i) + (z - b_j)) + (c_i + c_j);
+}
+
+__device__ __forceinline__ float logsigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+
+// Row-wise max / first-argmax over the inner m x n block. One wave per row.
+template <bool SG>
+__global__ __launch_bounds__(256) void best_rows_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+                                                        const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
+                                                        const float* __restrict__ rowvec, const float* __restrict__ colvec,
+                                                        const float* __restrict__ zlogit, float* __restrict__ max0,
+                                                        int* __restrict__ idx0) {
+    const int p = blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const int lane = threadIdx.x & 63;
+    const float* zr = zbuf + pd.z_off + (size_t)i * pd.ld;
+    const int vec0 = s0.row_off + 2 * p, vec1 = s1.row_off + 2 * p + 1;
+    const float norm = SG ? -logf((float)m + (float)n) : 0.f;
+    const float a_i = rowvec[vec0 + i];
+    const float c_i = SG ? 0.f : logsigmoid(zlogit[s0.row_off + i]);
+    float best = neg_inf();
+    int bj = 0x7fffffff;
+    for (int j = lane; j < n; j += 64) {
+        const float c_j = SG ? 0.f : logsigmoid(zlogit[s1.row_off + j]);
+        const float v = assign_value<SG>(zr[j], a_i, colvec[vec1 + j], norm, c_i, c_j);
+        if (v > best) {
+            best = v;
+            bj = j;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oj = __shfl_xor(bj, off, 64);
+        if (ob > best || (ob == best && oj < bj)) {
+            best = ob;
+            bj = oj;
+        }
+    }
+    if (lane == 0) {
+        max0[s0.row_off + i] = best;
+        idx0[s0.row_off + i] = bj;
+    }
+}
+
+// Column-wise max / first-argmax. Block = 64 columns x 4 row groups.
+template <bool SG>
+__global__ __launch_bounds__(256) void best_cols_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+                                                        const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
+                                                        const float* __restrict__ rowvec, const float* __restrict__ colvec,
+                                                        const float* __restrict__ zlogit, int* __restrict__ idx1) {
+    __shared__ float bv[4][64];
+    __shared__ int bi[4][64];
+    const int p = blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= n) return;
+    const float* Z = zbuf + pd.z_off;
+    const int vec0 = s0.row_off + 2 * p, vec1 = s1.row_off + 2 * p + 1;
+    const float norm = SG ? -logf((float)m + (float)n) : 0.f;
+    float best = neg_inf();
+    int bidx = 0x7fffffff;
+    if (j < n) {
+        const float b_j = colvec[vec1 + j];
+        const float c_j = SG ? 0.f : logsigmoid(zlogit[s1.row_off + j]);
+        for (int i = rg; i < m; i += 4) {
+            const float c_i = SG ? 0.f : logsigmoid(zlogit[s0.row_off + i]);
+            const float v = assign_value<SG>(Z[(size_t)i * pd.ld + j], rowvec[vec0 + i], b_j, norm, c_i, c_j);
+            if (v > best) {
+                best = v;
+                bidx = i;
+            }
+        }
+    }
+    bv[rg][lane] = best;
+    bi[rg][lane] = bidx;
+    __syncthreads();
+    if (rg == 0 && j < n) {
+#pragma unroll
+        for (int g = 1; g < 4; ++g) {
+            const float ob = bv[g][lane];
+            const int oi = bi[g][lane];
+            if (ob > best || (ob == best && oi < bidx)) {
+                best = ob;
+                bidx = oi;
+            }
+        }
+        idx1[s1.row_off + j] = bidx;
+    }
+}
+
+// Mutual check, exp, threshold (superglue.py:268-276; LightGlue filter_matches). matches are -1 when invalid.
+__global__ void mutual_matches_kernel(const SeqDesc* __restrict__ seqs, const int* __restrict__ counts, const float* __restrict__ max0,
+                                      const int* __restrict__ idx0, const int* __restrict__ idx1, float threshold,
+                                      int* __restrict__ matches, float* __restrict__ mscores) {
+    const int p = blockIdx.y;
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < max(m, n); t += gridDim.x * blockDim.x) {
+        if (t < m) {
+            const int j = idx0[s0.row_off + t];
+            const bool mutual = idx1[s1.row_off + j] == t;
+            const float ms = mutual ? expf(max0[s0.row_off + t]) : 0.f;
+            const bool valid = mutual && (ms > threshold);
+            matches[s0.row_off + t] = valid ? j : -1;
+            mscores[s0.row_off + t] = ms;
+        }
+        if (t < n) {
+            const int i = idx1[s1.row_off + t];
+            const bool mutual1 = idx0[s0.row_off + i] == t;
+            const float ms0 = mutual1 ? expf(max0[s0.row_off + i]) : 0.f;  // mutual1 implies mutual0(i)
+            const bool valid = mutual1 && (ms0 > threshold);
+            matches[s1.row_off + t] = valid ? i : -1;
+            mscores[s1.row_off + t] = ms0;
+        }
+    }
+}
+
+// Materialise the final log-assignment matrix (parity tests only): out has the layout of zbuf.
+template <bool SG>
+__global__ void materialize_assignment_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+                                              const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
+                                              const float* __restrict__ rowvec, const float* __restrict__ colvec,
+                                              const float* __restrict__ zlogit, float* __restrict__ out) {
+    const int p = blockIdx.z;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int rows = m + (SG ? 1 : 0), cols = n + (SG ? 1 : 0);
+    const int i = blockIdx.y, vec0 = s0.row_off + 2 * p, vec1 = s1.row_off + 2 * p + 1;
+    if (i >= rows) return;
+    const float norm = SG ? -logf((float)m + (float)n) : 0.f;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < cols; j += gridDim.x * blockDim.x) {
+        const float c_i = SG ? 0.f : logsigmoid(zlogit[s0.row_off + i]);
+        const float c_j = SG ? 0.f : logsigmoid(zlogit[s1.row_off + j]);
+        out[pd.z_off + (size_t)i * pd.ld + j] =
+            assign_value<SG>(zbuf[pd.z_off + (size_t)i * pd.ld + j], rowvec[vec0 + i], colvec[vec1 + j], norm, c_i, c_j);
+    }
+}
+
+int launch_materialize_assignment(const SweepArgs& a, int superglue, const float* zlogit, float* out, hipStream_t stream) {
+    if (a.npairs <= 0) return GTSFM_OK;
+    const int ext = superglue ? 1 : 0;
+    dim3 grid(ceil_div(a.max_n + ext, 256), a.max_m + ext, a.npairs);
+    if (superglue)
+        hipLaunchKernelGGL(materialize_assignment_kernel<true>, grid, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec,
+                           a.colvec, zlogit, out);
+    else
+        hipLaunchKernelGGL(materialize_assignment_kernel<false>, grid, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec,
+                           a.colvec, zlogit, out);
+    GTSFM_CHECK_LAUNCH("materialize_assignment_kernel");
+    return GTSFM_OK;
+}
+
+template <bool SG>
+static int sweep_impl(const SweepArgs& a, int iters, hipStream_t stream) {
+    if (a.npairs <= 0) return GTSFM_OK;
+    const int ext = SG ? 1 : 0;
+    dim3 grid_rows(ceil_div(a.max_m + ext, SK_ROWS), a.npairs);
+    dim3 grid_cols(ceil_div(a.max_n + ext, 256), a.npairs);
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(lse_rows_kernel<SG>, grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec,
+                           a.partials);
+        hipLaunchKernelGGL(lse_cols_kernel<SG>, grid_cols, dim3(256), 0, stream, a.pairs, a.seqs, a.counts, a.partials, a.colvec);
+    }
+    GTSFM_CHECK_LAUNCH("lse_rows/cols_kernel");
+    return GTSFM_OK;
+}
+
+int launch_sinkhorn(const SweepArgs& a, float bin_score, int iters, hipStream_t stream) {
+    if (a.npairs <= 0) return GTSFM_OK;
+    hipLaunchKernelGGL(sg_fill_bins_kernel, dim3(ceil_div(max(a.max_m, a.max_n) + 1, 256), a.npairs), dim3(256), 0, stream, a.zbuf, a.pairs,
+                       a.seqs, a.counts, bin_score, a.colvec);
+    GTSFM_CHECK_LAUNCH("sg_fill_bins_kernel");
+    return sweep_impl<true>(a, iters, stream);
+}
+
+int launch_double_softmax_lse(const SweepArgs& a, hipStream_t stream) { return sweep_impl<false>(a, 1, stream); }
+
+int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogit, float threshold, float* max0, int* idx0, int* idx1,
+                           int* matches, float* mscores, hipStream_t stream) {
+    if (a.npairs <= 0 || a.max_m <= 0 || a.max_n <= 0) return GTSFM_OK;
+    dim3 gr(ceil_div(a.max_m, 4), a.npairs), gc(ceil_div(a.max_n, 64), a.npairs);
+    if (superglue) {
+        hipLaunchKernelGGL(best_rows_kernel<true>, gr, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, zlogit, max0, idx0);
+        hipLaunchKernelGGL(best_cols_kernel<true>, gc, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, zlogit, idx1);
+    } else {
+        hipLaunchKernelGGL(best_rows_kernel<false>, gr, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, zlogit, max0, idx0);
+        hipLaunchKernelGGL(best_cols_kernel<false>, gc, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, zlogit, idx1);
+    }
+    hipLaunchKernelGGL(mutual_matches_kernel, dim3(ceil_div(max(a.max_m, a.max_n), 256), a.npairs), dim3(256), 0, stream, a.seqs, a.counts,
+                       max0, idx0, idx1, threshold, matches, mscores);
+    GTSFM_CHECK_LAUNCH("extract_matches kernels");
+    return GTSFM_OK;
+}

@@ -58,6 +58,21 @@ SIGNATURES = {
         [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_void_p, C.c_void_p],
     ),
+    "gtsfm_blob_floats": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gtsfm_pack_blob": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
+    "gtsfm_match_desc_ints": (C.c_size_t, [C.c_int]),
+    "gtsfm_match_build_desc": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gtsfm_attention_f32": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+         C.c_int, C.c_int, C.c_float, C.c_void_p],
+    ),
+    "gtsfm_sg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p]),
+    "gtsfm_sg_forward": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
     "gtsfm_sp_sample_descriptors": (
         C.c_int,
         [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],

@@ -1,0 +1,199 @@
+"""Host side of the matcher HIP paths (SuperGlue, LightGlue): checkpoint -> logical matrices -> packed blob, ragged
+batch descriptors, workspace management, kernel enqueue. PyTorch provides device memory and streams only.
+
+Weight preparation (done once, on the host, in float64 then rounded to fp32):
+
+SuperGlue (``thirdparty/SuperGluePretrainedNetwork/models/superglue.py``)
+  * eval-mode ``BatchNorm1d`` layers (superglue.py:57-58) are folded into the preceding ``Conv1d``:
+    ``W' = W * g / sqrt(var + eps)``, ``b' = (b - mean) * g / sqrt(var + eps) + beta``
+  * the attention head layout ``view(b, 64, 4, N)`` (superglue.py:104: channel = d*4 + h, head is the FAST axis) is
+    made head-major (channel = h*64 + d) by permuting the rows of the three projections and the columns of ``merge``
+  * the q/k/v projections are fused into one 256 -> 768 matrix
+  blob entry order: kenc (32,3) (64,32) (128,64) (256,128) (256,256); per GNN layer (768,256) (256,256) (512,512)
+  (256,512); final_proj (256,256).
+
+LightGlue (upstream ``cvg/LightGlue`` module names)
+  * ``Wqkv`` rows are regrouped from ``h*192 + d*3 + j`` to ``j*256 + h*64 + d`` (q | k | v, head-major)
+  * the cross block's ``to_qk`` and ``to_v`` are fused into one 256 -> 512 matrix
+  blob entry order: posenc.Wr (raw 64); per layer: Wqkv (768,256), out_proj (256,256), self ffn.0 (512,512), self LN
+  gamma (raw 512), beta (raw 512), self ffn.3 (256,512), cross to_qk|to_v (512,256), to_out (256,256), cross ffn.0,
+  LN gamma, beta, ffn.3, log_assignment final_proj (256,256), matchability w (raw 256), [token_confidence w (raw 256)
+  for all but the last layer]; the two scalar biases per layer travel separately (host floats).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from gtsfm_amd.runtime import lib as _lib
+from gtsfm_amd.runtime.superpoint_engine import require_gpu
+
+BN_EPS = 1e-5
+HEAD_PERM = np.array([(c % 64) * 4 + c // 64 for c in range(256)])  # new channel h*64+d <- old channel d*4+h
+
+Entry = Tuple[int, np.ndarray, Optional[np.ndarray]]  # (kind, W or raw vector, bias)
+
+
+def _f64(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().double().numpy()
+
+
+def pack_blob(entries: Sequence[Entry]) -> np.ndarray:
+    lib = _lib.load()
+    count = len(entries)
+    kinds = np.array([e[0] for e in entries], dtype=np.int32)
+    ws = [np.ascontiguousarray(e[1], dtype=np.float32) for e in entries]
+    bs = [None if e[2] is None else np.ascontiguousarray(e[2], dtype=np.float32) for e in entries]
+    n = np.array([w.shape[0] for w in ws], dtype=np.int32)
+    k = np.array([w.shape[1] if (e[0] == 0) else 0 for w, e in zip(ws, entries)], dtype=np.int32)
+    total = lib.gtsfm_blob_floats(count, kinds.ctypes.data, n.ctypes.data, k.ctypes.data)
+    out = np.empty(total, dtype=np.float32)
+    wp = (C.c_void_p * count)(*[w.ctypes.data for w in ws])
+    bp = (C.c_void_p * count)(*[None if b is None else b.ctypes.data for b in bs])
+    _lib.check(lib.gtsfm_pack_blob(count, kinds.ctypes.data, n.ctypes.data, k.ctypes.data, wp, bp, out.ctypes.data), "gtsfm_pack_blob")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SuperGlue
+# ------------------------------------------------------------------------------------------------------------------
+
+
+def superglue_num_layers(sd: Mapping[str, torch.Tensor]) -> int:
+    return 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("gnn.layers."))
+
+
+def _fold_bn(sd, conv: str, bn: Optional[str]) -> Tuple[np.ndarray, np.ndarray]:
+    w = _f64(sd[f"{conv}.weight"])[:, :, 0]
+    b = _f64(sd[f"{conv}.bias"])
+    if bn is not None:
+        scale = _f64(sd[f"{bn}.weight"]) / np.sqrt(_f64(sd[f"{bn}.running_var"]) + BN_EPS)
+        w = w * scale[:, None]
+        b = (b - _f64(sd[f"{bn}.running_mean"])) * scale + _f64(sd[f"{bn}.bias"])
+    return w, b
+
+
+def superglue_entries(sd: Mapping[str, torch.Tensor]) -> List[Entry]:
+    entries: List[Entry] = []
+    for i in range(5):  # kenc.encoder: conv at 0,3,6,9,12; BN at 1,4,7,10
+        w, b = _fold_bn(sd, f"kenc.encoder.{3 * i}", f"kenc.encoder.{3 * i + 1}" if i < 4 else None)
+        entries.append((0, w, b))
+    for l in range(superglue_num_layers(sd)):
+        p = f"gnn.layers.{l}"
+        ws, bs = [], []
+        for j in range(3):
+            w, b = _fold_bn(sd, f"{p}.attn.proj.{j}", None)
+            ws.append(w[HEAD_PERM]), bs.append(b[HEAD_PERM])
+        entries.append((0, np.concatenate(ws, 0), np.concatenate(bs, 0)))
+        w, b = _fold_bn(sd, f"{p}.attn.merge", None)
+        entries.append((0, w[:, HEAD_PERM], b))
+        entries.append((0, *_fold_bn(sd, f"{p}.mlp.0", f"{p}.mlp.1")))
+        entries.append((0, *_fold_bn(sd, f"{p}.mlp.3", None)))
+    entries.append((0, *_fold_bn(sd, "final_proj", None)))
+    return entries
+
+
+class _MatcherBase:
+    def __init__(self, device: Optional[torch.device]):
+        self.device = require_gpu(device)
+        self._lib = _lib.load()
+        self._workspace: Optional[torch.Tensor] = None
+
+    def _get_workspace(self, nbytes: int) -> torch.Tensor:
+        if self._workspace is None or self._workspace.numel() < nbytes:
+            self._workspace = None
+            self._workspace = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    def _build_desc(self, superglue: bool, n0: np.ndarray, n1: np.ndarray, hw: np.ndarray) -> torch.Tensor:
+        p = len(n0)
+        host = np.empty(self._lib.gtsfm_match_desc_ints(p), dtype=np.int32)
+        _lib.check(
+            self._lib.gtsfm_match_build_desc(int(superglue), p, n0.ctypes.data, n1.ctypes.data, hw.ctypes.data, host.ctypes.data),
+            "gtsfm_match_build_desc",
+        )
+        return torch.from_numpy(host).to(self.device)
+
+
+class SuperGlueEngine(_MatcherBase):
+    """Device-resident SuperGlue (superglue.py:228-283) for ragged batches of pairs."""
+
+    def __init__(self, state_dict: Mapping[str, torch.Tensor], device: Optional[torch.device] = None):
+        super().__init__(device)
+        self.num_layers = superglue_num_layers(state_dict)
+        self.bin_score = float(state_dict["bin_score"])
+        self.weights = torch.from_numpy(pack_blob(superglue_entries(state_dict))).to(self.device)
+
+    def match_batch(
+        self,
+        kpts: torch.Tensor,
+        scores: torch.Tensor,
+        desc: torch.Tensor,
+        n0: Sequence[int],
+        n1: Sequence[int],
+        hw: Sequence[Sequence[int]],
+        sinkhorn_iterations: int = 20,
+        match_threshold: float = 0.2,
+        return_ot: bool = False,
+    ) -> Dict[str, torch.Tensor]:
+        """Token-major device inputs concatenated as pair0/img0, pair0/img1, pair1/img0, ...: kpts [T,2], scores [T],
+        desc [T,256]; n0/n1 per-pair keypoint counts (all > 0); hw per pair (H0, W0, H1, W1).
+        Returns matches [T] int32 (matches0 for img0 rows, matches1 for img1 rows) and mscores [T]."""
+        n0 = np.ascontiguousarray(n0, dtype=np.int32)
+        n1 = np.ascontiguousarray(n1, dtype=np.int32)
+        hw = np.ascontiguousarray(hw, dtype=np.int32).reshape(-1, 4)
+        p = len(n0)
+        t = int(n0.sum() + n1.sum())
+        assert kpts.shape == (t, 2) and scores.shape == (t,) and desc.shape == (t, 256)
+        assert kpts.is_contiguous() and scores.is_contiguous() and desc.is_contiguous()
+        assert kpts.dtype == scores.dtype == desc.dtype == torch.float32
+        dsc = self._build_desc(True, n0, n1, hw)
+        ws = self._get_workspace(self._lib.gtsfm_sg_workspace_bytes(p, n0.ctypes.data, n1.ctypes.data))
+        matches = torch.empty(t, dtype=torch.int32, device=self.device)
+        mscores = torch.empty(t, dtype=torch.float32, device=self.device)
+        ot = None
+        if return_ot:
+            zf = sum((int(a) + 1) * ((int(b) + 1 + 3) // 4 * 4) for a, b in zip(n0, n1))
+            ot = torch.empty(zf, dtype=torch.float32, device=self.device)
+        rc = self._lib.gtsfm_sg_forward(
+            self.weights.data_ptr(), self.num_layers, self.bin_score, p, n0.ctypes.data, n1.ctypes.data, dsc.data_ptr(),
+            kpts.data_ptr(), scores.data_ptr(), desc.data_ptr(), int(sinkhorn_iterations), float(match_threshold),
+            ws.data_ptr(), ws.numel(), matches.data_ptr(), mscores.data_ptr(), _lib.ptr(ot),
+            torch.cuda.current_stream(self.device).cuda_stream,
+        )
+        _lib.check(rc, "gtsfm_sg_forward")
+        out = {"matches": matches, "mscores": mscores, "_desc": dsc}
+        if return_ot:
+            out["ot"] = ot
+        return out
+
+    def match_pair(
+        self, k0: np.ndarray, s0: np.ndarray, d0: np.ndarray, k1: np.ndarray, s1: np.ndarray, d1: np.ndarray,
+        shape0: Tuple[int, int], shape1: Tuple[int, int], sinkhorn_iterations: int = 20, match_threshold: float = 0.2,
+        return_ot: bool = False,
+    ) -> Dict[str, np.ndarray]:
+        """One pair from host arrays -> matches0 [n0] int64, matches1 [n1] int64, matching_scores0/1 (superglue.py
+        output dict), with the empty-input early-out of superglue.py:233-240."""
+        n0, n1 = len(k0), len(k1)
+        if n0 == 0 or n1 == 0:
+            return {
+                "matches0": np.full(n0, -1, dtype=np.int32), "matches1": np.full(n1, -1, dtype=np.int32),
+                "matching_scores0": np.zeros(n0, dtype=np.float32), "matching_scores1": np.zeros(n1, dtype=np.float32),
+            }
+        dev = self.device
+        f = lambda a, b: torch.from_numpy(np.ascontiguousarray(np.concatenate([a, b], 0), dtype=np.float32)).to(dev)  # noqa: E731
+        out = self.match_batch(
+            f(k0, k1), f(s0, s1), f(d0, d1), [n0], [n1], [[shape0[0], shape0[1], shape1[0], shape1[1]]],
+            sinkhorn_iterations, match_threshold, return_ot,
+        )
+        m = out["matches"].cpu().numpy().astype(np.int64)
+        ms = out["mscores"].cpu().numpy()
+        res = {"matches0": m[:n0], "matches1": m[n0:], "matching_scores0": ms[:n0], "matching_scores1": ms[n0:]}
+        if return_ot:
+            ld = (n1 + 1 + 3) // 4 * 4
+            res["ot"] = out["ot"].cpu().numpy().reshape(n0 + 1, ld)[:, : n1 + 1]
+        return res

@@ -123,6 +123,48 @@ int gtsfm_sp_extract_keypoints(const float* nms_dev, int batch, int h, int w, fl
 int gtsfm_sp_sample_descriptors(const float* dense_dev, int ld, int batch, int hc, int wc, const float* kp_xy_dev,
                                 const int32_t* kp_count_dev, int capacity, float* desc_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Matchers (SuperGlue / LightGlue): ragged batches of image pairs, token-major activations
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Weight blobs. A blob is a sequence of 64-float-aligned entries: kind 0 = linear (W [n][k] row-major + optional
+ * bias [n], stored packed for gtsfm_linear_f32), kind 1 = raw vector of n floats. The entry sequences of the two
+ * matchers are documented in gtsfm_amd/runtime/matcher_engine.py (BatchNorm folded, attention heads made
+ * contiguous); the forward passes walk the same sequence. */
+size_t gtsfm_blob_floats(int count, const int32_t* kinds, const int32_t* n, const int32_t* k);
+int gtsfm_pack_blob(int count, const int32_t* kinds, const int32_t* n, const int32_t* k, const float* const* w_host,
+                    const float* const* b_host, float* packed_host);
+
+/* Batch descriptors. A batch is `npairs` image pairs; pair p has n0[p] / n1[p] keypoints (all > 0) and image shapes
+ * hw[p] = {H0, W0, H1, W1}. Token-major inputs concatenate the keypoint sets in the order pair0/img0, pair0/img1,
+ * pair1/img0, ... (T = sum of all counts rows). The int32 descriptor block (counts, per-set row offsets / image
+ * shapes, per-pair score-matrix offsets, attention problem lists) is built on the host and uploaded by the caller;
+ * LightGlue's point pruning rewrites the counts section on the device. */
+size_t gtsfm_match_desc_ints(int npairs);
+int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* n0_host, const int32_t* n1_host,
+                           const int32_t* hw_host, int32_t* desc_host);
+
+/* out = softmax(scale * q k^T) v per head (head h = columns [64h, 64h+64)).          replaces SG:85-89,98-106
+ * problems_dev: [nproblems][4] int32 {q_row_off, q_count_idx, k_row_off, k_count_idx}; counts_dev: int32 array the
+ * *_count_idx fields index; max_q: upper bound of the query counts (grid sizing). */
+int gtsfm_attention_f32(const float* q_dev, int ldq, const float* k_dev, int ldk, const float* v_dev, int ldv,
+                        float* out_dev, int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems,
+                        int max_q, int heads, float scale, void* stream);
+
+/* SuperGlue.forward for a batch of pairs.                                                    replaces SG:228-283
+ * kpts_dev [T][2] (x, y) pixels, scores_dev [T], descriptors_dev [T][256] (the wrapper's (N, 256) layout,
+ * gtsfm/frontend/matcher/superglue_matcher.py:94-99 without the transposes).
+ * matches_dev [T] int32: for a keypoint of image i1 the matched index in image i2 (matches0), for a keypoint of
+ * image i2 the matched index in image i1 (matches1), -1 if unmatched; mscores_dev [T]: matching_scores0/1.
+ * ot_dev (optional, parity tests): final log optimal-transport matrices, pair p at the offset / row stride of the
+ * descriptor block ((n0+1) x (n1+1), SG:263). Pairs with an empty keypoint set must be handled by the caller
+ * (SG:233-240). */
+size_t gtsfm_sg_workspace_bytes(int npairs, const int32_t* n0_host, const int32_t* n1_host);
+int gtsfm_sg_forward(const float* blob_dev, int num_layers, float bin_score, int npairs, const int32_t* n0_host,
+                     const int32_t* n1_host, const int32_t* desc_dev, const float* kpts_dev, const float* scores_dev,
+                     const float* descriptors_dev, int sinkhorn_iters, float match_threshold, void* workspace_dev,
+                     size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* ot_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
