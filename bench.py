@@ -138,16 +138,25 @@ def cpu_baseline(h: int, w: int, n_images: int, matcher: str, n_keypoints: int, 
     return out
 
 
+def matcher_flops(matcher: str, n: int, layers: float, sinkhorn: int) -> float:
+    """SURVEY.md section 8(d) per-pair dense FLOP (N = M keypoints)."""
+    if matcher == "superglue":
+        return 2 * 217280 * n + 36 * (1310720 * n + 1024 * n * n) + 262144 * n + 512 * n * n
+    return layers * 2 * (2490368 * n + 1792 * n * n) + 262144 * n + 512 * n * n
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--images", type=int, default=8, help="images per rank per step")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images", type=int, default=46, help="images per rank per step (46 -> 1035 exhaustive pairs, first --pairs kept)")
+    ap.add_argument("--pairs", type=int, default=1000, help="exhaustive (i<j) pairs matched per rank per step")
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--matcher", choices=["none", "lightglue", "superglue"], default="none")
-    ap.add_argument("--keypoints", type=int, default=2048, help="keypoints kept per image for matching (host cap 5000)")
-    ap.add_argument("--sinkhorn", type=int, default=100)
+    ap.add_argument("--matcher", choices=["none", "lightglue", "superglue"], default="lightglue")
+    ap.add_argument("--keypoints", type=int, default=2048, help="keypoints kept per image (device top-k by response)")
+    ap.add_argument("--sinkhorn", type=int, default=100, help="SuperGlue Sinkhorn iterations (GTSfM runs 20; BASELINE config 4 asks for 100)")
+    ap.add_argument("--pair-chunk", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -166,25 +175,40 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from gtsfm_amd.parallel import broadcast_packed_weights
+    from gtsfm_amd import parallel
     from gtsfm_amd.runtime import lib as L
+    from gtsfm_amd.runtime import matcher_engine as ME
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
     from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine, pack_superpoint_weights
 
     lib = L.load()
+    # weights: packed once on rank 0, broadcast over RCCL (xGMI)
     packed = None
     if rank == 0:
         packed = torch.from_numpy(pack_superpoint_weights(synthetic.synthetic_superpoint_state_dict())).to(device)
-    packed = broadcast_packed_weights(packed, int(lib.gtsfm_sp_packed_weight_floats()), device)
-    engine = SuperPointEngine.from_packed(packed)
+    detector = SuperPointEngine.from_packed(parallel.broadcast_packed_weights(packed, int(lib.gtsfm_sp_packed_weight_floats()), device))
+    matcher = None
+    if args.matcher == "superglue":
+        matcher = ME.SuperGlueEngine(synthetic.synthetic_superglue_state_dict(), device)
+    elif args.matcher == "lightglue":
+        matcher = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(), device)
+    if matcher is not None and world > 1:
+        blob = matcher.weights if rank == 0 else None
+        matcher.weights = parallel.broadcast_packed_weights(blob, matcher.weights.numel(), device)
 
     h = w = args.size
     n = args.images
-    imgs = np.stack([synthetic.synthetic_gray_image(h, w, 100 * rank + i) for i in range(n)])
+    imgs = np.stack([synthetic.synthetic_gray_image(h, w, 1000 * rank + i) for i in range(n)])
     images = torch.from_numpy(imgs).to(device)  # inputs resident in HBM before the timed region
-    capacity = 16384
+    pairs = parallel.exhaustive_pairs(n)[: args.pairs] if matcher is not None else []
+    pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk)
+    shapes = [(h, w)] * n
+    mk = {"sinkhorn_iterations": args.sinkhorn} if args.matcher == "superglue" else {}
 
     def step():
-        return engine.forward(images, capacity=capacity)
+        feats = pipe.detect(images)
+        res = pipe.match(feats, pairs, shapes, **mk) if matcher is not None else []
+        return feats, res
 
     def sync():
         if dist is not None:
@@ -192,11 +216,11 @@ def main() -> None:
         torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
-        out = step()
+        feats, res = step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        feats, res = step()
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -204,15 +228,19 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    units_per_step = n * world  # images (matcher none) -- pairs once matching is part of the step
+    detect_only = matcher is None
+    units_per_step = (n if detect_only else len(pairs)) * world
     value = units_per_step / (ms_per_step * 1e-3)
 
     if rank == 0:
-        kcount = out["count"].tolist()
+        kcount = feats["count"].tolist()
+        layers = float(torch.cat([r["stop"] for r in res]).float().mean()) if args.matcher == "lightglue" else 18.0
+        nmatch = int(sum(int((r["matches"] > -1).sum()) for r in res)) // 2 if res else 0
+        flops_step = superpoint_flops(h, w) * n + (matcher_flops(args.matcher, args.keypoints, layers, args.sinkhorn) * len(pairs) if res else 0)
         result = {
-            "metric": "images/sec (SuperPoint detect+describe) @1024px" if args.matcher == "none" else "image-pairs/sec (detect+match) @1024px",
+            "metric": "images/sec (SuperPoint detect+describe) @1024px" if detect_only else "image-pairs/sec (detect+match) @1024px",
             "value": round(value, 2),
-            "unit": "images/s" if args.matcher == "none" else "image-pairs/s",
+            "unit": "images/s" if detect_only else "image-pairs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -223,15 +251,24 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"SuperPoint-only: {n} synthetic {h}x{w} gray images per GPU per step (matcher: {args.matcher})",
+                "workload": (
+                    f"SuperPoint-only: {n} synthetic {h}x{w} gray images per GPU per step" if detect_only else
+                    f"SuperPoint+{args.matcher}: {len(pairs)} exhaustive (i<j) pairs of {n} synthetic {h}x{w} gray images per GPU per step "
+                    f"(each image detected once per step), top-{args.keypoints} keypoints per image"
+                ),
+                "pair_definition": "exhaustive",
                 "images_per_gpu_per_step": n,
+                "pairs_per_gpu_per_step": len(pairs),
                 "keypoints_per_image": [int(min(kcount)), int(max(kcount))],
+                "matcher_layers_run": layers,
+                "sinkhorn_iterations": args.sinkhorn if args.matcher == "superglue" else None,
+                "matches_per_pair": round(nmatch / max(1, len(pairs)), 1),
                 "weights": "seeded synthetic (gtsfm_amd.utils.synthetic)",
-                "parallelism": f"dp{world} (independent images per rank, RCCL weight broadcast)",
+                "parallelism": f"dp{world}: independent image sets / pair lists per rank, RCCL weight broadcast, no data-path collective",
             },
-            "tflops": round(superpoint_flops(h, w) * units_per_step / (ms_per_step * 1e-3) / 1e12, 2),
+            "tflops": round(flops_step * world / (ms_per_step * 1e-3) / 1e12, 2),
         }
-        result["roofline"] = measure_conv_roofline(lib, device, n, h, w)
+        result["roofline"] = measure_conv_roofline(lib, device, min(n, 16), h, w)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(h, w, 2, args.matcher, args.keypoints, args.sinkhorn)
         print(json.dumps(result), flush=True)

@@ -28,6 +28,10 @@ struct GemmParams {
     int ldres;
     float alpha;
     int relu;
+    // optional per-M-tile masking for ragged batches whose sequences start at multiples of 128 rows
+    const int* tile_cnt_idx;  // [M tiles] index into live_counts
+    const int* tile_row0;     // [M tiles] first row of the tile within its sequence
+    const int* live_counts;
 };
 
 int launch_conv3x3(const ConvParams& p, hipStream_t stream);

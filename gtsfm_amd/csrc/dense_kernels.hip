@@ -143,8 +143,16 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int M = p.m_dev ? *p.m_dev : p.M;
+    int M = p.m_dev ? *p.m_dev : p.M;
     const int m0 = blockIdx.x * MT_TILE_M;
+    if (p.tile_cnt_idx) {
+        // ragged batch with 128-row-aligned sequences: this tile belongs to one sequence whose live row count sits in
+        // device memory (LightGlue early stop / point pruning shrink it without host synchronisation)
+        const int c = p.live_counts[p.tile_cnt_idx[blockIdx.x]];
+        const int r0 = p.tile_row0[blockIdx.x];
+        if (r0 >= c) return;
+        M = min(M, m0 + c - r0);
+    }
     if (m0 >= M) return;
     const int nb = blockIdx.y;
     const int total_steps = p.K >> 3;

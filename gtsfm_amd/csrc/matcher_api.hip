@@ -9,6 +9,7 @@
 #include "../../include/gtsfm_amd.h"
 #include "attention_kernels.h"
 #include "dense_kernels.h"
+#include "lightglue_kernels.h"
 #include "matcher_kernels.h"
 
 #define TRY(expr)                          \
@@ -74,50 +75,81 @@ extern "C" int gtsfm_pack_blob(int count, const int32_t* kinds, const int32_t* n
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Batch descriptors (int32 block built on the host, uploaded by the caller):
-//   counts [2P] | seqs [2P][4] | pairs [P][6] | self-attention problems [2P][4] | cross-attention problems [2P][4]
+// Batch descriptors (int32 block built on the host, uploaded by the caller). P pairs, NT = number of 128-row tiles
+// (LightGlue; 0 for SuperGlue):
+//   live counts [2P] | final counts [2P] | assign counts [2P] | original counts [2P] | old counts [2P] | stop layer [P]
+//   | seqs [2P][6] | pairs [P][6] | self-attention problems [2P][4] | cross-attention problems [2P][4]
+//   | tile -> count index [NT] | tile -> first row within its sequence [NT]
 // ---------------------------------------------------------------------------------------------------------------
 
 struct DescLayout {
-    size_t counts, seqs, pairs, self_p, cross_p, total;
+    size_t live, final_cnt, assign, orig, old_cnt, stop, seqs, pairs, self_p, cross_p, tile_idx, tile_row0, total;
 };
 
-static DescLayout desc_layout(int P) {
+static DescLayout desc_layout(int P, int NT) {
     DescLayout L;
     size_t o = 0;
-    L.counts = o, o += (size_t)2 * P;
+    L.live = o, o += (size_t)2 * P;
+    L.final_cnt = o, o += (size_t)2 * P;
+    L.assign = o, o += (size_t)2 * P;
+    L.orig = o, o += (size_t)2 * P;
+    L.old_cnt = o, o += (size_t)2 * P;
+    L.stop = o, o += (size_t)P;
     o = (o + 1) / 2 * 2;
-    L.seqs = o, o += (size_t)8 * P;
+    L.seqs = o, o += (size_t)12 * P;
+    o = (o + 1) / 2 * 2;
     L.pairs = o, o += (size_t)6 * P;
     L.self_p = o, o += (size_t)8 * P;
     L.cross_p = o, o += (size_t)8 * P;
+    L.tile_idx = o, o += (size_t)NT;
+    L.tile_row0 = o, o += (size_t)NT;
     L.total = o;
     return L;
 }
 
 static int z_ld(int n1, int ext) { return (n1 + ext + 3) / 4 * 4; }
+static int cap128(int n) { return (n + 127) / 128 * 128; }
 
-extern "C" size_t gtsfm_match_desc_ints(int npairs) { return desc_layout(npairs > 0 ? npairs : 0).total; }
+static int count_tiles(int superglue, int P, const int32_t* n0, const int32_t* n1) {
+    if (superglue) return 0;
+    int nt = 0;
+    for (int p = 0; p < P; ++p) nt += cap128(n0[p]) / 128 + cap128(n1[p]) / 128;
+    return nt;
+}
+
+extern "C" size_t gtsfm_match_desc_ints(int superglue, int npairs, const int32_t* n0, const int32_t* n1) {
+    if (npairs <= 0 || !n0 || !n1) return 0;
+    return desc_layout(npairs, count_tiles(superglue, npairs, n0, n1)).total;
+}
 
 extern "C" int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* n0, const int32_t* n1, const int32_t* hw,
                                       int32_t* out) {
     GTSFM_CHECK_ARG(npairs > 0 && n0 && n1 && hw && out, "match_build_desc: bad arguments");
-    const DescLayout L = desc_layout(npairs);
+    const DescLayout L = desc_layout(npairs, count_tiles(superglue, npairs, n0, n1));
     memset(out, 0, L.total * sizeof(int32_t));
     const int ext = superglue ? 1 : 0;
-    int row = 0;
+    int row = 0, in_row = 0, tile = 0;
     long long zoff = 0, poff = 0;
     for (int p = 0; p < npairs; ++p) {
         GTSFM_CHECK_ARG(n0[p] > 0 && n1[p] > 0, "match_build_desc: pair %d has an empty keypoint set", p);
         const int ns[2] = {n0[p], n1[p]};
         int offs[2];
+        out[L.stop + p] = -1;
         for (int s = 0; s < 2; ++s) {
             const int si = 2 * p + s;
-            out[L.counts + si] = ns[s];
-            SeqDesc sd = {row, si, hw[4 * p + 2 * s], hw[4 * p + 2 * s + 1]};
-            memcpy(out + L.seqs + 4 * si, &sd, sizeof(sd));
+            const int cap = superglue ? ns[s] : cap128(ns[s]);
+            out[L.live + si] = out[L.orig + si] = ns[s];
+            if (superglue) out[L.final_cnt + si] = ns[s];
+            SeqDesc sd = {row, si, hw[4 * p + 2 * s], hw[4 * p + 2 * s + 1], in_row, cap};
+            memcpy(out + L.seqs + 6 * si, &sd, sizeof(sd));
             offs[s] = row;
-            row += ns[s];
+            if (!superglue)
+                for (int t = 0; t < cap / 128; ++t, ++tile) {
+                    out[L.tile_idx + tile] = si;
+                    out[L.tile_row0 + tile] = t * 128;
+                }
+            row += cap;
+            in_row += ns[s];
         }
         PairDesc pd;
         pd.z_off = zoff, pd.part_off = poff, pd.ld = z_ld(n1[p], ext), pd.pad = 0;
@@ -229,8 +261,8 @@ extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_scor
         gtsfm_set_error("sg_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.total);
         return GTSFM_ERR_WORKSPACE;
     }
-    const DescLayout DL = desc_layout(npairs);
-    const int* counts = desc_dev + DL.counts;
+    const DescLayout DL = desc_layout(npairs, 0);
+    const int* counts = desc_dev + DL.live;
     const SeqDesc* seqs = (const SeqDesc*)(desc_dev + DL.seqs);
     const PairDesc* pairs = (const PairDesc*)(desc_dev + DL.pairs);
     const AttnProblem* self_p = (const AttnProblem*)(desc_dev + DL.self_p);
@@ -312,5 +344,219 @@ extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_scor
     }
     TRY(launch_extract_matches(sa, 1, nullptr, match_threshold, max0, idx0, idx1, matches_dev, mscores_dev, stream));
     if (ot_dev) TRY(launch_materialize_assignment(sa, 1, nullptr, ot_dev, stream));
+    return GTSFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LightGlue (features = "superpoint": 9 layers, 4 heads x 64, descriptor_dim 256)
+// ---------------------------------------------------------------------------------------------------------------
+
+namespace {
+
+struct LgDims {
+    int P, T, Tp, NT, max_n, max_n0, max_n1;
+    size_t z_floats, part_floats, pack_floats;
+};
+
+LgDims lg_dims(int P, const int32_t* n0, const int32_t* n1) {
+    LgDims d = {P, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < P; ++p) {
+        d.T += n0[p] + n1[p];
+        d.Tp += cap128(n0[p]) + cap128(n1[p]);
+        d.max_n0 = d.max_n0 > n0[p] ? d.max_n0 : n0[p];
+        d.max_n1 = d.max_n1 > n1[p] ? d.max_n1 : n1[p];
+        const int ld = z_ld(n1[p], 0);
+        d.z_floats += (size_t)n0[p] * ld;
+        d.part_floats += (size_t)ceil_div(n0[p], 16) * ld * 2;
+        const size_t pk = packed_linear_floats(256, n1[p]);
+        d.pack_floats = d.pack_floats > pk ? d.pack_floats : pk;
+    }
+    d.NT = d.Tp / 128;
+    d.max_n = d.max_n0 > d.max_n1 ? d.max_n0 : d.max_n1;
+    return d;
+}
+
+struct LgWorkspace {
+    size_t xa, xb, qkv, att, mlp, md, enca, encb, inda, indb, indf, conf, mval, z_logit, pos, pack, z, part, uv_row, uv_col, max0, idx0, idx1,
+        m_int, ms_int, total;
+};
+
+LgWorkspace lg_workspace_layout(const LgDims& d) {
+    LgWorkspace w;
+    size_t o = 0;
+    auto take = [&](size_t floats) {
+        size_t r = o;
+        o += align_up(floats * 4, 256);
+        return r;
+    };
+    const size_t T = d.Tp;
+    w.xa = take(T * 512), w.xb = take(T * 512), w.qkv = take(T * 768), w.att = take(T * 256), w.mlp = take(T * 512), w.md = take(T * 256);
+    w.enca = take(T * 64), w.encb = take(T * 64), w.inda = take(T), w.indb = take(T), w.indf = take(T);
+    w.conf = take(T), w.mval = take(T), w.z_logit = take(T), w.pos = take(T);
+    w.pack = take(d.pack_floats), w.z = take(d.z_floats), w.part = take(d.part_floats);
+    w.uv_row = take(T + 2 * d.P), w.uv_col = take(T + 2 * d.P);
+    w.max0 = take(T), w.idx0 = take(T), w.idx1 = take(T), w.m_int = take(T), w.ms_int = take(T);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t gtsfm_lg_workspace_bytes(int npairs, const int32_t* n0, const int32_t* n1) {
+    if (npairs <= 0 || !n0 || !n1) return 256;
+    return lg_workspace_layout(lg_dims(npairs, n0, n1)).total;
+}
+
+extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* match_bias_host, const float* conf_bias_host, int npairs,
+                                const int32_t* n0, const int32_t* n1, int32_t* desc_dev, const float* kpts_dev, const float* descriptors_dev,
+                                float depth_confidence, float width_confidence, float filter_threshold, int pruning_threshold,
+                                void* workspace_dev, size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev,
+                                void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GTSFM_CHECK_ARG(wts && match_bias_host && n0 && n1 && desc_dev && kpts_dev && descriptors_dev && workspace_dev && matches_dev && mscores_dev,
+                    "lg_forward: null pointer");
+    GTSFM_CHECK_ARG(npairs > 0 && num_layers > 0 && (num_layers == 1 || conf_bias_host), "lg_forward: bad arguments");
+    const LgDims d = lg_dims(npairs, n0, n1);
+    const LgWorkspace ws = lg_workspace_layout(d);
+    if (workspace_bytes < ws.total) {
+        gtsfm_set_error("lg_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.total);
+        return GTSFM_ERR_WORKSPACE;
+    }
+    const DescLayout DL = desc_layout(npairs, d.NT);
+    int* live = desc_dev + DL.live;
+    int* final_cnt = desc_dev + DL.final_cnt;
+    int* assign = desc_dev + DL.assign;
+    const int* orig = desc_dev + DL.orig;
+    int* old_cnt = desc_dev + DL.old_cnt;
+    int* stop_layer = desc_dev + DL.stop;
+    const SeqDesc* seqs = (const SeqDesc*)(desc_dev + DL.seqs);
+    const PairDesc* pairs = (const PairDesc*)(desc_dev + DL.pairs);
+    const AttnProblem* self_p = (const AttnProblem*)(desc_dev + DL.self_p);
+    const AttnProblem* cross_p = (const AttnProblem*)(desc_dev + DL.cross_p);
+    const int* tile_idx = desc_dev + DL.tile_idx;
+    const int* tile_row0 = desc_dev + DL.tile_row0;
+    char* wsp = (char*)workspace_dev;
+    float* X = (float*)(wsp + ws.xa);
+    float* Xalt = (float*)(wsp + ws.xb);
+    float* QKV = (float*)(wsp + ws.qkv);
+    float* ATT = (float*)(wsp + ws.att);
+    float* MLP = (float*)(wsp + ws.mlp);
+    float* MD = (float*)(wsp + ws.md);
+    float* enc = (float*)(wsp + ws.enca);
+    float* enc_alt = (float*)(wsp + ws.encb);
+    int* ind = (int*)(wsp + ws.inda);
+    int* ind_alt = (int*)(wsp + ws.indb);
+    int* ind_final = (int*)(wsp + ws.indf);
+    float* conf = (float*)(wsp + ws.conf);
+    float* mval = (float*)(wsp + ws.mval);
+    float* z_logit = (float*)(wsp + ws.z_logit);
+    int* pos = (int*)(wsp + ws.pos);
+    float* PACK = (float*)(wsp + ws.pack);
+    float* Z = sim_dev ? sim_dev : (float*)(wsp + ws.z);
+    float* PART = (float*)(wsp + ws.part);
+    float* rowvec = (float*)(wsp + ws.uv_row);
+    float* colvec = (float*)(wsp + ws.uv_col);
+    float* max0 = (float*)(wsp + ws.max0);
+    int* idx0 = (int*)(wsp + ws.idx0);
+    int* idx1 = (int*)(wsp + ws.idx1);
+    int* m_int = (int*)(wsp + ws.m_int);
+    float* ms_int = (float*)(wsp + ws.ms_int);
+    const int nseq = 2 * npairs;
+    const bool do_prune = width_confidence > 0.f && pruning_threshold != 0x7fffffff;
+
+    BlobCursor cur = {wts, 0};
+    // masked GEMM over the padded token rows; `cnt` selects which count array gates the tiles
+    auto gemm = [&](const float* A, int lda, int K, int N, float* C, int ldc, int coff, const float* res, int ldres, float alpha,
+                    const int* cnt) -> int {
+        const float *w, *b;
+        cur.linear(N, K, &w, &b);
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.A = A, g.lda = lda, g.M = d.Tp, g.K = K, g.wpack = w, g.bias = b, g.N = N;
+        g.C = C, g.ldc = ldc, g.c_coff = coff, g.res = res, g.ldres = ldres, g.alpha = alpha, g.relu = 0;
+        g.tile_cnt_idx = tile_idx, g.tile_row0 = tile_row0, g.live_counts = cnt;
+        return launch_gemm(g, stream);
+    };
+    auto ffn = [&](float* Xc) -> int {  // x + ffn(cat[x, message])
+        TRY(gemm(Xc, 512, 512, 512, MLP, 512, 0, nullptr, 0, 1.0f, live));
+        const float* gamma = cur.raw(512);
+        const float* beta = cur.raw(512);
+        TRY(launch_layernorm_gelu(MLP, 512, seqs, live, nseq, d.max_n, gamma, beta, stream));
+        TRY(gemm(MLP, 512, 512, 256, Xc, 512, 0, Xc, 512, 1.0f, live));
+        return GTSFM_OK;
+    };
+
+    const float* Wr = cur.raw(64);
+    TRY(launch_lg_load_inputs(descriptors_dev, seqs, live, nseq, d.max_n, X, 512, ind, stream));
+    TRY(launch_lg_posenc(kpts_dev, seqs, live, nseq, d.max_n, Wr, enc, stream));
+
+    for (int l = 0; l < num_layers; ++l) {
+        // self block: Wqkv, rotary on q and k, attention, out_proj, ffn
+        TRY(gemm(X, 512, 256, 768, QKV, 768, 0, nullptr, 0, 1.0f, live));
+        TRY(launch_lg_rotary(QKV, 768, 512, enc, seqs, live, nseq, d.max_n, stream));
+        AttnParams ap;
+        ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = ATT, ap.ldo = 256;
+        ap.problems = self_p, ap.counts = live, ap.scale = 0.125f, ap.heads = 4;
+        TRY(launch_attention(ap, nseq, d.max_n, stream));
+        TRY(gemm(ATT, 256, 256, 256, X, 512, 256, nullptr, 0, 1.0f, live));
+        TRY(ffn(X));
+        // cross block: shared to_qk | to_v, both directions of the bidirectional attention, to_out, ffn
+        TRY(gemm(X, 512, 256, 512, QKV, 768, 0, nullptr, 0, 1.0f, live));
+        ap.q = QKV, ap.k = QKV, ap.v = QKV + 256, ap.problems = cross_p;
+        TRY(launch_attention(ap, nseq, d.max_n, stream));
+        TRY(gemm(ATT, 256, 256, 256, X, 512, 256, nullptr, 0, 1.0f, live));
+        TRY(ffn(X));
+
+        // adaptive depth / final assignment inputs
+        const float *w_fp, *b_fp;
+        size_t fp_off = cur.off;
+        cur.linear(256, 256, &w_fp, &b_fp);  // log_assignment[l].final_proj (consumed below through `gemm`)
+        const float* w_match = cur.raw(256);
+        const float* w_conf = (l < num_layers - 1) ? cur.raw(256) : nullptr;
+        const float thr = (float)fmin(fmax(0.8 + 0.1 * exp(-4.0 * l / num_layers), 0.0), 1.0);
+        if (w_conf) TRY(launch_rowdot(X, 512, seqs, live, nseq, d.max_n, w_conf, conf_bias_host[l], 1, conf, stream));
+        TRY(launch_lg_stop_check(conf, seqs, live, final_cnt, assign, orig, stop_layer, npairs, l, num_layers - 1, thr, depth_confidence, stream));
+        {
+            // pairs that stopped at this layer: mdesc = final_proj(x) / 256^(1/4), z = matchability(x), freeze their index lists
+            const size_t keep = cur.off;
+            cur.off = fp_off;
+            TRY(gemm(X, 512, 256, 256, MD, 256, 0, nullptr, 0, 0.25f, assign));
+            cur.off = keep;
+            TRY(launch_rowdot(X, 512, seqs, assign, nseq, d.max_n, w_match, match_bias_host[l], 0, z_logit, stream));
+            TRY(launch_lg_save_ind(seqs, assign, ind, ind_final, nseq, d.max_n, stream));
+        }
+        if (do_prune && l < num_layers - 1) {
+            TRY(launch_rowdot(X, 512, seqs, live, nseq, d.max_n, w_match, match_bias_host[l], 1, mval, stream));
+            TRY(launch_lg_prune(conf, mval, seqs, live, old_cnt, pos, nseq, d.max_n, thr, (float)(1.0 - (double)width_confidence), pruning_threshold,
+                                depth_confidence > 0.f ? 1 : 0, X, Xalt, 512, enc, enc_alt, ind, ind_alt, stream));
+            float* tx = X; X = Xalt; Xalt = tx;
+            float* te = enc; enc = enc_alt; enc_alt = te;
+            int* ti = ind; ind = ind_alt; ind_alt = ti;
+        }
+    }
+
+    // sim = mdesc0 mdesc1^T per pair over the final (kept) keypoints
+    {
+        size_t zoff = 0;
+        int row = 0;
+        for (int p = 0; p < npairs; ++p) {
+            const int r0 = row, r1 = row + cap128(n0[p]);
+            const int ld = z_ld(n1[p], 0);
+            TRY(launch_pack_rows(MD + (size_t)r1 * 256, 256, n1[p], final_cnt + 2 * p + 1, 256, PACK, stream));
+            GemmParams g;
+            memset(&g, 0, sizeof(g));
+            g.A = MD + (size_t)r0 * 256, g.lda = 256, g.M = n0[p], g.m_dev = final_cnt + 2 * p, g.K = 256, g.wpack = PACK, g.N = n1[p];
+            g.C = Z + zoff, g.ldc = ld, g.alpha = 1.0f;
+            TRY(launch_gemm(g, stream));
+            zoff += (size_t)n0[p] * ld;
+            row += cap128(n0[p]) + cap128(n1[p]);
+        }
+    }
+    SweepArgs sa;
+    sa.pairs = pairs, sa.seqs = seqs, sa.counts = final_cnt, sa.npairs = npairs, sa.max_m = d.max_n0, sa.max_n = d.max_n1;
+    sa.zbuf = Z, sa.rowvec = rowvec, sa.colvec = colvec, sa.partials = PART;
+    TRY(launch_double_softmax_lse(sa, stream));
+    TRY(launch_extract_matches(sa, 0, z_logit, filter_threshold, max0, idx0, idx1, m_int, ms_int, stream));
+    TRY(launch_lg_scatter_matches(seqs, final_cnt, ind_final, m_int, ms_int, nseq, d.max_n, d.T, matches_dev, mscores_dev, stream));
     return GTSFM_OK;
 }

@@ -3,10 +3,12 @@
 
 #include "common.h"
 
-// One keypoint set ("sequence"): rows [row_off, row_off + counts[cnt_idx]) of every token-major array.
+// One keypoint set ("sequence"): rows [row_off, row_off + counts[cnt_idx]) of every internal token-major array and rows
+// [in_off, in_off + n) of the caller's input / output arrays. SuperGlue packs sequences back to back (in_off == row_off);
+// LightGlue aligns every sequence to 128 rows (cap = rows reserved) so that GEMM tiles can be masked per sequence.
 // Pair p consists of sequences 2p (image i1) and 2p + 1 (image i2).
 struct SeqDesc {
-    int row_off, cnt_idx, H, W;
+    int row_off, cnt_idx, H, W, in_off, cap;
 };
 
 // Score matrix of one pair: zbuf + z_off, row stride ld; Sinkhorn column partials at partials + part_off.
@@ -33,8 +35,10 @@ int launch_lg_posenc(const float* kpts, const SeqDesc* seqs, const int* counts, 
                      hipStream_t stream);
 int launch_lg_rotary(float* qkv, int ld, int ncols, const float* enc, const SeqDesc* seqs, const int* counts, int nseq, int max_n,
                      hipStream_t stream);
-int launch_layernorm_gelu(float* x, int ld, int rows, const float* gamma, const float* beta, hipStream_t stream);
-int launch_rowdot(const float* x, int ld, int rows, const float* w, float b, int act, float* out, hipStream_t stream);
+int launch_layernorm_gelu(float* x, int ld, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* gamma,
+                          const float* beta, hipStream_t stream);
+int launch_rowdot(const float* x, int ld, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* w, float b, int act,
+                  float* out, hipStream_t stream);
 int launch_sinkhorn(const SweepArgs& a, float bin_score, int iters, hipStream_t stream);
 int launch_double_softmax_lse(const SweepArgs& a, hipStream_t stream);
 int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogit, float threshold, float* max0, int* idx0, int* idx1,

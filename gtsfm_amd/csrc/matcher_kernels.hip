@@ -26,11 +26,11 @@ __global__ void sg_encode_input_kernel(const float* __restrict__ kpts, const flo
     const float cx = w / 2.0f, cy = h / 2.0f;
     const float scaling = fmaxf(w, h) * 0.7f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const size_t t = (size_t)sq.row_off + i;
+        const size_t t = (size_t)sq.row_off + i, ti = (size_t)sq.in_off + i;
         float* o = enc_in + t * 8;
-        o[0] = (kpts[t * 2 + 0] - cx) / scaling;
-        o[1] = (kpts[t * 2 + 1] - cy) / scaling;
-        o[2] = scores[t];
+        o[0] = (kpts[ti * 2 + 0] - cx) / scaling;
+        o[1] = (kpts[ti * 2 + 1] - cy) / scaling;
+        o[2] = scores[ti];
         o[3] = o[4] = o[5] = o[6] = o[7] = 0.f;
     }
 }
@@ -47,9 +47,9 @@ __global__ void lg_posenc_kernel(const float* __restrict__ kpts, const SeqDesc* 
     const int f = threadIdx.x & 31;
     const float w0 = Wr[f * 2 + 0], w1 = Wr[f * 2 + 1];
     for (int i = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5); i < n; i += gridDim.x * (blockDim.x >> 5)) {
-        const size_t t = (size_t)sq.row_off + i;
-        const float x = (kpts[t * 2 + 0] - sx) / scale;
-        const float y = (kpts[t * 2 + 1] - sy) / scale;
+        const size_t t = (size_t)sq.row_off + i, ti = (size_t)sq.in_off + i;
+        const float x = (kpts[ti * 2 + 0] - sx) / scale;
+        const float y = (kpts[ti * 2 + 1] - sy) / scale;
         const float pr = x * w0 + y * w1;  // F.linear without bias: sum over 2 inputs
         enc[t * 64 + f] = cosf(pr);
         enc[t * 64 + 32 + f] = sinf(pr);
@@ -77,10 +77,13 @@ __global__ void lg_rotary_kernel(float* __restrict__ qkv, int ld, int ncols /*51
 }
 
 // y = GELU(LayerNorm(x)) over rows of 512 (eps 1e-5, affine), in place. One wave per row, 8 elements per lane.
-__global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__ x, int ld, int rows, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__ x, int ld, const SeqDesc* __restrict__ seqs,
+                                                             const int* __restrict__ counts, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const SeqDesc sq = seqs[blockIdx.y];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= counts[sq.cnt_idx]) return;
+    const int row = sq.row_off + i;
     const int lane = threadIdx.x & 63;
     float* p = x + (size_t)row * ld + lane * 8;
     f32x4 a = *reinterpret_cast<f32x4*>(p), b = *reinterpret_cast<f32x4*>(p + 4);
@@ -89,13 +92,13 @@ __global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum += v[e];
     const float mean = wave_sum(sum) / 512.0f;
-    float sq = 0.f;
+    float ssq = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float d = v[e] - mean;
-        sq += d * d;
+        ssq += d * d;
     }
-    const float var = wave_sum(sq) / 512.0f;
+    const float var = wave_sum(ssq) / 512.0f;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -108,10 +111,13 @@ __global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__
 
 // out[t] = act(dot(x[t, :256], w) + b): token-confidence and matchability heads (Linear(256, 1)). One wave per token.
 // act: 0 = identity, 1 = sigmoid
-__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, int ld, int rows, const float* __restrict__ w, float b,
-                                                     int act, float* __restrict__ out) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, int ld, const SeqDesc* __restrict__ seqs,
+                                                     const int* __restrict__ counts, const float* __restrict__ w, float b, int act,
+                                                     float* __restrict__ out) {
+    const SeqDesc sq = seqs[blockIdx.y];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= counts[sq.cnt_idx]) return;
+    const int row = sq.row_off + i;
     const int lane = threadIdx.x & 63;
     const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)row * ld + lane * 4);
     const f32x4 ww = *reinterpret_cast<const f32x4*>(w + lane * 4);
@@ -146,16 +152,18 @@ int launch_lg_rotary(float* qkv, int ld, int ncols, const float* enc, const SeqD
     return GTSFM_OK;
 }
 
-int launch_layernorm_gelu(float* x, int ld, int rows, const float* gamma, const float* beta, hipStream_t stream) {
-    if (rows <= 0) return GTSFM_OK;
-    hipLaunchKernelGGL(layernorm_gelu_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, x, ld, rows, gamma, beta);
+int launch_layernorm_gelu(float* x, int ld, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* gamma,
+                          const float* beta, hipStream_t stream) {
+    if (nseq <= 0 || max_n <= 0) return GTSFM_OK;
+    hipLaunchKernelGGL(layernorm_gelu_kernel, dim3(ceil_div(max_n, 4), nseq), dim3(256), 0, stream, x, ld, seqs, counts, gamma, beta);
     GTSFM_CHECK_LAUNCH("layernorm_gelu_kernel");
     return GTSFM_OK;
 }
 
-int launch_rowdot(const float* x, int ld, int rows, const float* w, float b, int act, float* out, hipStream_t stream) {
-    if (rows <= 0) return GTSFM_OK;
-    hipLaunchKernelGGL(rowdot_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, x, ld, rows, w, b, act, out);
+int launch_rowdot(const float* x, int ld, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* w, float b, int act,
+                  float* out, hipStream_t stream) {
+    if (nseq <= 0 || max_n <= 0) return GTSFM_OK;
+    hipLaunchKernelGGL(rowdot_kernel, dim3(ceil_div(max_n, 4), nseq), dim3(256), 0, stream, x, ld, seqs, counts, w, b, act, out);
     GTSFM_CHECK_LAUNCH("rowdot_kernel");
     return GTSFM_OK;
 }

@@ -163,7 +163,8 @@ extern "C" int gtsfm_sp_pack_weights(const float* const* t, float* out) {
 namespace {
 
 struct SpWorkspace {
-    size_t ping0, ping1, logits, dense, scores, nms, ss, mask, supp, rows, total;
+    size_t ping0, ping1, logits, dense, scores, nms, ss, mask, supp, rows, xy_full, sc_full, cnt_full, total;
+    int full_capacity;
 };
 
 SpWorkspace sp_workspace_layout(int B, int H, int W) {
@@ -192,6 +193,11 @@ SpWorkspace sp_workspace_layout(int B, int H, int W) {
     ws.mask = take(pix8);
     ws.supp = take(pix8);
     ws.rows = take(((size_t)B * Hc * 8 * 2 + B) * 4);
+    // scratch for the top-k path: an NMS radius >= 1 leaves at most one keypoint per 2x2 block (ties aside)
+    ws.full_capacity = (int)(Hc * 8 * Wc * 8 / 4 + 64);
+    ws.xy_full = take((size_t)B * ws.full_capacity * 2 * 4);
+    ws.sc_full = take((size_t)B * ws.full_capacity * 4);
+    ws.cnt_full = take((size_t)B * 4);
     ws.total = o;
     return ws;
 }
@@ -238,6 +244,13 @@ extern "C" int gtsfm_sp_sample_descriptors(const float* dense_dev, int ld, int b
     return launch_sample_descriptors(dense_dev, ld, batch, hc, wc, kp_xy_dev, kp_count_dev, capacity, desc_dev, (hipStream_t)stream);
 }
 
+extern "C" int gtsfm_sp_select_topk(const float* kp_score_dev, const float* kp_xy_dev, const int32_t* kp_count_dev, int batch, int capacity,
+                                    int top_k, float* out_xy_dev, float* out_score_dev, int32_t* out_count_dev, void* stream) {
+    GTSFM_CHECK_ARG(kp_score_dev && kp_xy_dev && kp_count_dev && out_xy_dev && out_score_dev && out_count_dev, "sp_select_topk: null pointer");
+    return launch_select_topk(kp_score_dev, kp_count_dev, batch, capacity, top_k, kp_xy_dev, out_xy_dev, out_score_dev, out_count_dev,
+                              (hipStream_t)stream);
+}
+
 #define SP_TRY(expr)                 \
     do {                             \
         int rc_ = (expr);            \
@@ -245,12 +258,14 @@ extern "C" int gtsfm_sp_sample_descriptors(const float* dense_dev, int ld, int b
     } while (0)
 
 extern "C" int gtsfm_sp_forward(const float* wts, const void* image_dev, int image_is_u8, int B, int H, int W, float thr, int nms_radius,
-                                int border, int capacity, void* workspace_dev, size_t workspace_bytes, int32_t* kp_count_dev,
+                                int border, int capacity, int top_k, void* workspace_dev, size_t workspace_bytes, int32_t* kp_count_dev,
                                 int32_t* kp_count_raw_dev, float* kp_xy_dev, float* kp_score_dev, float* desc_dev,
                                 float* dense_scores_dev, float* nms_scores_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GTSFM_CHECK_ARG(wts && image_dev && workspace_dev && kp_count_dev && kp_xy_dev && kp_score_dev && desc_dev, "sp_forward: null pointer");
     GTSFM_CHECK_ARG(B > 0 && H > 0 && W > 0 && capacity > 0, "sp_forward: bad shape (batch %d, %d x %d, capacity %d)", B, H, W, capacity);
+    GTSFM_CHECK_ARG(top_k <= 0 || top_k == capacity, "sp_forward: with top_k > 0 the output arrays must have capacity == top_k");
+    GTSFM_CHECK_ARG(top_k <= 0 || nms_radius >= 1, "sp_forward: the device top-k path needs nms_radius >= 1 (scratch sizing)");
     const SpWorkspace ws = sp_workspace_layout(B, H, W);
     if (workspace_bytes < ws.total) {
         gtsfm_set_error("sp_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.total);
@@ -321,8 +336,19 @@ extern "C" int gtsfm_sp_forward(const float* wts, const void* image_dev, int ima
     }
     SP_TRY(launch_softmax_d2s(logits, 65, B, Hc, Wc, scores, stream));
     SP_TRY(launch_simple_nms(scores, B, H8, W8, nms_radius, mask, supp, ss, nms, stream));
-    SP_TRY(launch_extract_keypoints(nms, B, H8, W8, thr, border, capacity, rows, rows + (size_t)B * H8, kp_count_dev, count_raw,
-                                    kp_xy_dev, kp_score_dev, stream));
-    SP_TRY(launch_sample_descriptors(dense, 256, B, Hc, Wc, kp_xy_dev, kp_count_dev, capacity, desc_dev, stream));
+    if (top_k <= 0) {
+        SP_TRY(launch_extract_keypoints(nms, B, H8, W8, thr, border, capacity, rows, rows + (size_t)B * H8, kp_count_dev, count_raw,
+                                        kp_xy_dev, kp_score_dev, stream));
+        SP_TRY(launch_sample_descriptors(dense, 256, B, Hc, Wc, kp_xy_dev, kp_count_dev, capacity, desc_dev, stream));
+    } else {
+        // extract everything into the workspace, keep the top_k responses (row-major order), describe only those
+        float* xy_full = (float*)(wsp + ws.xy_full);
+        float* sc_full = (float*)(wsp + ws.sc_full);
+        int* cnt_full = (int*)(wsp + ws.cnt_full);
+        SP_TRY(launch_extract_keypoints(nms, B, H8, W8, thr, border, ws.full_capacity, rows, rows + (size_t)B * H8, cnt_full, count_raw,
+                                        xy_full, sc_full, stream));
+        SP_TRY(launch_select_topk(sc_full, cnt_full, B, ws.full_capacity, top_k, xy_full, kp_xy_dev, kp_score_dev, kp_count_dev, stream));
+        SP_TRY(launch_sample_descriptors(dense, 256, B, Hc, Wc, kp_xy_dev, kp_count_dev, top_k, desc_dev, stream));
+    }
     return GTSFM_OK;
 }

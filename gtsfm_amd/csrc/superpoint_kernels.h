@@ -12,3 +12,5 @@ int launch_extract_keypoints(const float* nms, int B, int H, int W, float thr, i
                              int* count, int* count_raw, float* kp_xy, float* kp_score, hipStream_t stream);
 int launch_sample_descriptors(const float* dense, int ld, int B, int Hc, int Wc, const float* kp_xy, const int* count, int capacity,
                               float* desc, hipStream_t stream);
+int launch_select_topk(const float* scores, const int* count, int B, int cap, int k, const float* xy, float* out_xy, float* out_score,
+                       int* out_count, hipStream_t stream);

@@ -337,3 +337,109 @@ int launch_sample_descriptors(const float* dense, int ld, int B, int Hc, int Wc,
     GTSFM_CHECK_LAUNCH("sample_descriptors_kernel");
     return GTSFM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device-side top-k by response (the selection gtsfm/common/keypoints.py:89-110 performs on the host with
+// np.argpartition), keeping the survivors in row-major detection order. One workgroup per image: 4-pass radix select
+// on the fp32 bit patterns (scores are positive, so the unsigned order is the numeric order), then an ordered
+// compaction. Ties at the k-th value are broken by detection order (argpartition's choice is implementation-defined).
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(1024) void kp_select_topk_kernel(const float* __restrict__ scores, const int* __restrict__ count, int cap,
+                                                              int k, const float* __restrict__ xy, float* __restrict__ out_xy,
+                                                              float* __restrict__ out_score, int* __restrict__ out_count) {
+    __shared__ int hist[256];
+    __shared__ int wsum[16];
+    __shared__ unsigned sel_prefix;
+    __shared__ int sel_remaining, carry_s, tie_carry_s;
+    const int b = blockIdx.x;
+    const int n = min(count[b], cap);
+    const unsigned* bits = reinterpret_cast<const unsigned*>(scores) + (size_t)b * cap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned tau = 0;
+    int ties_wanted = 0;
+    const bool select = n > k;
+    if (select) {
+        if (tid == 0) {
+            sel_prefix = 0;
+            sel_remaining = k;
+        }
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = sel_prefix;
+            const unsigned himask = (pass == 0) ? 0u : (0xffffffffu << (shift + 8));
+            for (int i = tid; i < n; i += 1024) {
+                const unsigned v = bits[i];
+                if ((v & himask) == prefix) atomicAdd(&hist[(v >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int remaining = sel_remaining, bin = 255;
+                for (; bin > 0; --bin) {
+                    if (hist[bin] >= remaining) break;
+                    remaining -= hist[bin];
+                }
+                sel_prefix = prefix | ((unsigned)bin << shift);
+                sel_remaining = remaining;
+            }
+            __syncthreads();
+        }
+        tau = sel_prefix;
+        ties_wanted = sel_remaining;
+    }
+    if (tid == 0) carry_s = tie_carry_s = 0;
+    __syncthreads();
+    float* oxy = out_xy + (size_t)b * k * 2;
+    float* osc = out_score + (size_t)b * k;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const unsigned v = (i < n) ? bits[i] : 0u;
+        const int is_tie = (select && i < n && v == tau) ? 1 : 0;
+        // exclusive rank among ties
+        int incl = is_tie;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += wsum[w];
+        const int tie_rank = tie_carry_s + wbase + incl - is_tie;
+        __syncthreads();
+        if (tid == 1023) tie_carry_s += wbase + incl;
+        const int keep = (i < n) && (!select || v > tau || (is_tie && tie_rank < ties_wanted)) ? 1 : 0;
+        incl = keep;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += wsum[w];
+        const int pos = carry_s + wbase + incl - keep;
+        if (keep && pos < k) {
+            oxy[pos * 2 + 0] = xy[((size_t)b * cap + i) * 2 + 0];
+            oxy[pos * 2 + 1] = xy[((size_t)b * cap + i) * 2 + 1];
+            osc[pos] = scores[(size_t)b * cap + i];
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s += wbase + incl;
+        __syncthreads();
+    }
+    if (tid == 0) out_count[b] = min(n, k);
+}
+
+int launch_select_topk(const float* scores, const int* count, int B, int cap, int k, const float* xy, float* out_xy, float* out_score,
+                       int* out_count, hipStream_t stream) {
+    GTSFM_CHECK_ARG(k > 0 && cap > 0, "select_topk: k and capacity must be positive");
+    if (B <= 0) return GTSFM_OK;
+    hipLaunchKernelGGL(kp_select_topk_kernel, dim3(B), dim3(1024), 0, stream, scores, count, cap, k, xy, out_xy, out_score, out_count);
+    GTSFM_CHECK_LAUNCH("kp_select_topk_kernel");
+    return GTSFM_OK;
+}

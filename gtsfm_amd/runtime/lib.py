@@ -47,7 +47,7 @@ SIGNATURES = {
     "gtsfm_sp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "gtsfm_sp_forward": (
         C.c_int,
-        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
          C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "gtsfm_sp_softmax_d2s": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -60,7 +60,7 @@ SIGNATURES = {
     ),
     "gtsfm_blob_floats": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gtsfm_pack_blob": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
-    "gtsfm_match_desc_ints": (C.c_size_t, [C.c_int]),
+    "gtsfm_match_desc_ints": (C.c_size_t, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gtsfm_match_build_desc": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gtsfm_attention_f32": (
         C.c_int,
@@ -72,6 +72,16 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "gtsfm_lg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p]),
+    "gtsfm_lg_forward": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "gtsfm_sp_select_topk": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "gtsfm_sp_sample_descriptors": (
         C.c_int,

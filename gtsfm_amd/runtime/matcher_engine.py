@@ -111,7 +111,7 @@ class _MatcherBase:
 
     def _build_desc(self, superglue: bool, n0: np.ndarray, n1: np.ndarray, hw: np.ndarray) -> torch.Tensor:
         p = len(n0)
-        host = np.empty(self._lib.gtsfm_match_desc_ints(p), dtype=np.int32)
+        host = np.empty(self._lib.gtsfm_match_desc_ints(int(superglue), p, n0.ctypes.data, n1.ctypes.data), dtype=np.int32)
         _lib.check(
             self._lib.gtsfm_match_build_desc(int(superglue), p, n0.ctypes.data, n1.ctypes.data, hw.ctypes.data, host.ctypes.data),
             "gtsfm_match_build_desc",
@@ -196,4 +196,141 @@ class SuperGlueEngine(_MatcherBase):
         if return_ot:
             ld = (n1 + 1 + 3) // 4 * 4
             res["ot"] = out["ot"].cpu().numpy().reshape(n0 + 1, ld)[:, : n1 + 1]
+        return res
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# LightGlue
+# ------------------------------------------------------------------------------------------------------------------
+
+LIGHTGLUE_DEPTH_CONFIDENCE = 0.95  # upstream default_conf
+LIGHTGLUE_WIDTH_CONFIDENCE = 0.99
+LIGHTGLUE_FILTER_THRESHOLD = 0.1
+# upstream pruning_keypoint_thresholds = {"cpu": -1, "mps": -1, "cuda": 1024, "flash": 1536}; GTSfM runs the matcher on
+# "cuda" with torch >= 2 (scaled_dot_product_attention available) -> "flash"
+LIGHTGLUE_PRUNING_THRESHOLD = 1536
+NO_PRUNING = 2**31 - 1
+
+
+def lightglue_num_layers(sd: Mapping[str, torch.Tensor]) -> int:
+    return 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("transformers."))
+
+
+def lightglue_entries(sd: Mapping[str, torch.Tensor]) -> Tuple[List[Entry], np.ndarray, np.ndarray]:
+    n_layers = lightglue_num_layers(sd)
+    qkv_perm = np.array([(r % 256 // 64) * 192 + (r % 64) * 3 + r // 256 for r in range(768)])  # new j*256+h*64+d <- old h*192+d*3+j
+    entries: List[Entry] = [(1, _f64(sd["posenc.Wr.weight"]).reshape(-1), None)]
+    match_bias, conf_bias = [], []
+    for l in range(n_layers):
+        p = f"transformers.{l}"
+        entries.append((0, _f64(sd[f"{p}.self_attn.Wqkv.weight"])[qkv_perm], _f64(sd[f"{p}.self_attn.Wqkv.bias"])[qkv_perm]))
+        entries.append((0, _f64(sd[f"{p}.self_attn.out_proj.weight"]), _f64(sd[f"{p}.self_attn.out_proj.bias"])))
+
+        def ffn(blk):
+            entries.append((0, _f64(sd[f"{p}.{blk}.ffn.0.weight"]), _f64(sd[f"{p}.{blk}.ffn.0.bias"])))
+            entries.append((1, _f64(sd[f"{p}.{blk}.ffn.1.weight"]), None))
+            entries.append((1, _f64(sd[f"{p}.{blk}.ffn.1.bias"]), None))
+            entries.append((0, _f64(sd[f"{p}.{blk}.ffn.3.weight"]), _f64(sd[f"{p}.{blk}.ffn.3.bias"])))
+
+        ffn("self_attn")
+        entries.append((
+            0,
+            np.concatenate([_f64(sd[f"{p}.cross_attn.to_qk.weight"]), _f64(sd[f"{p}.cross_attn.to_v.weight"])], 0),
+            np.concatenate([_f64(sd[f"{p}.cross_attn.to_qk.bias"]), _f64(sd[f"{p}.cross_attn.to_v.bias"])], 0),
+        ))
+        entries.append((0, _f64(sd[f"{p}.cross_attn.to_out.weight"]), _f64(sd[f"{p}.cross_attn.to_out.bias"])))
+        ffn("cross_attn")
+        a = f"log_assignment.{l}"
+        entries.append((0, _f64(sd[f"{a}.final_proj.weight"]), _f64(sd[f"{a}.final_proj.bias"])))
+        entries.append((1, _f64(sd[f"{a}.matchability.weight"]).reshape(-1), None))
+        match_bias.append(float(sd[f"{a}.matchability.bias"].reshape(-1)[0]))
+        if l < n_layers - 1:
+            entries.append((1, _f64(sd[f"token_confidence.{l}.token.0.weight"]).reshape(-1), None))
+            conf_bias.append(float(sd[f"token_confidence.{l}.token.0.bias"].reshape(-1)[0]))
+    return entries, np.array(match_bias, dtype=np.float32), np.array(conf_bias + [0.0], dtype=np.float32)
+
+
+class LightGlueEngine(_MatcherBase):
+    """Device-resident LightGlue(features="superpoint") for ragged batches of pairs; adaptive depth and width are
+    evaluated on the device (no host synchronisation inside the layer loop)."""
+
+    def __init__(self, state_dict: Mapping[str, torch.Tensor], device: Optional[torch.device] = None):
+        super().__init__(device)
+        self.num_layers = lightglue_num_layers(state_dict)
+        entries, self.match_bias, self.conf_bias = lightglue_entries(state_dict)
+        self.weights = torch.from_numpy(pack_blob(entries)).to(self.device)
+
+    def match_batch(
+        self,
+        kpts: torch.Tensor,
+        desc: torch.Tensor,
+        n0: Sequence[int],
+        n1: Sequence[int],
+        hw: Sequence[Sequence[int]],
+        depth_confidence: float = LIGHTGLUE_DEPTH_CONFIDENCE,
+        width_confidence: float = LIGHTGLUE_WIDTH_CONFIDENCE,
+        filter_threshold: float = LIGHTGLUE_FILTER_THRESHOLD,
+        pruning_threshold: Optional[int] = LIGHTGLUE_PRUNING_THRESHOLD,
+        return_sim: bool = False,
+    ) -> Dict[str, torch.Tensor]:
+        """kpts [T,2], desc [T,256] concatenated as pair0/img0, pair0/img1, ...; returns matches [T] int32 in ORIGINAL
+        keypoint indices, mscores [T], stop [P] (layers run), kept [2P] (keypoints alive at the final assignment)."""
+        n0 = np.ascontiguousarray(n0, dtype=np.int32)
+        n1 = np.ascontiguousarray(n1, dtype=np.int32)
+        hw = np.ascontiguousarray(hw, dtype=np.int32).reshape(-1, 4)
+        p = len(n0)
+        t = int(n0.sum() + n1.sum())
+        assert kpts.shape == (t, 2) and desc.shape == (t, 256) and kpts.is_contiguous() and desc.is_contiguous()
+        assert kpts.dtype == desc.dtype == torch.float32
+        dsc = self._build_desc(False, n0, n1, hw)
+        ws = self._get_workspace(self._lib.gtsfm_lg_workspace_bytes(p, n0.ctypes.data, n1.ctypes.data))
+        matches = torch.empty(t, dtype=torch.int32, device=self.device)
+        mscores = torch.empty(t, dtype=torch.float32, device=self.device)
+        sim = None
+        if return_sim:
+            sim = torch.zeros(sum(int(a) * ((int(b) + 3) // 4 * 4) for a, b in zip(n0, n1)), dtype=torch.float32, device=self.device)
+        rc = self._lib.gtsfm_lg_forward(
+            self.weights.data_ptr(), self.num_layers, self.match_bias.ctypes.data, self.conf_bias.ctypes.data, p,
+            n0.ctypes.data, n1.ctypes.data, dsc.data_ptr(), kpts.data_ptr(), desc.data_ptr(), float(depth_confidence),
+            float(width_confidence), float(filter_threshold), NO_PRUNING if pruning_threshold is None else int(pruning_threshold),
+            ws.data_ptr(), ws.numel(), matches.data_ptr(), mscores.data_ptr(), _lib.ptr(sim),
+            torch.cuda.current_stream(self.device).cuda_stream,
+        )
+        _lib.check(rc, "gtsfm_lg_forward")
+        out = {
+            "matches": matches, "mscores": mscores,
+            "kept": dsc[2 * p : 4 * p],        # final counts section of the descriptor block
+            "stop": dsc[10 * p : 11 * p] + 1,  # stop-layer section (+1 = number of layers run)
+        }
+        if return_sim:
+            out["sim"] = sim
+        return out
+
+    def match_pair(
+        self, k0: np.ndarray, d0: np.ndarray, k1: np.ndarray, d1: np.ndarray, shape0: Tuple[int, int], shape1: Tuple[int, int],
+        **kwargs,
+    ) -> Dict[str, np.ndarray]:
+        """One pair from host arrays -> upstream's output dict subset: matches (K,2) int64, scores (K,), matches0/1,
+        matching_scores0/1, stop. Empty inputs give empty matches (upstream breaks out of the layer loop)."""
+        n0, n1 = len(k0), len(k1)
+        if n0 == 0 or n1 == 0:
+            return {
+                "matches": np.zeros((0, 2), dtype=np.int64), "scores": np.zeros((0,), dtype=np.float32),
+                "matches0": np.full(n0, -1, dtype=np.int64), "matches1": np.full(n1, -1, dtype=np.int64),
+                "matching_scores0": np.zeros(n0, dtype=np.float32), "matching_scores1": np.zeros(n1, dtype=np.float32), "stop": 1,
+            }
+        dev = self.device
+        f = lambda a, b: torch.from_numpy(np.ascontiguousarray(np.concatenate([a, b], 0), dtype=np.float32)).to(dev)  # noqa: E731
+        out = self.match_batch(f(k0, k1), f(d0, d1), [n0], [n1], [[shape0[0], shape0[1], shape1[0], shape1[1]]], **kwargs)
+        m = out["matches"].cpu().numpy().astype(np.int64)
+        ms = out["mscores"].cpu().numpy()
+        m0 = m[:n0]
+        valid = m0 > -1
+        res = {
+            "matches": np.stack([np.flatnonzero(valid), m0[valid]], -1).astype(np.int64), "scores": ms[:n0][valid],
+            "matches0": m0, "matches1": m[n0:], "matching_scores0": ms[:n0], "matching_scores1": ms[n0:],
+            "stop": int(out["stop"][0]), "kept": out["kept"].cpu().numpy(),
+        }
+        if "sim" in out:
+            res["sim"] = out["sim"].cpu().numpy().reshape(n0, (n1 + 3) // 4 * 4)[:, :n1]
         return res

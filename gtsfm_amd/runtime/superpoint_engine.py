@@ -92,6 +92,7 @@ class SuperPointEngine:
         nms_radius: int = DEFAULT_NMS_RADIUS,
         remove_borders: int = DEFAULT_REMOVE_BORDERS,
         return_score_maps: bool = False,
+        top_k: int = 0,
     ) -> Dict[str, torch.Tensor]:
         """images: device tensor [B,H,W], uint8 or float32 in [0,1]. Returns device tensors:
         count [B] int32, count_raw [B] int32, xy [B,cap,2], scores [B,cap], descriptors [B,cap,256]."""
@@ -99,6 +100,8 @@ class SuperPointEngine:
         assert images.dtype in (torch.uint8, torch.float32)
         b, h, w = images.shape
         cap = capacity or self.default_capacity(h, w, nms_radius)
+        if top_k > 0:
+            cap = top_k  # device-side top-k: the outputs hold at most top_k rows per image
         dev = images.device
         count = torch.empty(b, dtype=torch.int32, device=dev)
         count_raw = torch.empty(b, dtype=torch.int32, device=dev)
@@ -113,7 +116,7 @@ class SuperPointEngine:
         ws = self._workspace(b, h, w)
         rc = self._lib.gtsfm_sp_forward(
             self.weights.data_ptr(), images.data_ptr(), int(images.dtype == torch.uint8), b, h, w,
-            float(keypoint_threshold), int(nms_radius), int(remove_borders), cap, ws.data_ptr(), ws.numel(),
+            float(keypoint_threshold), int(nms_radius), int(remove_borders), cap, int(top_k), ws.data_ptr(), ws.numel(),
             count.data_ptr(), count_raw.data_ptr(), xy.data_ptr(), scores.data_ptr(), desc.data_ptr(),
             _lib.ptr(dense), _lib.ptr(nms), torch.cuda.current_stream(dev).cuda_stream,
         )

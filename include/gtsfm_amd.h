@@ -97,10 +97,14 @@ size_t gtsfm_sp_workspace_bytes(int batch, int height, int width);
  * kp_score_dev    : [batch][capacity] fp32
  * desc_dev        : [batch][capacity][256] fp32, row i <-> keypoint i (the transposed layout the wrapper builds at
  *                   gtsfm/frontend/detector_descriptor/superpoint.py:84)
+ * top_k           : <= 0 returns every keypoint (what SP returns with max_keypoints = -1, as GTSfM runs it). > 0 (then
+ *                   capacity must equal top_k) keeps the top_k responses on the device, in detection order, and
+ *                   describes only those -- the selection gtsfm/common/keypoints.py:89-110 (get_top_k) makes on
+ *                   the host; used by the GPU-resident detect+match pipeline.
  * Optional taps for parity tests (NULL to skip): dense_scores_dev [batch][8*(h/8)][8*(w/8)] (pre-NMS, SP:163-166),
  * nms_scores_dev same shape (SP:167). */
 int gtsfm_sp_forward(const float* packed_weights_dev, const void* image_dev, int image_is_u8, int batch, int height,
-                     int width, float keypoint_threshold, int nms_radius, int remove_borders, int capacity,
+                     int width, float keypoint_threshold, int nms_radius, int remove_borders, int capacity, int top_k,
                      void* workspace_dev, size_t workspace_bytes, int32_t* kp_count_dev, int32_t* kp_count_raw_dev,
                      float* kp_xy_dev, float* kp_score_dev, float* desc_dev, float* dense_scores_dev,
                      float* nms_scores_dev, void* stream);
@@ -118,6 +122,11 @@ int gtsfm_sp_simple_nms(const float* scores_dev, int batch, int h, int w, int ra
 int gtsfm_sp_extract_keypoints(const float* nms_dev, int batch, int h, int w, float threshold, int border, int capacity,
                                int32_t* scratch_dev, int32_t* kp_count_dev, int32_t* kp_count_raw_dev, float* kp_xy_dev,
                                float* kp_score_dev, void* stream);
+/* Top-k by response, survivors in detection order (host analogue: Keypoints.get_top_k,   gtsfm/common/keypoints.py:89-110).
+ * in: kp_score [batch][capacity], kp_xy [batch][capacity][2], kp_count [batch]; out arrays have top_k rows per image. */
+int gtsfm_sp_select_topk(const float* kp_score_dev, const float* kp_xy_dev, const int32_t* kp_count_dev, int batch,
+                         int capacity, int top_k, float* out_xy_dev, float* out_score_dev, int32_t* out_count_dev,
+                         void* stream);
 /* L2-normalise dense descriptors, bilinear sample (align_corners=True), L2-normalise.   replaces SP:80-92,192-196
  * dense: [batch][hc*wc][ld] raw convDb output (256 channels). */
 int gtsfm_sp_sample_descriptors(const float* dense_dev, int ld, int batch, int hc, int wc, const float* kp_xy_dev,
@@ -140,7 +149,7 @@ int gtsfm_pack_blob(int count, const int32_t* kinds, const int32_t* n, const int
  * pair1/img0, ... (T = sum of all counts rows). The int32 descriptor block (counts, per-set row offsets / image
  * shapes, per-pair score-matrix offsets, attention problem lists) is built on the host and uploaded by the caller;
  * LightGlue's point pruning rewrites the counts section on the device. */
-size_t gtsfm_match_desc_ints(int npairs);
+size_t gtsfm_match_desc_ints(int superglue, int npairs, const int32_t* n0_host, const int32_t* n1_host);
 int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* n0_host, const int32_t* n1_host,
                            const int32_t* hw_host, int32_t* desc_host);
 
@@ -164,6 +173,23 @@ int gtsfm_sg_forward(const float* blob_dev, int num_layers, float bin_score, int
                      const int32_t* n1_host, const int32_t* desc_dev, const float* kpts_dev, const float* scores_dev,
                      const float* descriptors_dev, int sinkhorn_iters, float match_threshold, void* workspace_dev,
                      size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* ot_dev, void* stream);
+
+/* LightGlue(features="superpoint").forward for a batch of pairs.          replaces LG (upstream LightGlue._forward;
+ * reference call site gtsfm/frontend/matcher/lightglue_matcher.py:88-110). PARITY UNPINNED: the reference does not
+ * vendor LightGlue's source; this follows the published upstream algorithm (see oracle/lightglue_oracle.py).
+ * kpts_dev [T][2], descriptors_dev [T][256] as above. match_bias_host [num_layers] / conf_bias_host [num_layers-1]:
+ * the scalar biases of the matchability / token-confidence heads. desc_dev is READ-WRITE (live counts, stop layers).
+ * depth_confidence <= 0 disables early stopping; pruning_threshold = INT32_MAX disables point pruning (upstream:
+ * -1 on CPU = always prune, 1024 / 1536 on CUDA without / with flash attention).
+ * matches_dev [T] int32 / mscores_dev [T] as for SuperGlue (indices refer to the ORIGINAL keypoint order).
+ * sim_dev (optional, parity tests): raw similarity matrices over the kept keypoints. After the call the descriptor
+ * block holds the per-pair stop layer and the final (kept) keypoint counts. */
+size_t gtsfm_lg_workspace_bytes(int npairs, const int32_t* n0_host, const int32_t* n1_host);
+int gtsfm_lg_forward(const float* blob_dev, int num_layers, const float* match_bias_host, const float* conf_bias_host,
+                     int npairs, const int32_t* n0_host, const int32_t* n1_host, int32_t* desc_dev,
+                     const float* kpts_dev, const float* descriptors_dev, float depth_confidence,
+                     float width_confidence, float filter_threshold, int pruning_threshold, void* workspace_dev,
+                     size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,161 @@
+"""CPU: host-side logic of the matcher path -- batch descriptor builder, weight preparation (BatchNorm folding, head
+permutation), blob packing, and the multi-process plumbing (gloo, world_size 2)."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from gtsfm_amd.utils import synthetic
+
+
+def test_match_descriptor_block(built_library):
+    from gtsfm_amd.runtime import lib as L
+
+    lib = L.load()
+    n0 = np.array([5, 130], dtype=np.int32)
+    n1 = np.array([7, 1], dtype=np.int32)
+    hw = np.array([[10, 20, 30, 40], [50, 60, 70, 80]], dtype=np.int32)
+    for superglue in (1, 0):
+        size = lib.gtsfm_match_desc_ints(superglue, 2, n0.ctypes.data, n1.ctypes.data)
+        d = np.full(size, -7, dtype=np.int32)
+        assert lib.gtsfm_match_build_desc(superglue, 2, n0.ctypes.data, n1.ctypes.data, hw.ctypes.data, d.ctypes.data) == 0
+        live, orig = d[0:4], d[12:16]
+        assert live.tolist() == orig.tolist() == [5, 7, 130, 1]
+        assert d[20:22].tolist() == [-1, -1]  # stop layers
+        seqs = d[22 : 22 + 24].reshape(4, 6)
+        caps = [5, 7, 130, 1] if superglue else [128, 128, 256, 128]
+        assert seqs[:, 5].tolist() == caps
+        assert seqs[:, 0].tolist() == np.concatenate([[0], np.cumsum(caps)[:-1]]).tolist()  # internal row offsets
+        assert seqs[:, 4].tolist() == [0, 5, 12, 142]  # caller-side (unpadded) offsets
+        assert seqs[:, 2:4].tolist() == [[10, 20], [30, 40], [50, 60], [70, 80]]
+        pairs = d[46 : 46 + 12].view(np.int64).reshape(2, 3)
+        ext = 1 if superglue else 0
+        ld0 = (7 + ext + 3) // 4 * 4
+        assert pairs[0, 0] == 0 and pairs[1, 0] == (5 + ext) * ld0
+        if not superglue:
+            tiles = d[-2 * 5 :]
+            assert tiles[:5].tolist() == [0, 1, 2, 2, 3] and tiles[5:].tolist() == [0, 0, 0, 128, 0]
+    # empty keypoint sets are the caller's business (superglue.py:233-240)
+    n0[0] = 0
+    assert lib.gtsfm_match_build_desc(1, 2, n0.ctypes.data, n1.ctypes.data, hw.ctypes.data, d.ctypes.data) != 0
+    assert b"empty" in lib.gtsfm_last_error()
+
+
+def test_superglue_weight_preparation_is_equivalent(built_library):
+    """BatchNorm folding + head permutation + q/k/v fusion reproduce one propagation layer of the reference in
+    float64 (superglue.py:92-119)."""
+    from gtsfm_amd.runtime.matcher_engine import HEAD_PERM, superglue_entries
+    from oracle import superglue_oracle as sgo
+
+    sd = synthetic.synthetic_superglue_state_dict(num_layers=1)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    entries = superglue_entries(sd)
+    assert len(entries) == 5 + 4 + 1
+    x = torch.randn((1, 256, 40), dtype=torch.float64)
+    src = torch.randn((1, 256, 33), dtype=torch.float64)
+    ref = sgo._propagation(sd64, "gnn.layers.0", x, src)[0].T.numpy()
+    (_, wqkv, bqkv), (_, wm, bm), (_, w0, b0), (_, w1, b1) = entries[5:9]
+    xt, st = x[0].T.numpy(), src[0].T.numpy()
+    q = xt @ wqkv[:256].T + bqkv[:256]
+    k = st @ wqkv[256:512].T + bqkv[256:512]
+    v = st @ wqkv[512:].T + bqkv[512:]
+    att = np.zeros((40, 256))
+    for h in range(4):
+        s = q[:, 64 * h : 64 * h + 64] @ k[:, 64 * h : 64 * h + 64].T / 8.0
+        p = np.exp(s - s.max(1, keepdims=True))
+        att[:, 64 * h : 64 * h + 64] = (p / p.sum(1, keepdims=True)) @ v[:, 64 * h : 64 * h + 64]
+    msg = att @ wm.T + bm
+    hid = np.maximum(np.concatenate([xt, msg], 1) @ w0.T + b0, 0)
+    out = hid @ w1.T + b1
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
+    assert sorted(HEAD_PERM.tolist()) == list(range(256))
+
+
+def test_lightglue_weight_preparation_regroups_qkv(built_library):
+    from gtsfm_amd.runtime.matcher_engine import lightglue_entries
+
+    sd = synthetic.synthetic_lightglue_state_dict(num_layers=2)
+    entries, match_bias, conf_bias = lightglue_entries(sd)
+    assert len(entries) == 1 + 2 * 14 + 1 and match_bias.shape == (2,) and conf_bias.shape == (2,)
+    w = sd["transformers.0.self_attn.Wqkv.weight"].double().numpy()
+    x = np.random.default_rng(0).standard_normal((5, 256))
+    qkv = (x @ w.T).reshape(5, 4, 64, 3)  # upstream unflatten(-1, (heads, head_dim, 3))
+    new = x @ entries[1][1].T
+    np.testing.assert_allclose(new[:, :256].reshape(5, 4, 64), qkv[..., 0], atol=1e-12)
+    np.testing.assert_allclose(new[:, 256:512].reshape(5, 4, 64), qkv[..., 1], atol=1e-12)
+    np.testing.assert_allclose(new[:, 512:].reshape(5, 4, 64), qkv[..., 2], atol=1e-12)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, tmp: str):
+    import torch.distributed as dist
+
+    from gtsfm_amd import parallel
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    try:
+        # weight broadcast
+        blob = torch.arange(1000, dtype=torch.float32) * 0.5 if rank == 0 else None
+        got = parallel.broadcast_packed_weights(blob, 1000, dev)
+        assert torch.equal(got, torch.arange(1000, dtype=torch.float32) * 0.5)
+        # ownership
+        n_img = 5
+        mine = parallel.partition_images(n_img, rank, world)
+        pairs = parallel.exhaustive_pairs(n_img)
+        my_pairs = parallel.partition_pairs(pairs, rank, world)
+        # feature exchange between the detect and match phases
+        local = {}
+        for i in mine:
+            k = 3 + i
+            local[i] = (torch.full((k, 2), float(i)), torch.full((k,), i + 0.5), torch.full((k, 256), i + 0.25))
+        feats = parallel.gather_features(local, n_img, 16, dev)
+        assert sorted(feats) == list(range(n_img))
+        for i, (xy, sc, de) in feats.items():
+            assert xy.shape == (3 + i, 2) and float(xy[0, 0]) == i and float(sc[0]) == i + 0.5 and float(de[-1, -1]) == i + 0.25
+        # variable-length results back to every rank (incl. an empty match list)
+        res = {p: np.stack([np.arange(p[0] + p[1]), np.arange(p[0] + p[1]) + 1], 1).astype(np.int64) for p in my_pairs}
+        if my_pairs:
+            res[my_pairs[0]] = np.zeros((0, 2), dtype=np.int64)
+        allres = parallel.gather_matches(res, dev)
+        assert sorted(allres) == sorted(pairs)
+        firsts = {parallel.partition_pairs(pairs, r, world)[0] for r in range(world)}
+        for p, m in allres.items():
+            if p in firsts:
+                assert m.shape == (0, 2)
+            else:
+                assert m.shape == (p[0] + p[1], 2) and m[-1, 1] == p[0] + p[1]
+        with open(os.path.join(tmp, f"ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multiprocess_plumbing_gloo_world2(tmp_path):
+    """N > 1 path on CPU: gloo, world_size 2 -- weight broadcast, image / pair partitioning, feature all-gather, ragged
+    result gather (the same calls run over RCCL on the GPUs)."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_partitions_cover_everything_once():
+    from gtsfm_amd import parallel
+
+    pairs = parallel.exhaustive_pairs(9)
+    assert len(pairs) == 36
+    for world in (1, 2, 3, 8):
+        got = sum((parallel.partition_pairs(pairs, r, world) for r in range(world)), [])
+        assert sorted(got) == pairs
+        imgs = sum((parallel.partition_images(9, r, world) for r in range(world)), [])
+        assert sorted(imgs) == list(range(9))

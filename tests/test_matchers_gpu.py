@@ -1,0 +1,364 @@
+"""GPU parity tests of the matcher HIP paths (attention, SuperGlue, LightGlue) through the C ABI.
+
+Tolerances (BASELINE.json north_star): match indices bit-exact; match scores within 1e-4 fp32 (observed ~2e-6 for
+SuperGlue, ~2e-5 for LightGlue). SuperGlue is pinned on golden vectors produced by the reference's own superglue.py;
+LightGlue parity is UNPINNED (source absent from the reference) and reads "HIP path == oracle/lightglue_oracle.py".
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from gtsfm_amd.utils import synthetic
+from oracle import lightglue_oracle as lgo
+from oracle import superglue_oracle as sgo
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-4
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def lib(built_library):
+    from gtsfm_amd.runtime import lib as L
+
+    return L.load()
+
+
+@pytest.fixture(scope="module")
+def sg_sd():
+    return synthetic.synthetic_superglue_state_dict()
+
+
+@pytest.fixture(scope="module")
+def sg_engine(gpu_device, sg_sd):
+    from gtsfm_amd.runtime.matcher_engine import SuperGlueEngine
+
+    return SuperGlueEngine(sg_sd, gpu_device)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------------------------
+
+
+def _ref_attention(q, k, v, scale):
+    nq, nk = q.shape[0], k.shape[0]
+    qh, kh, vh = (t.view(-1, 4, 64).transpose(0, 1) for t in (q, k, v))
+    return (torch.softmax(qh @ kh.transpose(1, 2) * scale, -1) @ vh).transpose(0, 1).reshape(nq, 256)
+
+
+def test_attention_ragged_batch(lib, gpu_device):
+    """softmax(q k^T / 8) v per head (superglue.py:85-89) on a ragged batch: self and cross problems, strided packed
+    qkv buffer, counts smaller than the row capacity (rows beyond a count must stay untouched)."""
+    counts = [100, 70, 257, 1, 513]
+    caps = [128, 70, 300, 4, 513]
+    offs = np.concatenate([[0], np.cumsum(caps)])[:-1]
+    total = int(sum(caps))
+    gen = torch.Generator().manual_seed(0)
+    qkv = torch.randn((total, 768), generator=gen)
+    qkv[:, :512] *= 2.0
+    problems = [(0, 0), (1, 1), (0, 1), (1, 0), (2, 3), (3, 2), (4, 4), (2, 4)]
+    prob_arr = torch.tensor([[offs[a], a, offs[b], b] for a, b in problems], dtype=torch.int32, device=gpu_device)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=gpu_device)
+    d = qkv.to(gpu_device)
+    for pi, (a, b) in enumerate(problems):
+        out = torch.full((total, 256), float("nan"), device=gpu_device)
+        rc = lib.gtsfm_attention_f32(d.data_ptr(), 768, d.data_ptr() + 256 * 4, 768, d.data_ptr() + 512 * 4, 768, out.data_ptr(), 256,
+                                     prob_arr[pi : pi + 1].contiguous().data_ptr(), cnt.data_ptr(), 1, counts[a], 4, 0.125, _stream())
+        assert rc == 0, lib.gtsfm_last_error()
+        torch.cuda.synchronize()
+        qa = qkv[offs[a] : offs[a] + counts[a], :256]
+        kb = qkv[offs[b] : offs[b] + counts[b], 256:512]
+        vb = qkv[offs[b] : offs[b] + counts[b], 512:]
+        ref = _ref_attention(qa, kb, vb, 0.125)
+        got = out.cpu()
+        assert float((got[offs[a] : offs[a] + counts[a]] - ref).abs().max()) < 5e-6
+        untouched = torch.ones(total, dtype=torch.bool)
+        untouched[offs[a] : offs[a] + counts[a]] = False
+        assert torch.isnan(got[untouched]).all()
+    # all problems in one launch == one at a time
+    out_all = torch.zeros((total, 256), device=gpu_device)
+    sel = prob_arr[[0, 4, 6]].contiguous()  # disjoint query ranges
+    rc = lib.gtsfm_attention_f32(d.data_ptr(), 768, d.data_ptr() + 256 * 4, 768, d.data_ptr() + 512 * 4, 768, out_all.data_ptr(), 256,
+                                 sel.data_ptr(), cnt.data_ptr(), 3, max(counts), 4, 0.125, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref0 = _ref_attention(qkv[:100, :256], qkv[:100, 256:512], qkv[:100, 512:], 0.125)
+    assert float((out_all[:100].cpu() - ref0).abs().max()) < 5e-6
+
+
+def test_attention_peaked_softmax(lib, gpu_device):
+    """Online-softmax rescaling across key tiles: a late key dominates every row (max jumps after several tiles)."""
+    nq, nk = 200, 700
+    gen = torch.Generator().manual_seed(1)
+    q, k, v = (torch.randn((n, 256), generator=gen) for n in (nq, nk, nk))
+    k[650] = 0
+    k[650, :64] = q[:, :64].mean(0) * 50  # head 0: key 650 (in the 11th tile) wins by a large margin
+    ref = _ref_attention(q, k, v, 0.125)
+    qd, kd, vd = q.to(gpu_device), k.to(gpu_device), v.to(gpu_device)
+    out = torch.empty((nq, 256), device=gpu_device)
+    prob = torch.tensor([[0, 0, 0, 1]], dtype=torch.int32, device=gpu_device)
+    cnt = torch.tensor([nq, nk], dtype=torch.int32, device=gpu_device)
+    rc = lib.gtsfm_attention_f32(qd.data_ptr(), 256, kd.data_ptr(), 256, vd.data_ptr(), 256, out.data_ptr(), 256, prob.data_ptr(),
+                                 cnt.data_ptr(), 1, nq, 4, 0.125, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert float((out.cpu() - ref).abs().max()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SuperGlue
+# ------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("path", sorted(GOLDEN.glob("superglue_*.npz")), ids=lambda p: p.stem)
+def test_superglue_matches_golden(sg_engine, path):
+    """Whole model vs golden vectors produced by the reference's own superglue.py (20 and 100 Sinkhorn iterations)."""
+    g = np.load(path)
+    shp0, shp1 = tuple(int(v) for v in g["shape0"]), tuple(int(v) for v in g["shape1"])
+    k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(int(g["n0"]), int(g["n1"]), shp0, shp1, seed=int(g["seed"]))
+    res = sg_engine.match_pair(k0, s0, d0, k1, s1, d1, shp0, shp1, sinkhorn_iterations=int(g["iters"]), return_ot=True)
+    np.testing.assert_array_equal(res["matches0"], g["matches0"])  # bit-exact indices
+    np.testing.assert_array_equal(res["matches1"], g["matches1"])
+    np.testing.assert_allclose(res["matching_scores0"], g["matching_scores0"], rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(res["matching_scores1"], g["matching_scores1"], rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(res["ot"][::3, ::3], g["ot_sample"], rtol=0, atol=2e-4)  # log-space OT matrix, |values| ~ 10..60
+
+
+def test_superglue_ragged_batch_equals_single_pairs(sg_engine, sg_sd):
+    """A ragged batch (different keypoint counts and image shapes per pair) gives exactly the per-pair results, and
+    those match the oracle."""
+    specs = [(96, 80, (240, 320), (200, 300), 11), (130, 257, (480, 640), (480, 640), 21), (1, 5, (64, 64), (64, 64), 13), (300, 129, (600, 400), (400, 600), 22)]
+    feats = [synthetic.synthetic_pair_features(a, b, s0, s1, seed=sd) for a, b, s0, s1, sd in specs]
+    dev = sg_engine.device
+    kp = T(np.concatenate([np.concatenate([f[0], f[3]]) for f in feats])).to(dev)
+    sc = T(np.concatenate([np.concatenate([f[1], f[4]]) for f in feats])).to(dev)
+    de = T(np.concatenate([np.concatenate([f[2], f[5]]) for f in feats])).to(dev)
+    n0, n1 = [s[0] for s in specs], [s[1] for s in specs]
+    hw = [[s[2][0], s[2][1], s[3][0], s[3][1]] for s in specs]
+    out = sg_engine.match_batch(kp, sc, de, n0, n1, hw, sinkhorn_iterations=20)
+    m, ms = out["matches"].cpu().numpy(), out["mscores"].cpu().numpy()
+    row = 0
+    for (a, b, s0, s1, _), f in zip(specs, feats):
+        single = sg_engine.match_pair(f[0], f[1], f[2], f[3], f[4], f[5], s0, s1, sinkhorn_iterations=20)
+        np.testing.assert_array_equal(m[row : row + a], single["matches0"])
+        np.testing.assert_array_equal(m[row + a : row + a + b], single["matches1"])
+        np.testing.assert_array_equal(ms[row : row + a], single["matching_scores0"])
+        with torch.no_grad():
+            ora = sgo.superglue_forward(sg_sd, T(f[0])[None], T(f[3])[None], T(f[1])[None], T(f[4])[None], T(f[2]).T[None].contiguous(),
+                                        T(f[5]).T[None].contiguous(), s0, s1, sinkhorn_iterations=20)
+        np.testing.assert_array_equal(single["matches0"], ora["matches0"][0].numpy())
+        np.testing.assert_array_equal(single["matches1"], ora["matches1"][0].numpy())
+        np.testing.assert_allclose(single["matching_scores0"], ora["matching_scores0"][0].numpy(), rtol=0, atol=SCORE_TOL)
+        np.testing.assert_allclose(single["matching_scores1"], ora["matching_scores1"][0].numpy(), rtol=0, atol=SCORE_TOL)
+        row += a + b
+
+
+@pytest.mark.parametrize("iters", [0, 1, 100])
+def test_superglue_sinkhorn_iteration_counts(sg_engine, sg_sd, iters):
+    """The iteration count is a parameter: GTSfM runs 20, the third-party default / BASELINE config 4 is 100
+    (SURVEY.md F5); 0 and 1 exercise the u = v = 0 start (superglue.py:143)."""
+    k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(150, 170, (480, 640), (480, 640), seed=31)
+    res = sg_engine.match_pair(k0, s0, d0, k1, s1, d1, (480, 640), (480, 640), sinkhorn_iterations=iters, return_ot=True)
+    with torch.no_grad():
+        ora = sgo.superglue_forward(sg_sd, T(k0)[None], T(k1)[None], T(s0)[None], T(s1)[None], T(d0).T[None].contiguous(),
+                                    T(d1).T[None].contiguous(), (480, 640), (480, 640), sinkhorn_iterations=iters, return_intermediates=True)
+    np.testing.assert_array_equal(res["matches0"], ora["matches0"][0].numpy())
+    np.testing.assert_allclose(res["ot"], ora["ot"][0].numpy(), rtol=0, atol=2e-4)
+
+
+def test_superglue_plugin_contract(gpu_device, sg_sd, tmp_path):
+    """SuperGlueMatcher.match vs the restated reference wrapper (gtsfm/frontend/matcher/superglue_matcher.py:75-113)
+    and the reference's contract tests (tests/frontend/matcher/test_matcher_base.py:51-107,
+    test_superglue_matcher.py:24-41): dtype uint32, indices in range, one-to-one, empty input, error behaviour."""
+    from gtsfm_amd.common.keypoints import Keypoints
+    from gtsfm_amd.frontend.matcher.superglue_matcher import SuperGlueMatcher
+
+    path = tmp_path / "superglue_outdoor.pth"
+    torch.save(sg_sd, str(path))
+    matcher = SuperGlueMatcher(weights_path=path)
+    k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(200, 180, (480, 640), (360, 500), seed=41)
+    kp0, kp1 = Keypoints(k0, responses=s0), Keypoints(k1, responses=s1)
+    m = matcher.match(kp0, kp1, d0, d1, im_shape_i1=(480, 640, 3), im_shape_i2=(360, 500, 3))
+    ref = sgo.match(sg_sd, k0, k1, s0, s1, d0, d1, (480, 640, 3), (360, 500, 3), sinkhorn_iterations=20)
+    assert isinstance(m, np.ndarray) and m.dtype == np.uint32 and m.shape[1] == 2
+    np.testing.assert_array_equal(m, ref)
+    assert m.shape[0] > 20 and m[:, 0].max() < 200 and m[:, 1].max() < 180
+    assert len(set(m[:, 0].tolist())) == len(m) == len(set(m[:, 1].tolist()))
+    empty = matcher.match(Keypoints(np.zeros((0, 2), np.float32), responses=np.zeros(0, np.float32)), kp1,
+                          np.zeros((0, 256), np.float32), d1, (480, 640, 3), (360, 500, 3))
+    assert empty.shape == (0, 2) and empty.dtype == np.uint32
+    with pytest.raises(ValueError):
+        matcher.match(Keypoints(k0), kp1, d0, d1, (480, 640, 3), (360, 500, 3))
+    with pytest.raises(Exception):
+        matcher.match(kp0, kp1, d0[:, :128], d1[:, :128], (480, 640, 3), (360, 500, 3))
+
+
+def test_superglue_full_size_properties(sg_engine):
+    """BASELINE config-4 scale (N = 2048 per image, 100 Sinkhorn iterations): size-independent properties --
+    determinism, one-to-one mutual consistency, score thresholds, planted correspondences recovered."""
+    n = 2048
+    k0, s0, d0, k1, s1, d1, gt = synthetic.synthetic_pair_features(n, n, (1024, 1024), (1024, 1024), seed=5)
+    a = sg_engine.match_pair(k0, s0, d0, k1, s1, d1, (1024, 1024), (1024, 1024), sinkhorn_iterations=100)
+    b = sg_engine.match_pair(k0, s0, d0, k1, s1, d1, (1024, 1024), (1024, 1024), sinkhorn_iterations=100)
+    for key in a:
+        np.testing.assert_array_equal(a[key], b[key])
+    m0, m1 = a["matches0"], a["matches1"]
+    v0 = m0 > -1
+    assert v0.sum() > 500
+    assert np.array_equal(m1[m0[v0]], np.flatnonzero(v0))  # mutual
+    assert len(set(m0[v0].tolist())) == v0.sum()  # one-to-one
+    assert (a["matching_scores0"][v0] > 0.2).all() and (a["matching_scores0"] >= 0).all() and (a["matching_scores0"] <= 1.0 + 1e-5).all()
+    planted = gt > -1
+    assert (m0[planted] == gt[planted]).mean() > 0.9
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# LightGlue (parity unpinned: HIP path == oracle restatement)
+# ------------------------------------------------------------------------------------------------------------------
+
+LG_CASES = [
+    # (weight kwargs, n0, n1, pruning threshold, expects early stop, expects pruning)
+    ({}, 300, 280, 1536, False, False),
+    ({}, 300, 280, -1, False, False),
+    ({"conf_bias": 2.0, "conf_gain": 4.0}, 300, 280, None, True, False),
+    ({"conf_bias": 1.0, "conf_gain": 6.0, "match_bias": -2.0, "match_gain": 8.0}, 300, 280, -1, False, True),
+    ({"conf_bias": 1.0, "conf_gain": 6.0, "match_bias": -2.0, "match_gain": 8.0}, 700, 650, 256, False, True),
+    ({}, 1, 3, 1536, False, False),
+    ({}, 129, 128, 1536, False, False),
+]
+
+
+@pytest.mark.parametrize("kw,n0,n1,pth,early,pruned", LG_CASES)
+def test_lightglue_matches_oracle(gpu_device, kw, n0, n1, pth, early, pruned):
+    from gtsfm_amd.runtime.matcher_engine import LightGlueEngine
+
+    sd = synthetic.synthetic_lightglue_state_dict(**kw)
+    eng = LightGlueEngine(sd, gpu_device)
+    k0, _, d0, k1, _, d1, _ = synthetic.synthetic_pair_features(n0, n1, (480, 640), (400, 600), seed=3)
+    res = eng.match_pair(k0, d0, k1, d1, (480, 640), (400, 600), pruning_threshold=pth)
+    with torch.no_grad():
+        ora = lgo.lightglue_forward(sd, T(k0)[None], T(k1)[None], T(d0)[None], T(d1)[None], (480, 640), (400, 600),
+                                    pruning_threshold=pth, return_intermediates=True)
+    assert res["stop"] == ora["stop"] and (ora["stop"] < 9) == early
+    kept = (ora["ind0"].shape[1], ora["ind1"].shape[1])
+    assert tuple(res["kept"].tolist()) == kept and ((kept[0] < n0) or (kept[1] < n1)) == pruned
+    np.testing.assert_array_equal(res["matches0"], ora["matches0"][0].numpy())
+    np.testing.assert_array_equal(res["matches1"], ora["matches1"][0].numpy())
+    np.testing.assert_array_equal(res["matches"], ora["matches"].numpy())
+    assert res["matches"].dtype == np.int64
+    np.testing.assert_allclose(res["matching_scores0"], ora["matching_scores0"][0].numpy(), rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(res["matching_scores1"], ora["matching_scores1"][0].numpy(), rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(res["scores"], ora["scores"].numpy(), rtol=0, atol=SCORE_TOL)
+
+
+def test_lightglue_batch_mixed_depths(gpu_device):
+    """Pairs that stop at different layers and prune differently share one launch sequence (device-side control flow);
+    each must equal its stand-alone result."""
+    from gtsfm_amd.runtime.matcher_engine import LightGlueEngine
+
+    sd = synthetic.synthetic_lightglue_state_dict(conf_bias=1.2, conf_gain=5.0, match_bias=-1.0, match_gain=8.0)
+    eng = LightGlueEngine(sd, gpu_device)
+    specs = [(300, 280, 3, 0.6), (150, 400, 4, 0.0), (513, 511, 5, 0.9), (64, 64, 6, 0.3)]
+    feats = [synthetic.synthetic_pair_features(a, b, (480, 640), (480, 640), overlap=ov, seed=sdd) for a, b, sdd, ov in specs]
+    dev = eng.device
+    kp = T(np.concatenate([np.concatenate([f[0], f[3]]) for f in feats])).to(dev)
+    de = T(np.concatenate([np.concatenate([f[2], f[5]]) for f in feats])).to(dev)
+    n0, n1 = [s[0] for s in specs], [s[1] for s in specs]
+    out = eng.match_batch(kp, de, n0, n1, [[480, 640, 480, 640]] * 4, pruning_threshold=100)
+    m, ms = out["matches"].cpu().numpy(), out["mscores"].cpu().numpy()
+    stops = out["stop"].cpu().numpy().tolist()
+    row = 0
+    singles = []
+    for (a, b, _, _), f in zip(specs, feats):
+        single = eng.match_pair(f[0], f[2], f[3], f[5], (480, 640), (480, 640), pruning_threshold=100)
+        singles.append(single["stop"])
+        np.testing.assert_array_equal(m[row : row + a], single["matches0"])
+        np.testing.assert_array_equal(m[row + a : row + a + b], single["matches1"])
+        np.testing.assert_array_equal(ms[row : row + a], single["matching_scores0"])
+        row += a + b
+    assert stops == singles
+
+
+def test_lightglue_plugin_contract(gpu_device, tmp_path):
+    """LightGlueMatcher.match (gtsfm/frontend/matcher/lightglue_matcher.py:43-112): (K,2) int64, in range,
+    one-to-one, empty input -> empty result, ValueError without responses."""
+    from gtsfm_amd.common.keypoints import Keypoints
+    from gtsfm_amd.frontend.matcher.lightglue_matcher import LightGlueMatcher
+
+    sd = synthetic.synthetic_lightglue_state_dict()
+    path = tmp_path / "superpoint_lightglue.pth"
+    torch.save(sd, str(path))
+    matcher = LightGlueMatcher(features="superpoint", weights_path=path)
+    k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(220, 190, (480, 640), (360, 500), seed=43)
+    kp0, kp1 = Keypoints(k0, responses=s0), Keypoints(k1, responses=s1)
+    m = matcher.match(kp0, kp1, d0, d1, im_shape_i1=(480, 640, 3), im_shape_i2=(360, 500, 3))
+    ref = lgo.match(sd, k0, k1, d0, d1, (480, 640, 3), (360, 500, 3))
+    assert m.dtype == np.int64 and m.shape[1] == 2
+    np.testing.assert_array_equal(m, ref)
+    assert m.shape[0] > 20 and m[:, 0].max() < 220 and m[:, 1].max() < 190 and np.all(np.diff(m[:, 0]) > 0)
+    assert len(set(m[:, 1].tolist())) == len(m)
+    empty = matcher.match(Keypoints(np.zeros((0, 2), np.float32), responses=np.zeros(0, np.float32)), kp1,
+                          np.zeros((0, 256), np.float32), d1, (480, 640, 3), (360, 500, 3))
+    assert empty.shape == (0, 2)
+    with pytest.raises(ValueError):
+        matcher.match(Keypoints(k0), kp1, d0, d1, (480, 640, 3), (360, 500, 3))
+
+
+def test_lightglue_full_size_properties(gpu_device):
+    """BASELINE config-3 scale (N = 2048 per image): determinism, mutual one-to-one matches, planted
+    correspondences recovered, early stopping never changes which layer's assignment head is reported."""
+    from gtsfm_amd.runtime.matcher_engine import LightGlueEngine
+
+    eng = LightGlueEngine(synthetic.synthetic_lightglue_state_dict(), gpu_device)
+    n = 2048
+    k0, _, d0, k1, _, d1, gt = synthetic.synthetic_pair_features(n, n, (1024, 1024), (1024, 1024), seed=9)
+    a = eng.match_pair(k0, d0, k1, d1, (1024, 1024), (1024, 1024))
+    b = eng.match_pair(k0, d0, k1, d1, (1024, 1024), (1024, 1024))
+    for key in ("matches0", "matches1", "matching_scores0", "matches"):
+        np.testing.assert_array_equal(a[key], b[key])
+    m0, m1 = a["matches0"], a["matches1"]
+    v0 = m0 > -1
+    assert v0.sum() > 500 and np.array_equal(m1[m0[v0]], np.flatnonzero(v0))
+    assert (a["matching_scores0"][v0] > 0.1).all()
+    planted = gt > -1
+    assert (m0[planted] == gt[planted]).mean() > 0.9
+
+
+def test_resident_pipeline_equals_plugins(gpu_device, sg_sd, tmp_path):
+    """GPU-resident detect -> top-k -> match pipeline (features never leave HBM) vs the per-image / per-pair plugin
+    calls that go through host numpy like the reference's Dask tasks."""
+    from gtsfm_amd.common.image import Image
+    from gtsfm_amd.frontend.detector_descriptor.superpoint import SuperPointDetectorDescriptor
+    from gtsfm_amd.frontend.matcher.superglue_matcher import SuperGlueMatcher
+    from gtsfm_amd.runtime.matcher_engine import SuperGlueEngine
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+    from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+
+    sp_sd = synthetic.synthetic_superpoint_state_dict()
+    torch.save(sp_sd, str(tmp_path / "sp.pth"))
+    torch.save(sg_sd, str(tmp_path / "sg.pth"))
+    imgs = np.stack([synthetic.synthetic_gray_image(160, 200, s) for s in (61, 62, 63)])
+    pipe = FrontEndPipeline(SuperPointEngine(sp_sd, gpu_device), SuperGlueEngine(sg_sd, gpu_device), max_keypoints=150, pair_chunk=2)
+    feats = pipe.detect(torch.from_numpy(imgs).to(gpu_device))
+    pairs = [(0, 1), (0, 2), (1, 2)]
+    got = pipe.matches_to_numpy(pipe.match(feats, pairs, [(160, 200)] * 3), dtype=np.uint32)
+    det = SuperPointDetectorDescriptor(max_keypoints=150, weights_path=tmp_path / "sp.pth")
+    matcher = SuperGlueMatcher(weights_path=tmp_path / "sg.pth")
+    host = [det.detect_and_describe(Image(value_array=im)) for im in imgs]
+    for i, j in pairs:
+        # the plugin's top-k order is argpartition's; sort both keypoint sets into detection order to compare
+        oi = np.lexsort((host[i][0].coordinates[:, 0], host[i][0].coordinates[:, 1]))
+        oj = np.lexsort((host[j][0].coordinates[:, 0], host[j][0].coordinates[:, 1]))
+        ki = host[i][0].extract_indices(oi)
+        kj = host[j][0].extract_indices(oj)
+        np.testing.assert_array_equal(ki.coordinates, feats["xy"][i, : len(ki)].cpu().numpy())
+        ref = matcher.match(ki, kj, host[i][1][oi], host[j][1][oj], (160, 200, 1), (160, 200, 1))
+        np.testing.assert_array_equal(got[(i, j)], ref)

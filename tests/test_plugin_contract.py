@@ -71,3 +71,43 @@ def test_rgb_to_gray_matches_fixed_point_formula():
     ref = np.rint(0.299 * rgb[..., 0] + 0.587 * rgb[..., 1] + 0.114 * rgb[..., 2])
     assert np.abs(gray.astype(int) - ref.astype(int)).max() <= 1
     assert rgb_to_gray_u8(gray) is gray
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# matchers
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def test_matcher_plugins_lazy_picklable_registered(tmp_path):
+    """tests/frontend/matcher/test_matcher_base.py:102-107 (pickle) + registry / cache-key naming."""
+    from gtsfm_amd.frontend.matcher.lightglue_matcher import LightGlueMatcher
+    from gtsfm_amd.frontend.matcher.matcher_base import MatcherBase
+    from gtsfm_amd.frontend.matcher.superglue_matcher import SuperGlueMatcher
+
+    sg_path = tmp_path / "superglue_outdoor.pth"
+    torch.save(synthetic.synthetic_superglue_state_dict(num_layers=2), str(sg_path))
+    with pytest.raises(FileNotFoundError):
+        SuperGlueMatcher(weights_path=tmp_path / "nope.pth")
+    sg = SuperGlueMatcher(use_cuda=True, use_outdoor_model=True, weights_path=sg_path)
+    lg = LightGlueMatcher(features="superpoint")  # lazy like the reference: nothing is touched at construction
+    for obj, name in ((sg, "SuperGlueMatcher"), (lg, "LightGlueMatcher")):
+        assert isinstance(obj, MatcherBase) and isinstance(obj, GTSFMProcess)
+        assert type(obj).__name__ == name and obj._model is None
+        clone = pickle.loads(pickle.dumps(obj))
+        assert clone._model is None
+        assert obj.get_ui_metadata().display_name == "Matcher"
+    assert sg._config["sinkhorn_iterations"] == 20  # gtsfm/frontend/matcher/superglue_matcher.py:27
+
+
+def test_matcher_input_validation_needs_no_gpu(tmp_path):
+    from gtsfm_amd.frontend.matcher.superglue_matcher import SuperGlueMatcher
+
+    sg_path = tmp_path / "superglue_outdoor.pth"
+    torch.save(synthetic.synthetic_superglue_state_dict(num_layers=1), str(sg_path))
+    sg = SuperGlueMatcher(weights_path=sg_path)
+    k = np.zeros((3, 2), dtype=np.float32)
+    with pytest.raises(ValueError):
+        sg.match(Keypoints(k), Keypoints(k), np.zeros((3, 256), np.float32), np.zeros((3, 256), np.float32), (8, 8, 3), (8, 8, 3))
+    r = np.ones(3, dtype=np.float32)
+    with pytest.raises(Exception, match="256"):
+        sg.match(Keypoints(k, responses=r), Keypoints(k, responses=r), np.zeros((3, 128), np.float32), np.zeros((3, 128), np.float32), (8, 8, 3), (8, 8, 3))

@@ -306,7 +306,7 @@ def test_edge_cases(engine):
     tiny = torch.empty(1024, dtype=torch.uint8, device=dev)
     cnt = torch.empty(1, dtype=torch.int32, device=dev)
     buf = torch.empty((1, 16, 256), device=dev)
-    rc = lib.gtsfm_sp_forward(engine.weights.data_ptr(), img.data_ptr(), 1, 1, 160, 160, 0.005, 4, 4, 16, tiny.data_ptr(), tiny.numel(),
+    rc = lib.gtsfm_sp_forward(engine.weights.data_ptr(), img.data_ptr(), 1, 1, 160, 160, 0.005, 4, 4, 16, 0, tiny.data_ptr(), tiny.numel(),
                               cnt.data_ptr(), None, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), None, None, _stream())
     assert rc == -3 and b"workspace" in lib.gtsfm_last_error()
 
@@ -372,3 +372,48 @@ def test_plugin_matches_oracle_wrapper(gpu_device, sd, tmp_path):
         np.testing.assert_array_equal(kps.coordinates[oa], rc[ob])
         np.testing.assert_allclose(kps.responses[oa], rs[ob], rtol=0, atol=SCORE_TOL)
         np.testing.assert_allclose(desc[oa], rd[ob], rtol=0, atol=DESC_TOL)
+
+
+@pytest.mark.parametrize("k", [1, 100, 333, 5000])
+def test_device_topk_equals_host_selection(engine, k):
+    """The GPU-resident path keeps the top-k responses on the device (Keypoints.get_top_k on the host in the
+    reference, gtsfm/common/keypoints.py:89-110): same SET as argpartition on the full detection, rows in detection
+    order, values bit-identical to the unselected run."""
+    imgs = np.stack([synthetic.synthetic_gray_image(200, 264, s) for s in (51, 52)])
+    dev = engine.device
+    full = engine.forward(torch.from_numpy(imgs).to(dev))
+    sel = engine.forward(torch.from_numpy(imgs).to(dev), top_k=k)
+    for b in range(2):
+        n = int(full["count"][b])
+        kk = int(sel["count"][b])
+        assert kk == min(n, k) and int(sel["count_raw"][b]) == n
+        fs = full["scores"][b, :n].cpu().numpy()
+        fxy = full["xy"][b, :n].cpu().numpy().astype(np.int64)
+        sxy = sel["xy"][b, :kk].cpu().numpy().astype(np.int64)
+        lin_full = fxy[:, 1] * 264 + fxy[:, 0]
+        lin_sel = sxy[:, 1] * 264 + sxy[:, 0]
+        assert np.all(np.diff(lin_sel) > 0)
+        pos = np.searchsorted(lin_full, lin_sel)
+        assert np.array_equal(lin_full[pos], lin_sel)
+        if kk < n:
+            kth = np.sort(fs)[::-1][kk - 1]
+            assert (fs[pos] >= kth).all() and (np.delete(fs, pos) <= kth).all()
+        assert np.array_equal(sel["scores"][b, :kk].cpu().numpy(), fs[pos])
+        assert torch.equal(sel["descriptors"][b, :kk].cpu(), full["descriptors"][b, :n].cpu()[pos])
+
+
+def test_device_topk_with_ties(lib, gpu_device):
+    """Ties at the k-th value are resolved by detection order; fewer candidates than k are all kept."""
+    scores = torch.tensor([[0.5, 0.9, 0.5, 0.5, 0.1, 0.5, 0.7, 0.0], [0.3, 0.2, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]], device=gpu_device)
+    xy = torch.arange(32, dtype=torch.float32, device=gpu_device).reshape(2, 8, 2)
+    count = torch.tensor([7, 2], dtype=torch.int32, device=gpu_device)
+    oxy = torch.full((2, 4, 2), -1.0, device=gpu_device)
+    osc = torch.full((2, 4), -1.0, device=gpu_device)
+    ocnt = torch.empty(2, dtype=torch.int32, device=gpu_device)
+    _check(lib, lib.gtsfm_sp_select_topk(scores.data_ptr(), xy.data_ptr(), count.data_ptr(), 2, 8, 4, oxy.data_ptr(), osc.data_ptr(),
+                                         ocnt.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    assert ocnt.tolist() == [4, 2]
+    assert osc[0].tolist() == [0.5, pytest.approx(0.9), 0.5, pytest.approx(0.7)]  # 0.9, 0.7 and the first two 0.5s, in order
+    assert oxy[0, :, 0].tolist() == [0.0, 2.0, 4.0, 12.0]
+    assert osc[1, :2].tolist() == [pytest.approx(0.3), pytest.approx(0.2)]
