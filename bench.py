@@ -93,6 +93,69 @@ def measure_conv_roofline(lib, device, batch: int, h: int, w: int, reps: int = 5
     }
 
 
+def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5):
+    """Dominant kernel of the detect+match workload (attention_mfma_kernel, ~50 % of GPU time): one launch = the self
+    attention of `npairs` pairs (2 sequences x 4 heads each) at N = n, timed with HIP events on the launch stream.
+    Algorithmic work: 1024 * N^2 FLOP per sequence per layer."""
+    from gtsfm_amd.runtime import lib as L
+
+    stream = torch.cuda.current_stream(device)
+    nseq = 2 * npairs
+    qkv = torch.randn((nseq * n, 768), device=device)
+    out = torch.empty((nseq * n, 256), device=device)
+    probs = torch.tensor([[s * n, s, s * n, s] for s in range(nseq)], dtype=torch.int32, device=device)
+    counts = torch.full((nseq,), n, dtype=torch.int32, device=device)
+    args = (qkv.data_ptr(), 768, qkv.data_ptr() + 256 * 4, 768, qkv.data_ptr() + 512 * 4, 768, out.data_ptr(), 256, probs.data_ptr(),
+            counts.data_ptr(), nseq, n, 4, 0.125, stream.cuda_stream)
+    L.check(lib.gtsfm_attention_f32(*args), "attention")
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        L.check(lib.gtsfm_attention_f32(*args), "attention")
+    e1.record(stream)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 1024.0 * n * n * nseq
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {
+        "bound": "mfma",
+        "kernel": "attention_mfma_kernel",
+        "achieved": round(achieved, 2),
+        "peak": FP32_MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+        "traffic": None,
+        "avg_launch_ms": round(ms, 4),
+        "flops_per_launch": flops,
+        "launch_shape": f"{nseq} sequences x 4 heads, N = {n} queries = keys, head_dim 64",
+    }
+
+
+def measure_gemm_roofline(lib, device, rows: int, k: int, n: int, reps: int = 5):
+    """gemm_mfma_kernel at one of the matcher's projection shapes (rows x k -> n)."""
+    from gtsfm_amd.runtime import lib as L
+
+    stream = torch.cuda.current_stream(device)
+    a = torch.randn((rows, k), device=device)
+    w = torch.randn(lib.gtsfm_packed_linear_floats(k, n), device=device) * 0.05
+    bias = torch.zeros((n + 63) // 64 * 64, device=device)
+    c = torch.empty((rows, n), device=device)
+    args = (a.data_ptr(), k, rows, None, k, w.data_ptr(), bias.data_ptr(), n, c.data_ptr(), n, 0, None, 0, 1.0, 0, stream.cuda_stream)
+    L.check(lib.gtsfm_linear_f32(*args), "linear")
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        L.check(lib.gtsfm_linear_f32(*args), "linear")
+    e1.record(stream)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    achieved = 2.0 * rows * k * n / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_mfma_kernel", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 4), "launch_shape": f"{rows} x {k} -> {n}"}
+
+
 def cpu_baseline(h: int, w: int, n_images: int, matcher: str, n_keypoints: int, sinkhorn_iters: int):
     """The oracle (kind "port": restatement of the reference's torch CPU path, bit-exact with it in the build
     container) on a bounded sample: ``n_images`` detections and one pair match, on all host cores."""
@@ -268,7 +331,15 @@ def main() -> None:
             },
             "tflops": round(flops_step * world / (ms_per_step * 1e-3) / 1e12, 2),
         }
-        result["roofline"] = measure_conv_roofline(lib, device, min(n, 16), h, w)
+        conv_roof = measure_conv_roofline(lib, device, min(n, 16), h, w)
+        if detect_only:
+            result["roofline"] = conv_roof
+        else:  # dominant kernel of this workload first; the other two MFMA kernels alongside
+            result["roofline"] = measure_attention_roofline(lib, device, args.keypoints, min(args.pair_chunk, max(1, len(pairs))))
+            result["roofline_other"] = [
+                measure_gemm_roofline(lib, device, 2 * min(args.pair_chunk, max(1, len(pairs))) * args.keypoints, 256, 768),
+                conv_roof,
+            ]
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(h, w, 2, args.matcher, args.keypoints, args.sinkhorn)
         print(json.dumps(result), flush=True)

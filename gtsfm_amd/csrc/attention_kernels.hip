@@ -19,10 +19,15 @@
 #define AT_QW 32       // queries per wave
 #define AT_QB 128      // queries per workgroup
 #define AT_ROW 68      // LDS row stride (floats)
+#define AT_TILE (AT_KT * AT_ROW)
 
 __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) float Ks[AT_KT * AT_ROW];
-    __shared__ __attribute__((aligned(16))) float Vt[64 * AT_ROW];
+    // LDS: two K tiles and two V tiles ([key][d], row stride 68). While the waves work on tile t out of one pair of
+    // buffers, tile t+1 travels global -> registers (issued before the MFMAs) -> the other pair (written after them):
+    // one barrier per tile and no exposed global latency.
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ks = lds;
+    float* Vs = lds + 2 * AT_TILE;
     const AttnProblem pr = p.problems[blockIdx.z];
     const int nq = p.counts[pr.q_cnt_idx], nk = p.counts[pr.k_cnt_idx];
     const int q0 = blockIdx.x * AT_QB;
@@ -48,60 +53,73 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnParams p) {
     f32x16 o0, o1;  // O^T: rows d 0..31 / 32..63, column q
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    // softmax runs in the base-2 domain: exp(x) = exp2(x log2 e), one v_exp_f32 per element
+    const float scale2 = p.scale * 1.44269504088896340736f;
     float m = -__builtin_inff(), l = 0.f;
 
     const float* kbase = p.k + (size_t)pr.k_off * p.ldk + h * 64;
     const float* vbase = p.v + (size_t)pr.k_off * p.ldv + h * 64;
 
-    for (int k0 = 0; k0 < nk; k0 += AT_KT) {
-        __syncthreads();
-        // stage K tile [key][d]: 64 rows x 16 float4
-        for (int idx = tid; idx < AT_KT * 16; idx += 256) {
-            const int row = idx >> 4, q4 = idx & 15;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k0 + row < nk) v = *reinterpret_cast<const f32x4*>(kbase + (size_t)(k0 + row) * p.ldk + q4 * 4);
-            *reinterpret_cast<f32x4*>(&Ks[row * AT_ROW + q4 * 4]) = v;
-        }
-        // stage V tile transposed [d][key]: item = (d, group of 4 keys); global reads coalesced along d
-        for (int idx = tid; idx < 64 * 16; idx += 256) {
-            const int d = idx & 63, kg = idx >> 6;
-            f32x4 v;
+    // staging: thread t moves float4 #(t + 256 i), i = 0..3, of the K tile and of the V tile (64 rows x 16 float4 each)
+    const int srow = tid >> 4, sq = tid & 15;
+    f32x4 kst[4], vst[4];
+    auto stage_load = [&](int k0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = k0 + kg * 4 + e;
-                v[e] = (key < nk) ? vbase[(size_t)key * p.ldv + d] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int key = k0 + srow + 16 * i;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < nk) {
+                kv = *reinterpret_cast<const f32x4*>(kbase + (size_t)key * p.ldk + sq * 4);
+                vv = *reinterpret_cast<const f32x4*>(vbase + (size_t)key * p.ldv + sq * 4);
             }
-            *reinterpret_cast<f32x4*>(&Vt[d * AT_ROW + kg * 4]) = v;
+            kst[i] = kv, vst[i] = vv;
         }
-        __syncthreads();
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&Ks[buf * AT_TILE + (srow + 16 * i) * AT_ROW + sq * 4]) = kst[i];
+            *reinterpret_cast<f32x4*>(&Vs[buf * AT_TILE + (srow + 16 * i) * AT_ROW + sq * 4]) = vst[i];
+        }
+    };
+
+    const int ntiles = (nk + AT_KT - 1) / AT_KT;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * AT_KT;
+        const float* Kt = Ks + (t & 1) * AT_TILE;
+        const float* Vt = Vs + (t & 1) * AT_TILE;
+        if (t + 1 < ntiles) stage_load(k0 + AT_KT);
 
         // S^T = K Q^T  (two 32-key tiles)
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Ks[j * AT_ROW + t * 8 + kh * 4]);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Ks[(32 + j) * AT_ROW + t * 8 + kh * 4]);
-            mt_step(s0, s1, a0, a1, qreg[t]);
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Kt[j * AT_ROW + u * 8 + kh * 4]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Kt[(32 + j) * AT_ROW + u * 8 + kh * 4]);
+            mt_step(s0, s1, a0, a1, qreg[u]);
         }
         // scale, mask, online softmax (per query = per lane; the two lane halves hold different keys of the same query)
         float mloc = -__builtin_inff();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            s0[r] = (key < nk) ? s0[r] * p.scale : -__builtin_inff();
-            s1[r] = (key + 32 < nk) ? s1[r] * p.scale : -__builtin_inff();
+            s0[r] = (key < nk) ? s0[r] * scale2 : -__builtin_inff();
+            s1[r] = (key + 32 < nk) ? s1[r] * scale2 : -__builtin_inff();
             mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
         }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float mnew = fmaxf(m, mloc);  // finite: key k0 is always valid
-        const float alpha = expf(m - mnew);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
         float lsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = expf(s0[r] - mnew);
-            s1[r] = expf(s1[r] - mnew);
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] - mnew);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r] - mnew);
             lsum += s0[r] + s1[r];
         }
         lsum += __shfl_xor(lsum, 32, 64);
@@ -112,21 +130,26 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnParams p) {
             o0[r] *= alpha;
             o1[r] *= alpha;
         }
-        // O^T += V^T P^T : accumulator register r of S^T tile T holds key 32T + (r&3) + 8(r>>2) + 4kh -> it IS the B
-        // operand of k-step r; the A operand reads the matching 4 consecutive keys of V^T with one ds_read_b128.
+        // O^T += V^T P^T. Accumulator register r of S^T tile T holds key 32T + (r&3) + 8(r>>2) + 4kh, so it IS the B
+        // operand of k-step r; the A operand V^T[d = lane][key] is a conflict-free row read of the row-major V tile.
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Vt[j * AT_ROW + 8 * g + 4 * kh]);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Vt[(32 + j) * AT_ROW + 8 * g + 4 * kh]);
-            const f32x4 b = {s0[4 * g], s0[4 * g + 1], s0[4 * g + 2], s0[4 * g + 3]};
-            mt_step(o0, o1, a0, a1, b);
+        for (int T = 0; T < 2; ++T) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int key = 32 * T + 8 * g + 4 * kh;
+                f32x4 a0, a1, b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a0[e] = Vt[(key + e) * AT_ROW + j];
+                    a1[e] = Vt[(key + e) * AT_ROW + 32 + j];
+                    b[e] = T ? s1[4 * g + e] : s0[4 * g + e];
+                }
+                mt_step(o0, o1, a0, a1, b);
+            }
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Vt[j * AT_ROW + 32 + 8 * g + 4 * kh]);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Vt[(32 + j) * AT_ROW + 32 + 8 * g + 4 * kh]);
-            const f32x4 b = {s1[4 * g], s1[4 * g + 1], s1[4 * g + 2], s1[4 * g + 3]};
-            mt_step(o0, o1, a0, a1, b);
+        if (t + 1 < ntiles) {
+            stage_store((t + 1) & 1);
+            __syncthreads();
         }
     }
 
@@ -143,11 +166,11 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnParams p) {
 }
 
 int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t stream) {
-    GTSFM_CHECK_ARG(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldo % 4 == 0, "attention: leading dimensions must be multiples of 4");
+    GTSFM_CHECK_ARG(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, "attention: leading dimensions must be multiples of 4");
     GTSFM_CHECK_ARG(p.heads > 0, "attention: heads must be positive");
     if (nproblems <= 0 || max_q <= 0) return GTSFM_OK;
     dim3 grid(ceil_div(max_q, AT_QB), p.heads, nproblems);
-    hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(256), (size_t)4 * AT_TILE * sizeof(float), stream, p);
     GTSFM_CHECK_LAUNCH("attention_mfma_kernel");
     return GTSFM_OK;
 }

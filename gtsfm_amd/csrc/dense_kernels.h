@@ -32,6 +32,8 @@ struct GemmParams {
     const int* tile_cnt_idx;  // [M tiles] index into live_counts
     const int* tile_row0;     // [M tiles] first row of the tile within its sequence
     const int* live_counts;
+    int nb_per_wg;  // filled by the launcher: 128-column blocks one workgroup walks
+    int debug;      // developer ablation switches (GTSFM_GEMM_DEBUG): 1 = skip epilogue, 2 = skip A loads
 };
 
 int launch_conv3x3(const ConvParams& p, hipStream_t stream);

@@ -5,6 +5,8 @@
 //   thirdparty/SuperGluePretrainedNetwork/models/superglue.py:49-60,98-107,110-119,254
 // See mfma_tiles.h for the tiling and the packed weight layout.
 
+#include <stdlib.h>
+
 #include "dense_kernels.h"
 #include "mfma_tiles.h"
 
@@ -134,91 +136,186 @@ int launch_conv3x3(const ConvParams& pin, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// GEMM: C[M, N] (+)= A[M, K] * W[N, K]^T with packed W. Workgroup tile 128 x 64, K staged in 64-deep chunks.
+// GEMM: C[M, N] = epilogue(A[M, K] * W[N, K]^T) with packed W. Workgroup tile 128 rows x 128 columns (4 waves as
+// 2 (M) x 2 (N), wave tile 64 x 64 = four 32x32 accumulators), K staged through LDS in 64-deep chunks.
+// Block order: blockIdx.x walks the column blocks of one row tile first, so the A tile staged by neighbouring
+// workgroups is the same and stays L2-resident.
 // ---------------------------------------------------------------------------------------------------------------
 
+__device__ __forceinline__ void gemm_step(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, const f32x4 a0, const f32x4 a1,
+                                          const f32x4 b0, const f32x4 b1) {
+    // The weight fragment is passed as the MFMA's A operand and the activation fragment as its B operand: the
+    // accumulator then holds, per lane, ONE output row and 16 output columns in groups of 4 consecutive ones, so the
+    // epilogue moves 16 bytes per lane per instruction (4x fewer store instructions than the row-per-register form;
+    // the store tail is issue-bound, cdna_hip_programming.md T21).
+#define GS(e)                                                                 \
+    c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.e, a0.e, c00, 0, 0, 0);     \
+    c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a0.e, c01, 0, 0, 0);     \
+    c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.e, a1.e, c10, 0, 0, 0);     \
+    c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a1.e, c11, 0, 0, 0);
+    GS(x) GS(y) GS(z) GS(w)
+#undef GS
+}
+
+
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmParams p) {
+    // A workgroup owns a 128-row tile and walks p.nb_per_wg 128-column blocks of the output with ONE software
+    // pipeline: the loop runs over (column block, 64-deep K chunk) pairs; while the waves run the MFMAs of one chunk
+    // out of one LDS buffer, the A rows of the next chunk travel global/L2 -> registers (issued before the MFMAs) ->
+    // the other buffer (written after them). One barrier per chunk; the prologue is paid once per workgroup and the
+    // epilogue stores of a column block drain under the next block's MFMAs.
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int M = p.m_dev ? *p.m_dev : p.M;
-    const int m0 = blockIdx.x * MT_TILE_M;
+    const int mt = blockIdx.y;
+    const int m0 = mt * MT_TILE_M;
     if (p.tile_cnt_idx) {
         // ragged batch with 128-row-aligned sequences: this tile belongs to one sequence whose live row count sits in
         // device memory (LightGlue early stop / point pruning shrink it without host synchronisation)
-        const int c = p.live_counts[p.tile_cnt_idx[blockIdx.x]];
-        const int r0 = p.tile_row0[blockIdx.x];
+        const int c = p.live_counts[p.tile_cnt_idx[mt]];
+        const int r0 = p.tile_row0[mt];
         if (r0 >= c) return;
         M = min(M, m0 + c - r0);
     }
     if (m0 >= M) return;
-    const int nb = blockIdx.y;
+    const int nblocks = (p.N + 63) >> 6;                     // 64-column blocks in the output
+    const int cb0 = blockIdx.x * p.nb_per_wg;                // first 128-column block of this workgroup
+    const int ncb = min(p.nb_per_wg, ((p.N + 127) >> 7) - cb0);
     const int total_steps = p.K >> 3;
-    const float* __restrict__ wp = p.wpack + (size_t)nb * total_steps * MT_PACK_STEP_FLOATS;
-
+    const int nchunks = (p.K + 63) >> 6;
     const int j = lane & 31, kh = lane >> 5;
-    const int col = nb * 64 + wn * 32 + j;
-    const float bias = p.bias ? p.bias[col] : 0.f;  // padded to a multiple of 64
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        acc0[r] = bias;
-        acc1[r] = bias;
-    }
     const int a_base0 = (64 * wm + j) * MT_LDS_ROW + kh * 4;
     const int a_base1 = a_base0 + 32 * MT_LDS_ROW;
+    constexpr int BUF = MT_TILE_M * MT_LDS_ROW;
 
-    int kstep = 0;
-    f32x4 bcur = mt_load_b(wp, 0, wn, lane);
-    for (int k0 = 0; k0 < p.K; k0 += 64) {
-        if (k0 > 0) __syncthreads();
-        for (int idx = tid; idx < MT_TILE_M * 16; idx += 256) {
-            const int row = idx >> 4, q = idx & 15;
-            const int gr = m0 + row, gk = k0 + q * 4;
+    // staging: thread t moves float4 #(t + 256 i), i = 0..7: row = idx / 16, 16-byte column = idx % 16
+    f32x4 st[8];
+    const int srow = tid >> 4, sq = tid & 15;
+    auto stage_load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int gr = m0 + srow + 16 * i, gk = k0 + sq * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gr < M && gk < p.K) v = *reinterpret_cast<const f32x4*>(p.A + (size_t)gr * p.lda + gk);
-            *reinterpret_cast<f32x4*>(&lds[row * MT_LDS_ROW + q * 4]) = v;
+            if (gr < M && gk < p.K && !(p.debug & 2)) v = *reinterpret_cast<const f32x4*>(p.A + (size_t)gr * p.lda + gk);
+            st[i] = v;
         }
-        __syncthreads();
-        const int nsteps = min(8, (p.K - k0) >> 3);
-        if (nsteps == 8) {
+    };
+    auto stage_store = [&](float* buf) {
 #pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) {
-                const int nxt = (kstep + 1 < total_steps) ? kstep + 1 : kstep;
-                const f32x4 bnext = mt_load_b(wp, nxt, wn, lane);
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[a_base0 + c8 * 8]);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[a_base1 + c8 * 8]);
-                mt_step(acc0, acc1, a0, a1, bcur);
-                bcur = bnext;
-                ++kstep;
-            }
-        } else {
-            for (int c8 = 0; c8 < nsteps; ++c8) {
-                const int nxt = (kstep + 1 < total_steps) ? kstep + 1 : kstep;
-                const f32x4 bnext = mt_load_b(wp, nxt, wn, lane);
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[a_base0 + c8 * 8]);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[a_base1 + c8 * 8]);
-                mt_step(acc0, acc1, a0, a1, bcur);
-                bcur = bnext;
-                ++kstep;
-            }
-        }
-    }
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&buf[(srow + 16 * i) * MT_LDS_ROW + sq * 4]) = st[i];
+    };
+    // B operands: global k-step index g = column-block index * total_steps + k-step; they run two steps ahead so that
+    // their (in-order) wait never has to cover the younger A-row loads
+    const int gsteps = ncb * total_steps;
+    auto ldb = [&](int g, int half) {
+        g = g < gsteps ? g : gsteps - 1;
+        const int cbi = g / total_steps, s = g - cbi * total_steps;
+        int nb = (cb0 + cbi) * 2 + wn;
+        nb = nb < nblocks ? nb : nblocks - 1;
+        return mt_load_b(p.wpack + (size_t)nb * total_steps * MT_PACK_STEP_FLOATS, s, half, lane);
+    };
 
-    if (col >= p.N) return;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    stage_load(0);
+    f32x4 b0c = ldb(0, 0), b1c = ldb(0, 1), b0n = ldb(1, 0), b1n = ldb(1, 1);
+    stage_store(lds);
+    __syncthreads();
+    f32x16 c00, c01, c10, c11;
+    int g = 0;
+    const int iters = ncb * nchunks;
+    int it = 0;
+    for (int cbi = 0; cbi < ncb; ++cbi) {
+        const int nb = (cb0 + cbi) * 2 + wn;  // 64-column block of this wave
+        const bool active = nb < nblocks;     // waves beyond N still help staging
+        const int colb = nb * 64 + 4 * kh;  // + 32 * (column half) + 8 * (r >> 2) + (r & 3)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + 64 * wm + 32 * t + mt_acc_row(r, lane);
-            if (row < M) {
-                float v = t ? acc1[r] : acc0[r];
-                if (p.alpha != 1.0f) v *= p.alpha;
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.res) v = p.res[(size_t)row * p.ldres + col] + v;
-                p.C[(size_t)row * p.ldc + p.c_coff + col] = v;
+            const int cc = colb + 8 * (r >> 2) + (r & 3);
+            const float bb0 = (p.bias && active) ? p.bias[cc] : 0.f;  // bias is padded to a multiple of 64
+            const float bb1 = (p.bias && active) ? p.bias[cc + 32] : 0.f;
+            c00[r] = c10[r] = bb0;
+            c01[r] = c11[r] = bb1;
+        }
+        for (int c = 0; c < nchunks; ++c, ++it) {
+            const float* buf = lds + (it & 1) * BUF;
+            if (it + 1 < iters) stage_load(((c + 1 < nchunks) ? c + 1 : 0) * 64);
+            const int nsteps = min(8, total_steps - c * 8);
+            if (nsteps == 8) {
+                f32x4 a0 = *reinterpret_cast<const f32x4*>(&buf[a_base0]);
+                f32x4 a1 = *reinterpret_cast<const f32x4*>(&buf[a_base1]);
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const f32x4 b0f = ldb(g + 2, 0), b1f = ldb(g + 2, 1);
+                    f32x4 a0n = a0, a1n = a1;
+                    if (c8 < 7) {  // A fragments run one k-step ahead (within the chunk)
+                        a0n = *reinterpret_cast<const f32x4*>(&buf[a_base0 + (c8 + 1) * 8]);
+                        a1n = *reinterpret_cast<const f32x4*>(&buf[a_base1 + (c8 + 1) * 8]);
+                    }
+                    gemm_step(c00, c01, c10, c11, a0, a1, b0c, b1c);
+                    b0c = b0n, b1c = b1n, b0n = b0f, b1n = b1f;
+                    a0 = a0n, a1 = a1n;
+                    ++g;
+                    // pin the issue order per k-step: the two B loads (consumed two steps later) and the two A reads (next
+                    // step) go out FIRST, then the 16 MFMAs -- left alone, the scheduler sinks the loads next to their use
+                    // and every step stalls on vmcnt / lgkmcnt
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    if (c8 < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                }
+            } else {
+                for (int c8 = 0; c8 < nsteps; ++c8) {
+                    const f32x4 b0f = ldb(g + 2, 0), b1f = ldb(g + 2, 1);
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(&buf[a_base0 + c8 * 8]);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(&buf[a_base1 + c8 * 8]);
+                    gemm_step(c00, c01, c10, c11, a0, a1, b0c, b1c);
+                    b0c = b0n, b1c = b1n, b0n = b0f, b1n = b1f;
+                    ++g;
+                }
+            }
+            if (c == nchunks - 1 && active && !(p.debug & 1)) {
+                // the row offsets are loop-invariant; keep the compiler from hoisting 64 addresses out of the column-block
+                // loop (they would live across the whole pipeline and spill): make the base opaque per block
+                int row_base = m0 + 64 * wm + j;
+                asm volatile("" : "+v"(row_base));
+                const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!p.res || (p.ldres & 3) == 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {  // t = 2 * (row half) + (column half)
+                    const int row = row_base + 32 * (t >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (row >= M) continue;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int col = colb + 32 * (t & 1) + 8 * gq;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = (t == 0) ? c00[4 * gq + e] : (t == 1) ? c01[4 * gq + e] : (t == 2) ? c10[4 * gq + e] : c11[4 * gq + e];
+                            if (p.alpha != 1.0f) x *= p.alpha;
+                            if (p.relu) x = fmaxf(x, 0.f);
+                            v[e] = x;
+                        }
+                        float* cp = p.C + (size_t)row * p.ldc + p.c_coff + col;
+                        if (vec_ok) {
+                            if (col < p.N) {
+                                if (p.res) {
+                                    const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldres + col);
+                                    v = rr + v;
+                                }
+                                *reinterpret_cast<f32x4*>(cp) = v;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (col + e < p.N) cp[e] = p.res ? p.res[(size_t)row * p.ldres + col + e] + v[e] : v[e];
+                        }
+                    }
+                }
+            }
+            if (it + 1 < iters) {
+                stage_store(lds + ((it + 1) & 1) * BUF);
+                __syncthreads();
             }
         }
     }
@@ -228,9 +325,20 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     GTSFM_CHECK_ARG(p.K % 8 == 0 && p.K >= 8, "gemm: K must be a multiple of 8 (got %d)", p.K);
     GTSFM_CHECK_ARG(p.lda % 4 == 0, "gemm: lda must be a multiple of 4 (got %d)", p.lda);
     if (p.M <= 0) return GTSFM_OK;
-    dim3 grid(ceil_div(p.M, MT_TILE_M), ceil_div(p.N, 64));
-    const size_t lds_bytes = (size_t)MT_TILE_M * MT_LDS_ROW * sizeof(float);
-    hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), lds_bytes, stream, p);
+    // column blocks per workgroup: as many as possible (prologue paid once, A tile L2-hot) while the grid still holds
+    // >= 2 workgroups per CU
+    GemmParams q = p;
+    const int ncb_total = ceil_div(p.N, 128), mtiles = ceil_div(p.M, MT_TILE_M);
+    int nbw = ncb_total;
+    while (nbw > 1 && (long long)mtiles * ceil_div(ncb_total, nbw) < 512) --nbw;
+    static const char* env = getenv("GTSFM_GEMM_NB");
+    if (env && atoi(env) > 0) nbw = atoi(env);
+    q.nb_per_wg = nbw;
+    static const char* dbg = getenv("GTSFM_GEMM_DEBUG");
+    q.debug = dbg ? atoi(dbg) : 0;
+    dim3 grid(ceil_div(ncb_total, nbw), mtiles);
+    const size_t lds_bytes = (size_t)2 * MT_TILE_M * MT_LDS_ROW * sizeof(float);
+    hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), lds_bytes, stream, q);
     GTSFM_CHECK_LAUNCH("gemm_mfma_kernel");
     return GTSFM_OK;
 }
