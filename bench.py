@@ -261,7 +261,10 @@ def main() -> None:
 
     h = w = args.size
     n = args.images
-    imgs = np.stack([synthetic.synthetic_gray_image(h, w, 1000 * rank + i) for i in range(n)])
+    # overlapping views: every image is a crop of one seeded canvas, shifted by multiples of the 8-px SuperPoint cell, so
+    # that exhaustive pairs share content (non-trivial match lists) while every image is still detected independently
+    canvas = synthetic.synthetic_gray_image(h + 8 * n, w + 8 * n, 1000 + rank)
+    imgs = np.stack([canvas[8 * i : 8 * i + h, 8 * ((7 * i) % n) : 8 * ((7 * i) % n) + w] for i in range(n)])
     images = torch.from_numpy(imgs).to(device)  # inputs resident in HBM before the timed region
     pairs = parallel.exhaustive_pairs(n)[: args.pairs] if matcher is not None else []
     pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk)
@@ -340,7 +343,7 @@ def main() -> None:
                 measure_gemm_roofline(lib, device, 2 * min(args.pair_chunk, max(1, len(pairs))) * args.keypoints, 256, 768),
                 conv_roof,
             ]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(h, w, 2, args.matcher, args.keypoints, args.sinkhorn)
         print(json.dumps(result), flush=True)
     if dist is not None:

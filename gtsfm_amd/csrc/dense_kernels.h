@@ -13,6 +13,11 @@ struct ConvParams {
     int B, H, W, Cin, Cout;
     int relu, pool;      // pool: fused 2x2/stride-2 max-pool, Ho = H/2, Wo = W/2 (floor)
     int tiles_x, tiles_y;  // filled by the launcher
+    // optional fused first layer: when img != null the input activation is relu(conv1a(img)) computed on the fly
+    const void* img;   // [B][H][W] gray image, fp32 or uint8
+    int img_is_u8;
+    const float* w1a;  // conv1a weights [9 taps][64]
+    const float* b1a;  // conv1a bias [64]
 };
 
 struct GemmParams {

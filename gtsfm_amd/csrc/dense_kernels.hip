@@ -20,6 +20,10 @@
 #define CV_HW (CV_TW + 2)
 #define CV_HALO_PIX ((CV_TH + 2) * CV_HW)
 
+// FUSE_C1A: the input activation is not read from HBM but recomputed on the fly from the gray image: the halo tile of
+// conv1b's input IS relu(conv1a(image)) (superpoint.py:148-149), 9 fma per value in conv1a_kernel's tap order (bit-identical
+// to the stand-alone kernel). Removes conv1a's 256 B/pixel write and conv1b's 360 B/pixel read.
+template <bool FUSE_C1A>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -57,13 +61,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
     for (int cc = 0; cc < nchunks; ++cc) {
         if (cc > 0) __syncthreads();
         // stage the halo tile of this 64-channel chunk: 180 pixels x 16 float4
-        for (int idx = tid; idx < CV_HALO_PIX * 16; idx += 256) {
-            const int pix = idx >> 4, q = idx & 15;
-            const int gy = y0 - 1 + pix / CV_HW, gx = x0 - 1 + pix % CV_HW;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                v = *reinterpret_cast<const f32x4*>(in_b + ((size_t)gy * p.W + gx) * p.in_stride + cc * 64 + q * 4);
-            *reinterpret_cast<f32x4*>(&lds[pix * MT_LDS_ROW + q * 4]) = v;
+        if (FUSE_C1A) {
+            float* w1 = lds + CV_HALO_PIX * MT_LDS_ROW;  // [9 taps][64] + [64] bias
+            for (int idx = tid; idx < 10 * 64 / 4; idx += 256)
+                *reinterpret_cast<f32x4*>(&w1[idx * 4]) = *reinterpret_cast<const f32x4*>((idx < 144 ? p.w1a : p.b1a - 576) + idx * 4);
+            __syncthreads();
+            const size_t img_b = (size_t)b * p.H * p.W;
+            for (int idx = tid; idx < CV_HALO_PIX * 16; idx += 256) {
+                const int pix = idx >> 4, q = idx & 15;
+                const int gy = y0 - 1 + pix / CV_HW, gx = x0 - 1 + pix % CV_HW;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                    v = *reinterpret_cast<const f32x4*>(&w1[576 + q * 4]);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int iy = gy + ky - 1, ix = gx + kx - 1;
+                            float a = 0.f;
+                            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                                a = p.img_is_u8 ? (float)reinterpret_cast<const uint8_t*>(p.img)[img_b + (size_t)iy * p.W + ix] / 255.0f
+                                                : reinterpret_cast<const float*>(p.img)[img_b + (size_t)iy * p.W + ix];
+                            const f32x4 wt = *reinterpret_cast<const f32x4*>(&w1[(ky * 3 + kx) * 64 + q * 4]);
+                            v.x = fmaf(a, wt.x, v.x);
+                            v.y = fmaf(a, wt.y, v.y);
+                            v.z = fmaf(a, wt.z, v.z);
+                            v.w = fmaf(a, wt.w, v.w);
+                        }
+                    }
+                    v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                }
+                *reinterpret_cast<f32x4*>(&lds[pix * MT_LDS_ROW + q * 4]) = v;
+            }
+        } else {
+            for (int idx = tid; idx < CV_HALO_PIX * 16; idx += 256) {
+                const int pix = idx >> 4, q = idx & 15;
+                const int gy = y0 - 1 + pix / CV_HW, gx = x0 - 1 + pix % CV_HW;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    v = *reinterpret_cast<const f32x4*>(in_b + ((size_t)gy * p.W + gx) * p.in_stride + cc * 64 + q * 4);
+                *reinterpret_cast<f32x4*>(&lds[pix * MT_LDS_ROW + q * 4]) = v;
+            }
         }
         __syncthreads();
         for (int tap = 0; tap < 9; ++tap) {
@@ -129,8 +167,14 @@ int launch_conv3x3(const ConvParams& pin, hipStream_t stream) {
     p.tiles_x = ceil_div(p.W, CV_TW);
     p.tiles_y = ceil_div(p.H, CV_TH);
     dim3 grid(p.B * p.tiles_x * p.tiles_y, ceil_div(p.Cout, 64));
-    const size_t lds_bytes = (size_t)CV_HALO_PIX * MT_LDS_ROW * sizeof(float);
-    hipLaunchKernelGGL(conv3x3_mfma_kernel, grid, dim3(256), lds_bytes, stream, p);
+    size_t lds_bytes = (size_t)CV_HALO_PIX * MT_LDS_ROW * sizeof(float);
+    if (p.img) {
+        GTSFM_CHECK_ARG(p.Cin == 64 && p.w1a && p.b1a, "conv3x3: the fused first layer needs Cin == 64 and conv1a weights");
+        lds_bytes += 640 * sizeof(float);
+        hipLaunchKernelGGL(conv3x3_mfma_kernel<true>, grid, dim3(256), lds_bytes, stream, p);
+    } else {
+        hipLaunchKernelGGL(conv3x3_mfma_kernel<false>, grid, dim3(256), lds_bytes, stream, p);
+    }
     GTSFM_CHECK_LAUNCH("conv3x3_mfma_kernel");
     return GTSFM_OK;
 }

@@ -76,37 +76,54 @@ __global__ void lg_rotary_kernel(float* __restrict__ qkv, int ld, int ncols /*51
     }
 }
 
-// y = GELU(LayerNorm(x)) over rows of 512 (eps 1e-5, affine), in place. One wave per row, 8 elements per lane.
+// y = GELU(LayerNorm(x)) over rows of 512 (eps 1e-5, affine), in place. One wave owns LN_ROWS consecutive rows (all
+// loads issued up front for memory-level parallelism), 8 elements per lane per row.
+#define LN_ROWS 4
 __global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__ x, int ld, const SeqDesc* __restrict__ seqs,
                                                              const int* __restrict__ counts, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta) {
     const SeqDesc sq = seqs[blockIdx.y];
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= counts[sq.cnt_idx]) return;
-    const int row = sq.row_off + i;
+    const int n = counts[sq.cnt_idx];
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS;
+    if (i0 >= n) return;
     const int lane = threadIdx.x & 63;
-    float* p = x + (size_t)row * ld + lane * 8;
-    f32x4 a = *reinterpret_cast<f32x4*>(p), b = *reinterpret_cast<f32x4*>(p + 4);
-    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    float sum = 0.f;
+    f32x4 a[LN_ROWS], b[LN_ROWS];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sum += v[e];
-    const float mean = wave_sum(sum) / 512.0f;
-    float ssq = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float d = v[e] - mean;
-        ssq += d * d;
+    for (int r = 0; r < LN_ROWS; ++r) {
+        const int i = min(i0 + r, n - 1);
+        const float* p = x + (size_t)(sq.row_off + i) * ld + lane * 8;
+        a[r] = *reinterpret_cast<const f32x4*>(p);
+        b[r] = *reinterpret_cast<const f32x4*>(p + 4);
     }
-    const float var = wave_sum(ssq) / 512.0f;
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + lane * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + lane * 8 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + lane * 8), b1 = *reinterpret_cast<const f32x4*>(beta + lane * 8 + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float y = (v[e] - mean) * rstd * gamma[lane * 8 + e] + beta[lane * 8 + e];
-        v[e] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+    for (int r = 0; r < LN_ROWS; ++r) {
+        if (i0 + r >= n) break;
+        float v[8] = {a[r].x, a[r].y, a[r].z, a[r].w, b[r].x, b[r].y, b[r].z, b[r].w};
+        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += v[e];
+        const float mean = wave_sum(sum) / 512.0f;
+        float ssq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = v[e] - mean;
+            ssq += d * d;
+        }
+        const float var = wave_sum(ssq) / 512.0f;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float y = (v[e] - mean) * rstd * gm[e] + bt[e];
+            v[e] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+        }
+        float* p = x + (size_t)(sq.row_off + i0 + r) * ld + lane * 8;
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
     }
-    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
 }
 
 // out[t] = act(dot(x[t, :256], w) + b): token-confidence and matchability heads (Linear(256, 1)). One wave per token.
@@ -155,7 +172,7 @@ int launch_lg_rotary(float* qkv, int ld, int ncols, const float* enc, const SeqD
 int launch_layernorm_gelu(float* x, int ld, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* gamma,
                           const float* beta, hipStream_t stream) {
     if (nseq <= 0 || max_n <= 0) return GTSFM_OK;
-    hipLaunchKernelGGL(layernorm_gelu_kernel, dim3(ceil_div(max_n, 4), nseq), dim3(256), 0, stream, x, ld, seqs, counts, gamma, beta);
+    hipLaunchKernelGGL(layernorm_gelu_kernel, dim3(ceil_div(max_n, 4 * LN_ROWS), nseq), dim3(256), 0, stream, x, ld, seqs, counts, gamma, beta);
     GTSFM_CHECK_LAUNCH("layernorm_gelu_kernel");
     return GTSFM_OK;
 }

@@ -177,8 +177,7 @@ SpWorkspace sp_workspace_layout(int B, int H, int W) {
         o += align_up(bytes, 256);
         return r;
     };
-    size_t p0 = (size_t)B * H * W * 64;                  // conv1a out
-    p0 = p0 > (size_t)B * H2 * W2 * 64 ? p0 : (size_t)B * H2 * W2 * 64;
+    size_t p0 = (size_t)B * H2 * W2 * 64;  // conv2a out (conv1a's output lives only in LDS, fused into conv1b)
     p0 = p0 > (size_t)B * H4 * W4 * 128 ? p0 : (size_t)B * H4 * W4 * 128;
     p0 = p0 > cells * 512 ? p0 : cells * 512;
     size_t p1 = (size_t)B * H2 * W2 * 64;
@@ -303,8 +302,15 @@ extern "C" int gtsfm_sp_forward(const float* wts, const void* image_dev, int ima
         return launch_conv3x3(p, stream);
     };
 
-    SP_TRY(launch_conv1a(image_dev, image_is_u8, B, H, W, wts + L.w1a, wts + L.b1a, p0, stream));
-    SP_TRY(conv(L1B, p0, 64, p1, H, W, 1));
+    {  // conv1a + ReLU fused into conv1b's halo staging (conv1a's output never touches HBM), + conv1b + ReLU + pool
+        ConvParams p;
+        memset(&p, 0, sizeof(p));
+        p.in = p0, p.in_stride = 64, p.out = p1, p.out_stride = 64;
+        p.wpack = wts + L.w[L1B], p.bias = wts + L.b[L1B];
+        p.B = B, p.H = H, p.W = W, p.Cin = 64, p.Cout = 64, p.relu = 1, p.pool = 1;
+        p.img = image_dev, p.img_is_u8 = image_is_u8, p.w1a = wts + L.w1a, p.b1a = wts + L.b1a;
+        SP_TRY(launch_conv3x3(p, stream));
+    }
     SP_TRY(conv(L2A, p1, 64, p0, H2, W2, 0));
     SP_TRY(conv(L2B, p0, 64, p1, H2, W2, 1));
     SP_TRY(conv(L3A, p1, 64, p0, H4, W4, 0));

@@ -362,3 +362,49 @@ def test_resident_pipeline_equals_plugins(gpu_device, sg_sd, tmp_path):
         np.testing.assert_array_equal(ki.coordinates, feats["xy"][i, : len(ki)].cpu().numpy())
         ref = matcher.match(ki, kj, host[i][1][oi], host[j][1][oj], (160, 200, 1), (160, 200, 1))
         np.testing.assert_array_equal(got[(i, j)], ref)
+
+
+def test_batched_correspondence_generator(gpu_device, sg_sd, tmp_path):
+    """BatchedDetDescCorrespondenceGenerator.generate_correspondences (contract of
+    gtsfm/frontend/correspondence_generator/det_desc_correspondence_generator.py:33-87) vs per-image / per-pair plugin
+    calls: mixed image sizes, one masked image, SuperGlue and LightGlue."""
+    from gtsfm_amd.common.image import Image
+    from gtsfm_amd.frontend.correspondence_generator.batched_det_desc_correspondence_generator import (
+        BatchedDetDescCorrespondenceGenerator,
+    )
+    from gtsfm_amd.frontend.detector_descriptor.superpoint import SuperPointDetectorDescriptor
+    from gtsfm_amd.frontend.matcher.lightglue_matcher import LightGlueMatcher
+    from gtsfm_amd.frontend.matcher.superglue_matcher import SuperGlueMatcher
+
+    torch.save(synthetic.synthetic_superpoint_state_dict(), str(tmp_path / "sp.pth"))
+    torch.save(sg_sd, str(tmp_path / "sg.pth"))
+    torch.save(synthetic.synthetic_lightglue_state_dict(), str(tmp_path / "lg.pth"))
+    mask = np.zeros((120, 176), dtype=np.uint8)
+    mask[10:100, 20:160] = 1
+    images = [
+        Image(value_array=synthetic.synthetic_gray_image(160, 200, 71)),
+        Image(value_array=synthetic.synthetic_gray_image(160, 200, 72)),
+        Image(value_array=np.stack([synthetic.synthetic_gray_image(120, 176, 73)] * 3, -1), mask=mask),
+        Image(value_array=synthetic.synthetic_gray_image(120, 176, 74)),
+    ]
+    graph = [(0, 1), (0, 2), (1, 3), (2, 3)]
+    det = SuperPointDetectorDescriptor(max_keypoints=120, weights_path=tmp_path / "sp.pth")
+    for matcher in (SuperGlueMatcher(weights_path=tmp_path / "sg.pth"), LightGlueMatcher("superpoint", weights_path=tmp_path / "lg.pth")):
+        gen = BatchedDetDescCorrespondenceGenerator(matcher, det, image_batch=2, pair_batch=3)
+        kps, corr = gen.generate_correspondences(None, images, graph)
+        assert len(kps) == 4 and sorted(corr) == sorted(graph)
+        host = []
+        for im in images:
+            kp, d = det.detect_and_describe(im)
+            order = np.lexsort((kp.coordinates[:, 0], kp.coordinates[:, 1]))
+            host.append((kp.extract_indices(order), d[order]))
+        for i in range(4):
+            assert len(kps[i]) <= 120 and kps[i] == host[i][0]
+        if images[2].mask is not None:
+            rc = np.round(kps[2].coordinates).astype(int)
+            assert (mask[rc[:, 1], rc[:, 0]] == 1).all()
+        for i, j in graph:
+            ref = matcher.match(host[i][0], host[j][0], host[i][1], host[j][1], images[i].shape + (1,) * (3 - len(images[i].shape)),
+                                images[j].shape + (1,) * (3 - len(images[j].shape)))
+            np.testing.assert_array_equal(corr[(i, j)], ref)
+            assert corr[(i, j)].dtype == ref.dtype

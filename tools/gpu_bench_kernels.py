@@ -6,6 +6,8 @@ import torch
 import bench
 from gtsfm_amd.runtime import lib as L
 lib = L.load(); dev = torch.device("cuda:0")
+# warm the clocks up: the first kernels after idle run ~15-20 % slower
+for _ in range(3): bench.measure_attention_roofline(lib, dev, 2048, 32, reps=10)
 for rows, k, n in [(131072, 256, 768), (131072, 256, 256), (131072, 512, 512), (131072, 512, 256), (131072, 256, 512), (4096, 256, 768), (16384, 256, 65)]:
     r = bench.measure_gemm_roofline(lib, dev, rows, k, n, reps=10)
     print(f"gemm {rows}x{k}->{n}: {r['avg_launch_ms']:.3f} ms {r['achieved']:.1f} TF ({r['frac']*100:.1f}%)")
