@@ -128,8 +128,10 @@ extern "C" int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* 
     const DescLayout L = desc_layout(npairs, count_tiles(superglue, npairs, n0, n1));
     memset(out, 0, L.total * sizeof(int32_t));
     const int ext = superglue ? 1 : 0;
-    int row = 0, in_row = 0, tile = 0;
+    int row = 0, in_row = 0, tile = 0, max_n1 = 0;
     long long zoff = 0, poff = 0;
+    for (int p = 0; p < npairs; ++p) max_n1 = max_n1 > n1[p] ? max_n1 : n1[p];
+    const int R = sweep_rows_per_block(max_n1 + ext);
     for (int p = 0; p < npairs; ++p) {
         GTSFM_CHECK_ARG(n0[p] > 0 && n1[p] > 0, "match_build_desc: pair %d has an empty keypoint set", p);
         const int ns[2] = {n0[p], n1[p]};
@@ -155,7 +157,7 @@ extern "C" int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* 
         pd.z_off = zoff, pd.part_off = poff, pd.ld = z_ld(n1[p], ext), pd.pad = 0;
         memcpy(out + L.pairs + 6 * p, &pd, sizeof(pd));
         zoff += (long long)(n0[p] + ext) * pd.ld;
-        poff += (long long)ceil_div(n0[p] + ext, 16) * pd.ld * 2;
+        poff += (long long)ceil_div(n0[p] + ext, R) * pd.ld * 2;
         for (int s = 0; s < 2; ++s) {
             AttnProblem self = {offs[s], 2 * p + s, offs[s], 2 * p + s};
             AttnProblem cross = {offs[s], 2 * p + s, offs[1 - s], 2 * p + 1 - s};
@@ -193,13 +195,16 @@ struct BatchDims {
 
 BatchDims batch_dims(int P, const int32_t* n0, const int32_t* n1, int ext) {
     BatchDims d = {P, 0, 0, 0, 0, 0, 0, 0};
+    int mx1 = 0;
+    for (int p = 0; p < P; ++p) mx1 = mx1 > n1[p] ? mx1 : n1[p];
+    const int R = sweep_rows_per_block(mx1 + ext);
     for (int p = 0; p < P; ++p) {
         d.T += n0[p] + n1[p];
         d.max_n0 = d.max_n0 > n0[p] ? d.max_n0 : n0[p];
         d.max_n1 = d.max_n1 > n1[p] ? d.max_n1 : n1[p];
         const int ld = z_ld(n1[p], ext);
         d.z_floats += (size_t)(n0[p] + ext) * ld;
-        d.part_floats += (size_t)ceil_div(n0[p] + ext, 16) * ld * 2;
+        d.part_floats += (size_t)ceil_div(n0[p] + ext, R) * ld * 2;
         const size_t pk = packed_linear_floats(256, n1[p]);
         d.pack_floats = d.pack_floats > pk ? d.pack_floats : pk;
     }
@@ -231,8 +236,8 @@ SgWorkspace sg_workspace_layout(const BatchDims& d) {
     w.pack = take(d.pack_floats);
     w.z = take(d.z_floats);
     w.part = take(d.part_floats);
-    w.uv_row = take(T + 2 * d.P);
-    w.uv_col = take(T + 2 * d.P);
+    w.uv_row = take(T + 16 * d.P + 8);
+    w.uv_col = take(T + 16 * d.P + 8);
     w.max0 = take(T);
     w.idx0 = take(T);
     w.idx1 = take(T);
@@ -340,7 +345,7 @@ extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_scor
     sa.zbuf = Z, sa.rowvec = rowvec, sa.colvec = colvec, sa.partials = PART;
     TRY(launch_sinkhorn(sa, bin_score, sinkhorn_iters, stream));
     if (sinkhorn_iters == 0) {  // u stays 0 (superglue.py:143)
-        if (hipMemsetAsync(rowvec, 0, sizeof(float) * (T + 2 * npairs), stream) != hipSuccess) return GTSFM_ERR_HIP;
+        if (hipMemsetAsync(rowvec, 0, sizeof(float) * (T + 16 * npairs + 8), stream) != hipSuccess) return GTSFM_ERR_HIP;
     }
     TRY(launch_extract_matches(sa, 1, nullptr, match_threshold, max0, idx0, idx1, matches_dev, mscores_dev, stream));
     if (ot_dev) TRY(launch_materialize_assignment(sa, 1, nullptr, ot_dev, stream));
@@ -360,6 +365,9 @@ struct LgDims {
 
 LgDims lg_dims(int P, const int32_t* n0, const int32_t* n1) {
     LgDims d = {P, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int mx1 = 0;
+    for (int p = 0; p < P; ++p) mx1 = mx1 > n1[p] ? mx1 : n1[p];
+    const int R = sweep_rows_per_block(mx1);
     for (int p = 0; p < P; ++p) {
         d.T += n0[p] + n1[p];
         d.Tp += cap128(n0[p]) + cap128(n1[p]);
@@ -367,7 +375,7 @@ LgDims lg_dims(int P, const int32_t* n0, const int32_t* n1) {
         d.max_n1 = d.max_n1 > n1[p] ? d.max_n1 : n1[p];
         const int ld = z_ld(n1[p], 0);
         d.z_floats += (size_t)n0[p] * ld;
-        d.part_floats += (size_t)ceil_div(n0[p], 16) * ld * 2;
+        d.part_floats += (size_t)ceil_div(n0[p], R) * ld * 2;
         const size_t pk = packed_linear_floats(256, n1[p]);
         d.pack_floats = d.pack_floats > pk ? d.pack_floats : pk;
     }
@@ -394,7 +402,7 @@ LgWorkspace lg_workspace_layout(const LgDims& d) {
     w.enca = take(T * 64), w.encb = take(T * 64), w.inda = take(T), w.indb = take(T), w.indf = take(T);
     w.conf = take(T), w.mval = take(T), w.z_logit = take(T), w.pos = take(T);
     w.pack = take(d.pack_floats), w.z = take(d.z_floats), w.part = take(d.part_floats);
-    w.uv_row = take(T + 2 * d.P), w.uv_col = take(T + 2 * d.P);
+    w.uv_row = take(T + 16 * d.P + 8), w.uv_col = take(T + 16 * d.P + 8);
     w.max0 = take(T), w.idx0 = take(T), w.idx1 = take(T), w.m_int = take(T), w.ms_int = take(T);
     w.total = o;
     return w;

@@ -24,7 +24,7 @@ struct SweepArgs {
     const int* counts;      // device
     int npairs, max_m, max_n;
     float* zbuf;
-    float* rowvec;  // [T + 2P]: entry vec(s) + i with vec(s) = row_off(s) + s
+    float* rowvec;  // [T + 16P + 8]: entry vec(s) + i with vec(s) = align4(row_off(s)) + 8 s
     float* colvec;  // same indexing (a sequence is a "row" set in one role and a "column" set in the other)
     float* partials;
 };
@@ -44,3 +44,4 @@ int launch_double_softmax_lse(const SweepArgs& a, hipStream_t stream);
 int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogit, float threshold, float* max0, int* idx0, int* idx1,
                            int* matches, float* mscores, hipStream_t stream);
 int launch_materialize_assignment(const SweepArgs& a, int superglue, const float* zlogit, float* out, hipStream_t stream);
+int sweep_rows_per_block(int max_cols);  // rows of the score matrix one workgroup of the row sweep owns

@@ -197,92 +197,165 @@ int launch_rowdot(const float* x, int ld, const SeqDesc* seqs, const int* counts
 // LightGlue's double softmax uses the same two kernels once with u = v = 0 and plain log-sum-exp outputs.
 // ---------------------------------------------------------------------------------------------------------------
 
-#define SK_ROWS 16
+// Rows per workgroup of the row sweep: as many as fit a 64 KiB LDS slab (2 workgroups per CU), at most 16.
+int sweep_rows_per_block(int max_cols) {
+    const int ld = (max_cols + 3) / 4 * 4;
+    int r = (64 * 1024 / 4 - 16) / ld - 1;  // one extra row of LDS holds the column vector v
+    return r < 1 ? 1 : (r > 16 ? 16 : r);
+}
+
+// Row / column vectors of a pair live at a 16-byte-aligned offset per sequence (float4 loads of v in the row sweep).
+__device__ __forceinline__ int vec_off(const SeqDesc& sq, int s) { return ((sq.row_off + 3) & ~3) + 8 * s; }
 
 template <bool SG>
 __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                        const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
                                                        float* __restrict__ rowvec, const float* __restrict__ colvec,
-                                                       float* __restrict__ partials) {
-    __shared__ float u_s[SK_ROWS];
+                                                       float* __restrict__ partials, int R) {
+    // The workgroup's R rows are staged ONCE into LDS (coalesced 16-byte loads, all in flight together); the row
+    // log-sum-exp (phase A) and the column partials (phase B) both run out of LDS, so Z is read from HBM exactly once
+    // per Sinkhorn iteration.
+    extern __shared__ __attribute__((aligned(16))) float zs[];  // [R][ld] + u[R]
     const int p = blockIdx.y;
     const PairDesc pd = pairs[p];
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
     const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
     const int rows = m + (SG ? 1 : 0), cols = n + (SG ? 1 : 0);
-    const int r0 = blockIdx.x * SK_ROWS;
+    const int r0 = blockIdx.x * R;
     if (r0 >= rows) return;
-    const float* Z = zbuf + pd.z_off;
-    const int vec0 = s0.row_off + 2 * p, vec1 = s1.row_off + 2 * p + 1;
+    const int nr = min(R, rows - r0);
+    const int ld = pd.ld, ld4 = ld >> 2;
+    const float* Z = zbuf + pd.z_off + (size_t)r0 * ld;
+    const int vec0 = vec_off(s0, 2 * p), vec1 = vec_off(s1, 2 * p + 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float norm = SG ? -logf((float)m + (float)n) : 0.f;
-    // phase A: each wave reduces 4 rows
-    for (int rr = wave; rr < SK_ROWS; rr += 4) {
-        const int i = r0 + rr;
-        float ui = 0.f;
-        if (i < rows) {
-            const float* zr = Z + (size_t)i * pd.ld;
-            float mx = neg_inf();
-            for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, SG ? zr[j] + colvec[vec1 + j] : zr[j]);
-            mx = wave_max(mx);
-            float sum = 0.f;
-            for (int j = lane; j < cols; j += 64) sum += expf((SG ? zr[j] + colvec[vec1 + j] : zr[j]) - mx);
-            sum = wave_sum(sum);
-            const float lse = logf(sum) + mx;
-            if (SG) {
-                const float log_mu = (i < m) ? norm : logf((float)n) + norm;
-                ui = log_mu - lse;
-            } else {
-                ui = lse;
-            }
-            if (lane == 0) rowvec[vec0 + i] = ui;
+    const float NEG = neg_inf();
+    float* v_s = zs + (size_t)R * ld;  // staged column vector (SuperGlue's v)
+    float* u_s = v_s + ld;
+    if (SG)
+        for (int j = threadIdx.x * 4; j < cols; j += 1024) *reinterpret_cast<f32x4*>(v_s + j) = *reinterpret_cast<const f32x4*>(colvec + vec1 + j);
+    // stage: the nr rows are contiguous in memory (row stride ld), nr * ld4 float4 in total
+    for (int base = 0; base < nr * ld4; base += 256 * 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = base + e * 256 + threadIdx.x;
+            t[e] = (idx < nr * ld4) ? reinterpret_cast<const f32x4*>(Z)[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (lane == 0) u_s[rr] = ui;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = base + e * 256 + threadIdx.x;
+            if (idx < nr * ld4) reinterpret_cast<f32x4*>(zs)[idx] = t[e];
+        }
     }
     __syncthreads();
-    // phase B: column partials over this block's rows
-    const int nr = min(SK_ROWS, rows - r0);
-    float* part = partials + pd.part_off + (size_t)blockIdx.x * pd.ld * 2;
-    for (int j = threadIdx.x; j < cols; j += 256) {
-        float mx = neg_inf();
-        float vals[SK_ROWS];
-#pragma unroll
-        for (int rr = 0; rr < SK_ROWS; ++rr) {
-            float v = neg_inf();
-            if (rr < nr) v = SG ? Z[(size_t)(r0 + rr) * pd.ld + j] + u_s[rr] : Z[(size_t)(r0 + rr) * pd.ld + j];
-            vals[rr] = v;
-            mx = fmaxf(mx, v);
+    // phase A: wave w reduces rows w, w+4, ... (two passes over LDS: max, then sum of exp -- as torch.logsumexp does)
+    for (int rr = wave; rr < nr; rr += 4) {
+        const int i = r0 + rr;
+        const float* zr = zs + (size_t)rr * ld;
+        float mx = NEG;
+#pragma unroll 4
+        for (int j = lane * 4; j < cols; j += 256) {
+            f32x4 z = *reinterpret_cast<const f32x4*>(zr + j);
+            if (SG) z = z + *reinterpret_cast<const f32x4*>(v_s + j);
+            mx = fmaxf(mx, z.x);
+            if (j + 1 < cols) mx = fmaxf(mx, z.y);
+            if (j + 2 < cols) mx = fmaxf(mx, z.z);
+            if (j + 3 < cols) mx = fmaxf(mx, z.w);
         }
+        mx = wave_max(mx);
         float sum = 0.f;
-#pragma unroll
-        for (int rr = 0; rr < SK_ROWS; ++rr) sum += (rr < nr) ? expf(vals[rr] - mx) : 0.f;
-        part[(size_t)j * 2 + 0] = mx;
-        part[(size_t)j * 2 + 1] = sum;
+#pragma unroll 4
+        for (int j = lane * 4; j < cols; j += 256) {
+            f32x4 z = *reinterpret_cast<const f32x4*>(zr + j);
+            if (SG) z = z + *reinterpret_cast<const f32x4*>(v_s + j);
+            sum += expf(z.x - mx);
+            if (j + 1 < cols) sum += expf(z.y - mx);
+            if (j + 2 < cols) sum += expf(z.z - mx);
+            if (j + 3 < cols) sum += expf(z.w - mx);
+        }
+        sum = wave_sum(sum);
+        const float lse = logf(sum) + mx;
+        float ui;
+        if (SG) {
+            const float log_mu = (i < m) ? norm : logf((float)n) + norm;
+            ui = log_mu - lse;
+        } else {
+            ui = lse;
+        }
+        if (lane == 0) {
+            rowvec[vec0 + i] = ui;
+            u_s[rr] = ui;
+        }
+    }
+    __syncthreads();
+    // phase B: column partials (max, sum) of Z + u over this block's rows, 4 columns per thread, from LDS
+    float* part = partials + pd.part_off + (size_t)blockIdx.x * ld * 2;
+    for (int j = threadIdx.x * 4; j < cols; j += 1024) {
+        f32x4 mx = {NEG, NEG, NEG, NEG};
+        for (int rr = 0; rr < nr; ++rr) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(zs + (size_t)rr * ld + j);
+            if (SG) {
+                const float u = u_s[rr];
+                v.x += u, v.y += u, v.z += u, v.w += u;
+            }
+            mx.x = fmaxf(mx.x, v.x), mx.y = fmaxf(mx.y, v.y), mx.z = fmaxf(mx.z, v.z), mx.w = fmaxf(mx.w, v.w);
+        }
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int rr = 0; rr < nr; ++rr) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(zs + (size_t)rr * ld + j);
+            if (SG) {
+                const float u = u_s[rr];
+                v.x += u, v.y += u, v.z += u, v.w += u;
+            }
+            sum.x += expf(v.x - mx.x), sum.y += expf(v.y - mx.y), sum.z += expf(v.z - mx.z), sum.w += expf(v.w - mx.w);
+        }
+        // columns beyond `cols` (row padding) produce garbage partials that are never read
+        *reinterpret_cast<f32x4*>(part + (size_t)j * 2) = f32x4{mx.x, sum.x, mx.y, sum.y};
+        *reinterpret_cast<f32x4*>(part + (size_t)j * 2 + 4) = f32x4{mx.z, sum.z, mx.w, sum.w};
     }
 }
 
+// Combine the row-block partials of 64 columns: 4 thread groups stride over the blocks, then merge through LDS.
 template <bool SG>
 __global__ __launch_bounds__(256) void lse_cols_kernel(const PairDesc* __restrict__ pairs, const SeqDesc* __restrict__ seqs,
                                                        const int* __restrict__ counts, const float* __restrict__ partials,
-                                                       float* __restrict__ colvec) {
+                                                       float* __restrict__ colvec, int R) {
+    __shared__ float pm[4][64], ps[4][64];
     const int p = blockIdx.y;
     const PairDesc pd = pairs[p];
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
     const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
     const int rows = m + (SG ? 1 : 0), cols = n + (SG ? 1 : 0);
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= cols) return;
-    const int nblk = ceil_div(rows, SK_ROWS);
-    const float* part = partials + pd.part_off + (size_t)j * 2;
+    if (blockIdx.x * 64 >= cols) return;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const int nblk = ceil_div(rows, R);
     float mx = neg_inf(), sum = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        const float pm = part[(size_t)b * pd.ld * 2 + 0], ps = part[(size_t)b * pd.ld * 2 + 1];
-        const float nm = fmaxf(mx, pm);
-        sum = sum * expf(mx - nm) + ps * expf(pm - nm);
+    if (j < cols) {
+        const float* part = partials + pd.part_off + (size_t)j * 2;
+        const size_t bstride = (size_t)pd.ld * 2;
+#pragma unroll 4
+        for (int b = grp; b < nblk; b += 4) {
+            const float2 ms = *reinterpret_cast<const float2*>(part + b * bstride);
+            const float nm = fmaxf(mx, ms.x);
+            sum = sum * expf(mx - nm) + ms.y * expf(ms.x - nm);
+            mx = nm;
+        }
+    }
+    pm[grp][lane] = mx;
+    ps[grp][lane] = sum;
+    __syncthreads();
+    if (grp != 0 || j >= cols) return;
+#pragma unroll
+    for (int g = 1; g < 4; ++g) {
+        const float om = pm[g][lane], os = ps[g][lane];
+        const float nm = fmaxf(mx, om);
+        if (nm != neg_inf()) sum = sum * expf(mx - nm) + os * expf(om - nm);
         mx = nm;
     }
     const float lse = logf(sum) + mx;
-    const int vec1 = s1.row_off + 2 * p + 1;
+    const int vec1 = vec_off(s1, 2 * p + 1);
     if (SG) {
         const float norm = -logf((float)m + (float)n);
         const float log_nu = (j < n) ? norm : logf((float)m) + norm;
@@ -300,7 +373,7 @@ __global__ void sg_fill_bins_kernel(float* __restrict__ zbuf, const PairDesc* __
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
     const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
     float* Z = zbuf + pd.z_off;
-    const int vec1 = s1.row_off + 2 * p + 1;
+    const int vec1 = vec_off(s1, 2 * p + 1);
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= max(m, n); t += gridDim.x * blockDim.x) {
         if (t <= m) Z[(size_t)t * pd.ld + n] = alpha;
         if (t <= n) {
@@ -336,7 +409,7 @@ __global__ __launch_bounds__(256) void best_rows_kernel(const float* __restrict_
     if (i >= m) return;
     const int lane = threadIdx.x & 63;
     const float* zr = zbuf + pd.z_off + (size_t)i * pd.ld;
-    const int vec0 = s0.row_off + 2 * p, vec1 = s1.row_off + 2 * p + 1;
+    const int vec0 = vec_off(s0, 2 * p), vec1 = vec_off(s1, 2 * p + 1);
     const float norm = SG ? -logf((float)m + (float)n) : 0.f;
     const float a_i = rowvec[vec0 + i];
     const float c_i = SG ? 0.f : logsigmoid(zlogit[s0.row_off + i]);
@@ -361,7 +434,7 @@ __global__ __launch_bounds__(256) void best_rows_kernel(const float* __restrict_
     }
     if (lane == 0) {
         max0[s0.row_off + i] = best;
-        idx0[s0.row_off + i] = bj;
+        idx0[s0.row_off + i] = (bj == 0x7fffffff) ? 0 : bj;  // all-NaN row: stay in range
     }
 }
 
@@ -381,7 +454,7 @@ __global__ __launch_bounds__(256) void best_cols_kernel(const float* __restrict_
     const int j = blockIdx.x * 64 + lane;
     if (blockIdx.x * 64 >= n) return;
     const float* Z = zbuf + pd.z_off;
-    const int vec0 = s0.row_off + 2 * p, vec1 = s1.row_off + 2 * p + 1;
+    const int vec0 = vec_off(s0, 2 * p), vec1 = vec_off(s1, 2 * p + 1);
     const float norm = SG ? -logf((float)m + (float)n) : 0.f;
     float best = neg_inf();
     int bidx = 0x7fffffff;
@@ -410,7 +483,7 @@ __global__ __launch_bounds__(256) void best_cols_kernel(const float* __restrict_
                 bidx = oi;
             }
         }
-        idx1[s1.row_off + j] = bidx;
+        idx1[s1.row_off + j] = (bidx == 0x7fffffff) ? 0 : bidx;  // all-NaN column: stay in range
     }
 }
 
@@ -452,7 +525,7 @@ __global__ void materialize_assignment_kernel(const float* __restrict__ zbuf, co
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
     const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
     const int rows = m + (SG ? 1 : 0), cols = n + (SG ? 1 : 0);
-    const int i = blockIdx.y, vec0 = s0.row_off + 2 * p, vec1 = s1.row_off + 2 * p + 1;
+    const int i = blockIdx.y, vec0 = vec_off(s0, 2 * p), vec1 = vec_off(s1, 2 * p + 1);
     if (i >= rows) return;
     const float norm = SG ? -logf((float)m + (float)n) : 0.f;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < cols; j += gridDim.x * blockDim.x) {
@@ -481,12 +554,15 @@ template <bool SG>
 static int sweep_impl(const SweepArgs& a, int iters, hipStream_t stream) {
     if (a.npairs <= 0) return GTSFM_OK;
     const int ext = SG ? 1 : 0;
-    dim3 grid_rows(ceil_div(a.max_m + ext, SK_ROWS), a.npairs);
-    dim3 grid_cols(ceil_div(a.max_n + ext, 256), a.npairs);
+    const int R = sweep_rows_per_block(a.max_n + ext);
+    const int ld_max = (a.max_n + ext + 3) / 4 * 4;
+    const size_t lds_bytes = ((size_t)(R + 1) * ld_max + R) * sizeof(float);
+    dim3 grid_rows(ceil_div(a.max_m + ext, R), a.npairs);
+    dim3 grid_cols(ceil_div(a.max_n + ext, 64), a.npairs);
     for (int it = 0; it < iters; ++it) {
-        hipLaunchKernelGGL(lse_rows_kernel<SG>, grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec,
-                           a.partials);
-        hipLaunchKernelGGL(lse_cols_kernel<SG>, grid_cols, dim3(256), 0, stream, a.pairs, a.seqs, a.counts, a.partials, a.colvec);
+        hipLaunchKernelGGL(lse_rows_kernel<SG>, grid_rows, dim3(256), lds_bytes, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec,
+                           a.colvec, a.partials, R);
+        hipLaunchKernelGGL(lse_cols_kernel<SG>, grid_cols, dim3(256), 0, stream, a.pairs, a.seqs, a.counts, a.partials, a.colvec, R);
     }
     GTSFM_CHECK_LAUNCH("lse_rows/cols_kernel");
     return GTSFM_OK;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer recipe (GPU box): per-kernel time split of one LightGlue batch (32 pairs, N = 2048).
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/plg
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/plg -o lg -- python $GRAFT_REPO_ROOT/tools/gpu_time_lg.py > /tmp/plg.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/plg -o lg -- python $GRAFT_REPO_ROOT/tools/${PROF_SCRIPT:-gpu_time_lg.py} > /tmp/plg.log 2>&1
 tail -1 /tmp/plg.log
 python - <<'PY'
 import csv
