@@ -43,18 +43,19 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnParams p) {
     f32x4 qreg[8];
     {
         const float* qp = p.q + (size_t)(pr.q_off + (qvalid ? qrow : 0)) * p.ldq + h * 64 + kh * 4;
+        // softmax runs in the base-2 domain (exp(x) = exp2(x log2 e), one v_exp_f32 per element); the factor
+        // scale * log2(e) is folded into Q once instead of into every score
+        const float scale2 = p.scale * 1.44269504088896340736f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             f32x4 v = *reinterpret_cast<const f32x4*>(qp + t * 8);
             if (!qvalid) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            qreg[t] = v;
+            qreg[t] = v * scale2;
         }
     }
     f32x16 o0, o1;  // O^T: rows d 0..31 / 32..63, column q
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    // softmax runs in the base-2 domain: exp(x) = exp2(x log2 e), one v_exp_f32 per element
-    const float scale2 = p.scale * 1.44269504088896340736f;
     float m = -__builtin_inff(), l = 0.f;
 
     const float* kbase = p.k + (size_t)pr.k_off * p.ldk + h * 64;
@@ -103,18 +104,21 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnParams p) {
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Kt[(32 + j) * AT_ROW + u * 8 + kh * 4]);
             mt_step(s0, s1, a0, a1, qreg[u]);
         }
-        // scale, mask, online softmax (per query = per lane; the two lane halves hold different keys of the same query)
+        // mask (last tile only), online softmax (per query = per lane; the two lane halves hold different keys of the same
+        // query)
+        if (k0 + AT_KT > nk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (key >= nk) s0[r] = -__builtin_inff();
+                if (key + 32 >= nk) s1[r] = -__builtin_inff();
+            }
+        }
         float mloc = -__builtin_inff();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            s0[r] = (key < nk) ? s0[r] * scale2 : -__builtin_inff();
-            s1[r] = (key + 32 < nk) ? s1[r] * scale2 : -__builtin_inff();
-            mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
-        }
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float mnew = fmaxf(m, mloc);  // finite: key k0 is always valid
-        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
         float lsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -123,13 +127,17 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(AttnParams p) {
             lsum += s0[r] + s1[r];
         }
         lsum += __shfl_xor(lsum, 32, 64);
-        l = l * alpha + lsum;
-        m = mnew;
+        if (__any(mnew != m)) {  // wave-uniform: skip the rescale when no running maximum moved (alpha == 1 exactly)
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            l *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o0[r] *= alpha;
-            o1[r] *= alpha;
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= alpha;
+                o1[r] *= alpha;
+            }
         }
+        l += lsum;
+        m = mnew;
         // O^T += V^T P^T. Accumulator register r of S^T tile T holds key 32T + (r&3) + 8(r>>2) + 4kh, so it IS the B
         // operand of k-step r; the A operand V^T[d = lane][key] is a conflict-free row read of the row-major V tile.
 #pragma unroll

@@ -79,7 +79,8 @@ def test_attention_ragged_batch(lib, gpu_device):
         vb = qkv[offs[b] : offs[b] + counts[b], 512:]
         ref = _ref_attention(qa, kb, vb, 0.125)
         got = out.cpu()
-        assert float((got[offs[a] : offs[a] + counts[a]] - ref).abs().max()) < 5e-6
+        # logits reach +-45 here (ulp 4e-6 in fp32): both implementations carry ~1e-5 of round-off in the exponent
+        assert float((got[offs[a] : offs[a] + counts[a]] - ref).abs().max()) < 2e-5
         untouched = torch.ones(total, dtype=torch.bool)
         untouched[offs[a] : offs[a] + counts[a]] = False
         assert torch.isnan(got[untouched]).all()
@@ -91,7 +92,7 @@ def test_attention_ragged_batch(lib, gpu_device):
     assert rc == 0
     torch.cuda.synchronize()
     ref0 = _ref_attention(qkv[:100, :256], qkv[:100, 256:512], qkv[:100, 512:], 0.125)
-    assert float((out_all[:100].cpu() - ref0).abs().max()) < 5e-6
+    assert float((out_all[:100].cpu() - ref0).abs().max()) < 2e-5
 
 
 def test_attention_peaked_softmax(lib, gpu_device):
