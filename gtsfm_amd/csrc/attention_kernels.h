@@ -23,6 +23,7 @@ struct AttnParams {
     const int* counts;            // device
     float scale;                  // softmax(scale * q k^T)
     int heads;
+    int qtiles, nproblems;        // filled by the launcher
 };
 
 int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t stream);

@@ -8,8 +8,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/full -o full -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/full.log 2>&1
 rm -f $OUT/full/*kernel_trace.csv
+cat > /tmp/pmc_workload.sh <<'SH'
+python $GRAFT_REPO_ROOT/bench.py --matcher none --images 4 --steps 1 --warmup 1 --no-cpu-baseline
+python $GRAFT_REPO_ROOT/tools/gpu_time_lg.py
+SH
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o pmc -- python $GRAFT_REPO_ROOT/bench.py --matcher none --images 4 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o pmc -- bash /tmp/pmc_workload.sh > $OUT/pmc_$C.log 2>&1
   python - <<PY
 import csv, collections, glob
 f = glob.glob("$OUT/pmc_$C/*counter_collection.csv")
