@@ -231,7 +231,8 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # GTSFM_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, weight broadcast, barrier, max-reduce) on one GPU
+    if world > 1 or os.environ.get("GTSFM_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -255,7 +256,7 @@ def main() -> None:
         matcher = ME.SuperGlueEngine(synthetic.synthetic_superglue_state_dict(), device)
     elif args.matcher == "lightglue":
         matcher = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(), device)
-    if matcher is not None and world > 1:
+    if matcher is not None and dist is not None:
         blob = matcher.weights if rank == 0 else None
         matcher.weights = parallel.broadcast_packed_weights(blob, matcher.weights.numel(), device)
 

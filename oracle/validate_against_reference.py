@@ -167,6 +167,59 @@ def check_superglue(write: bool) -> None:
     print("superglue empty-input early-out: identical")
 
 
+def check_lund_door(write: bool) -> None:
+    """BASELINE config 1 (plumbing) on REAL images: two frames of the reference's own fixture
+    tests/data/set1_lund_door (1296x1936 JPEG), decoded with PIL, converted to gray and reduced to a short side of 380 px
+    (PIL bicubic -- NOT the loader's cv.INTER_CUBIC, cv2 is absent here), run through the reference SuperPoint and
+    SuperGlue (synthetic weights). The reduced gray images travel with the golden outputs because /root/reference does
+    not exist on the GPU box."""
+    from PIL import Image as PILImage
+
+    folder = REFERENCE / "tests" / "data" / "set1_lund_door" / "images"
+    sp_sd = synthetic.synthetic_superpoint_state_dict()
+    sg_sd = synthetic.synthetic_superglue_state_dict()
+    sp = reference_superpoint(sp_sd)
+    grays, feats = [], []
+    for name in ("DSC_0001.JPG", "DSC_0002.JPG"):
+        im = PILImage.open(folder / name).convert("L")
+        w, h = im.size
+        scale = 380.0 / min(w, h)
+        im = im.resize((int(round(w * scale)), int(round(h * scale))), PILImage.BICUBIC)
+        gray = np.asarray(im, dtype=np.uint8)
+        img = superpoint_oracle.gray_u8_to_tensor(gray)
+        with torch.no_grad(), _force_align_corners():
+            ref = sp({"image": img})
+            ora = superpoint_oracle.superpoint_forward(sp_sd, img)
+        assert torch.equal(ref["keypoints"][0], ora["keypoints"]) and torch.equal(ref["descriptors"][0], ora["descriptors"])
+        grays.append(gray)
+        feats.append((ref["keypoints"][0], ref["scores"][0], ref["descriptors"][0]))
+        print(f"lund door {name}: {gray.shape[0]}x{gray.shape[1]}, K={ref['keypoints'][0].shape[0]} restatement bit-exact with reference")
+    # wrapper top-k (keep the 1024 strongest, detection order) then SuperGlue with GTSfM's 20 iterations
+    sel = []
+    for kp, sc, de in feats:
+        k = min(1024, kp.shape[0])
+        idx = torch.topk(sc, k).indices.sort().values
+        sel.append((kp[idx], sc[idx], de[:, idx]))
+    sg = reference_superglue(sg_sd, 20)
+    data = {
+        "keypoints0": sel[0][0][None], "keypoints1": sel[1][0][None], "scores0": sel[0][1][None], "scores1": sel[1][1][None],
+        "descriptors0": sel[0][2][None].contiguous(), "descriptors1": sel[1][2][None].contiguous(),
+        "image0": torch.empty((1, 1) + grays[0].shape), "image1": torch.empty((1, 1) + grays[1].shape),
+    }
+    with torch.no_grad():
+        ref = sg(data)
+    print(f"lund door superglue: {int((ref['matches0'] > -1).sum())} matches")
+    if write:
+        np.savez_compressed(
+            GOLDEN / "lund_door_pair.npz",
+            gray0=grays[0], gray1=grays[1],
+            keypoints0=feats[0][0].numpy().astype(np.int32), keypoints1=feats[1][0].numpy().astype(np.int32),
+            scores0=feats[0][1].numpy(), scores1=feats[1][1].numpy(),
+            descriptors0_head=feats[0][2].numpy().T[:256].copy(), descriptors1_head=feats[1][2].numpy().T[:256].copy(),
+            matches0=ref["matches0"][0].numpy(), matching_scores0=ref["matching_scores0"][0].numpy(),
+        )
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", action="store_true", help="(re)write tests/golden/*.npz")
@@ -177,6 +230,7 @@ def main() -> None:
     GOLDEN.mkdir(parents=True, exist_ok=True)
     check_superpoint(args.write)
     check_superglue(args.write)
+    check_lund_door(args.write)
     print("OK")
 
 

@@ -409,3 +409,22 @@ def test_batched_correspondence_generator(gpu_device, sg_sd, tmp_path):
                                 images[j].shape + (1,) * (3 - len(images[j].shape)))
             np.testing.assert_array_equal(corr[(i, j)], ref)
             assert corr[(i, j)].dtype == ref.dtype
+
+
+def test_real_images_lund_door_pair(gpu_device, sg_engine):
+    """Real-image pair end to end on the device (SuperPoint -> top-1024 -> SuperGlue, 20 iterations) vs the reference's
+    outputs for the same two Lund-door frames."""
+    from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+
+    g = np.load(GOLDEN / "lund_door_pair.npz")
+    sp = SuperPointEngine(synthetic.synthetic_superpoint_state_dict(), gpu_device)
+    out = sp.forward(torch.from_numpy(np.stack([g["gray0"], g["gray1"]])).to(gpu_device), top_k=1024)
+    assert out["count"].tolist() == [1024, 1024]
+    n = 1024
+    kp = out["xy"].reshape(-1, 2).contiguous()
+    sc = out["scores"].reshape(-1).contiguous()
+    de = out["descriptors"].reshape(-1, 256).contiguous()
+    res = sg_engine.match_batch(kp, sc, de, [n], [n], [[568, 380, 568, 380]], sinkhorn_iterations=20)
+    m0 = res["matches"][:n].cpu().numpy().astype(np.int64)
+    np.testing.assert_array_equal(m0, g["matches0"])
+    np.testing.assert_allclose(res["mscores"][:n].cpu().numpy(), g["matching_scores0"], rtol=0, atol=SCORE_TOL)

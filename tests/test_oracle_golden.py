@@ -80,3 +80,16 @@ def test_superglue_empty_input_early_out():
     )
     assert out["matches0"].shape == (1, 0) and out["matches0"].dtype == torch.int
     assert torch.equal(out["matches1"], torch.full((1, 3), -1, dtype=torch.int))
+
+
+def test_real_image_fixture_lund_door():
+    """BASELINE config 1 (plumbing) fixture: two frames of the reference's set1_lund_door, reduced to 568x380 gray, with the
+    reference SuperPoint / SuperGlue outputs (synthetic weights)."""
+    g = np.load(GOLDEN / "lund_door_pair.npz")
+    sd = synthetic.synthetic_superpoint_state_dict()
+    assert g["gray0"].dtype == np.uint8 and g["gray0"].shape == (568, 380)
+    with torch.no_grad():
+        out = superpoint_oracle.superpoint_forward(sd, superpoint_oracle.gray_u8_to_tensor(g["gray0"]))
+    np.testing.assert_array_equal(out["keypoints"].numpy().astype(np.int32), g["keypoints0"])
+    np.testing.assert_allclose(out["scores"].numpy(), g["scores0"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out["descriptors"].numpy().T[:256], g["descriptors0_head"], rtol=0, atol=1e-6)

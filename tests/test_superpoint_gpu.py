@@ -417,3 +417,15 @@ def test_device_topk_with_ties(lib, gpu_device):
     assert osc[0].tolist() == [0.5, pytest.approx(0.9), 0.5, pytest.approx(0.7)]  # 0.9, 0.7 and the first two 0.5s, in order
     assert oxy[0, :, 0].tolist() == [0.0, 2.0, 4.0, 12.0]
     assert osc[1, :2].tolist() == [pytest.approx(0.3), pytest.approx(0.2)]
+
+
+def test_real_images_lund_door(engine):
+    """BASELINE config 1 (plumbing): real photographs (two frames of the reference's tests/data/set1_lund_door, 568x380
+    after reduction) vs the reference's own SuperPoint outputs: ~1 850 keypoints per frame, identical; scores and
+    descriptors within tolerance."""
+    g = np.load(GOLDEN / "lund_door_pair.npz")
+    for i in (0, 1):
+        xy, sc, de = engine.detect(g[f"gray{i}"])
+        np.testing.assert_array_equal(xy.astype(np.int32), g[f"keypoints{i}"])
+        np.testing.assert_allclose(sc, g[f"scores{i}"], rtol=0, atol=SCORE_TOL)
+        np.testing.assert_allclose(de[:256], g[f"descriptors{i}_head"], rtol=0, atol=DESC_TOL)
