@@ -52,6 +52,16 @@ def superpoint_flops(h: int, w: int) -> float:
     return float(total)
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch measured with rocprofv3 PMC passes and committed under profiles/ (bench.py cannot collect
+    counters itself); None when the file is missing."""
+    path = REPO / "profiles" / "r01_pmc_traffic.json"
+    try:
+        return json.loads(path.read_text()).get(kernel)
+    except (OSError, ValueError):
+        return None
+
+
 def measure_conv_roofline(lib, device, batch: int, h: int, w: int, reps: int = 5):
     """Times the dominant kernel (conv3x3_mfma_kernel) launch by launch with HIP events on the launch stream."""
     from gtsfm_amd.runtime import lib as L
@@ -79,6 +89,7 @@ def measure_conv_roofline(lib, device, batch: int, h: int, w: int, reps: int = 5
         launches += 1
         del x, y, wp
     achieved = total_flops / (total_ms * 1e-3) / 1e12
+    t = pmc_traffic("conv3x3_mfma_kernel") if (h, w) == (1024, 1024) else None
     return {
         "bound": "mfma",
         "kernel": "conv3x3_mfma_kernel",
@@ -86,7 +97,8 @@ def measure_conv_roofline(lib, device, batch: int, h: int, w: int, reps: int = 5
         "peak": FP32_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-        "traffic": None,
+        "traffic": None if t is None else (t["fetch_bytes_per_image"] + t["write_bytes_per_image"]) * batch,
+        "traffic_note": None if t is None else "HBM bytes per launch (avg over the 8 launches), rocprofv3 PMC, profiles/r01_pmc_traffic.json",
         "launches_per_step": launches,
         "avg_launch_ms": round(total_ms / launches, 4),
         "flops_per_step": total_flops,
@@ -118,6 +130,7 @@ def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5):
     ms = e0.elapsed_time(e1) / reps
     flops = 1024.0 * n * n * nseq
     achieved = flops / (ms * 1e-3) / 1e12
+    t = pmc_traffic("attention_mfma_kernel") if (n, nseq) == (2048, 64) else None
     return {
         "bound": "mfma",
         "kernel": "attention_mfma_kernel",
@@ -125,7 +138,8 @@ def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5):
         "peak": FP32_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-        "traffic": None,
+        "traffic": None if t is None else t["fetch_bytes"] + t["write_bytes"],
+        "traffic_note": None if t is None else "HBM bytes per launch, rocprofv3 PMC, profiles/r01_pmc_traffic.json",
         "avg_launch_ms": round(ms, 4),
         "flops_per_launch": flops,
         "launch_shape": f"{nseq} sequences x 4 heads, N = {n} queries = keys, head_dim 64",
