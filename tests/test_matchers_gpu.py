@@ -428,3 +428,33 @@ def test_real_images_lund_door_pair(gpu_device, sg_engine):
     m0 = res["matches"][:n].cpu().numpy().astype(np.int64)
     np.testing.assert_array_equal(m0, g["matches0"])
     np.testing.assert_allclose(res["mscores"][:n].cpu().numpy(), g["matching_scores0"], rtol=0, atol=SCORE_TOL)
+
+
+@pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
+def test_max_keypoints_5000_vs_oracle(gpu_device, sg_engine, sg_sd, matcher):
+    """GTSfM's default cap (max_keypoints = 5000, deep_front_end.yaml:29): 100 MB score matrices, ragged 5000 x 4800 pair,
+    LightGlue above its pruning threshold (1536). Matches identical to the oracle, scores within tolerance."""
+    n0, n1 = 5000, 4800
+    k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(n0, n1, (1024, 1024), (1024, 1024), seed=77)
+    if matcher == "superglue":
+        res = sg_engine.match_pair(k0, s0, d0, k1, s1, d1, (1024, 1024), (1024, 1024), sinkhorn_iterations=20)
+        with torch.no_grad():
+            ora = sgo.superglue_forward(sg_sd, T(k0)[None], T(k1)[None], T(s0)[None], T(s1)[None], T(d0).T[None].contiguous(),
+                                        T(d1).T[None].contiguous(), (1024, 1024), (1024, 1024), sinkhorn_iterations=20)
+    else:
+        from gtsfm_amd.runtime.matcher_engine import LightGlueEngine
+
+        sd = synthetic.synthetic_lightglue_state_dict(conf_bias=1.0, conf_gain=6.0, match_bias=-2.0, match_gain=8.0)
+        res = LightGlueEngine(sd, gpu_device).match_pair(k0, d0, k1, d1, (1024, 1024), (1024, 1024))
+        with torch.no_grad():
+            ora = lgo.lightglue_forward(sd, T(k0)[None], T(k1)[None], T(d0)[None], T(d1)[None], (1024, 1024), (1024, 1024),
+                                        return_intermediates=True)
+        assert res["stop"] == ora["stop"]
+        assert tuple(res["kept"].tolist()) == (ora["ind0"].shape[1], ora["ind1"].shape[1])
+        assert res["kept"][0] < n0 and res["kept"][1] < n1  # point pruning was active on both images
+    m0 = ora["matches0"][0].numpy()
+    if matcher == "superglue":
+        assert (m0 > -1).sum() > 1000
+    np.testing.assert_array_equal(res["matches0"], m0)
+    np.testing.assert_array_equal(res["matches1"], ora["matches1"][0].numpy())
+    np.testing.assert_allclose(res["matching_scores0"], ora["matching_scores0"][0].numpy(), rtol=0, atol=SCORE_TOL)
