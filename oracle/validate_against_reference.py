@@ -38,6 +38,8 @@ GOLDEN = REPO / "tests" / "golden"
 
 # (height, width, seed): includes non-multiple-of-8 sizes (floor pooling, SURVEY.md section 7 "hard parts").
 SUPERPOINT_CASES = [(120, 160, 1), (123, 157, 2), (240, 320, 3)]
+# BASELINE config-2 shape (480x640): keypoints and scores in full, descriptors of the first 256 keypoints
+SUPERPOINT_LARGE_CASES = [(480, 640, 4)]
 # (n0, n1, shape0, shape1, seed, sinkhorn iterations)
 SUPERGLUE_CASES = [
     (96, 80, (240, 320), (200, 300), 11, 20),
@@ -114,6 +116,25 @@ def check_superpoint(write: bool) -> None:
                 scores=sc.numpy(),
                 descriptors=de.numpy().T.copy(),  # (K, 256), wrapper layout
                 dense_scores_sample=ora["dense_scores"][0, ::7, ::5].numpy().copy(),
+            )
+
+
+def check_superpoint_large(write: bool) -> None:
+    sd = synthetic.synthetic_superpoint_state_dict()
+    model = reference_superpoint(sd)
+    for h, w, seed in SUPERPOINT_LARGE_CASES:
+        gray = synthetic.synthetic_gray_image(h, w, seed)
+        img = superpoint_oracle.gray_u8_to_tensor(gray)
+        with torch.no_grad(), _force_align_corners():
+            ref = model({"image": img})
+            ora = superpoint_oracle.superpoint_forward(sd, img)
+        kp, sc, de = ref["keypoints"][0], ref["scores"][0], ref["descriptors"][0]
+        assert torch.equal(kp, ora["keypoints"]) and torch.equal(sc, ora["scores"]) and torch.equal(de, ora["descriptors"])
+        print(f"superpoint {h}x{w} seed={seed}: K={kp.shape[0]} restatement bit-exact with reference")
+        if write:
+            np.savez_compressed(
+                GOLDEN / f"config2_superpoint_{h}x{w}_s{seed}.npz", height=h, width=w, seed=seed,
+                keypoints=kp.numpy().astype(np.int32), scores=sc.numpy(), descriptors_head=de.numpy().T[:256].copy(),
             )
 
 
@@ -229,6 +250,7 @@ def main() -> None:
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     GOLDEN.mkdir(parents=True, exist_ok=True)
     check_superpoint(args.write)
+    check_superpoint_large(args.write)
     check_superglue(args.write)
     check_lund_door(args.write)
     print("OK")

@@ -93,3 +93,27 @@ def test_real_image_fixture_lund_door():
     np.testing.assert_array_equal(out["keypoints"].numpy().astype(np.int32), g["keypoints0"])
     np.testing.assert_allclose(out["scores"].numpy(), g["scores0"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(out["descriptors"].numpy().T[:256], g["descriptors0_head"], rtol=0, atol=1e-6)
+
+
+def test_superpoint_oracle_matches_golden_config2_shape():
+    """BASELINE config-2 shape (480x640) vs the fixture generated from the reference (full keypoint list)."""
+    g = np.load(GOLDEN / "config2_superpoint_480x640_s4.npz")
+    sd = synthetic.synthetic_superpoint_state_dict()
+    gray = synthetic.synthetic_gray_image(480, 640, 4)
+    with torch.no_grad():
+        out = superpoint_oracle.superpoint_forward(sd, superpoint_oracle.gray_u8_to_tensor(gray))
+    np.testing.assert_array_equal(out["keypoints"].numpy().astype(np.int32), g["keypoints"])
+    np.testing.assert_allclose(out["scores"].numpy(), g["scores"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out["descriptors"].numpy().T[:256], g["descriptors_head"], rtol=0, atol=1e-6)
+
+
+def test_bench_work_formulas_match_survey():
+    """bench.py's algorithmic-work formulas reproduce SURVEY.md section 8(d): 177.85 / 52.10 GFLOP per image,
+    254.8 GFLOP per SuperGlue pair and 229.8 GFLOP per full-depth LightGlue pair at N = 2048."""
+    import bench
+
+    assert abs(bench.superpoint_flops(1024, 1024) / 1e9 - 177.85) < 0.01
+    assert abs(bench.superpoint_flops(480, 640) / 1e9 - 52.10) < 0.01
+    assert abs(bench.matcher_flops("superglue", 2048, 18, 100) / 1e9 - 254.8) < 0.1
+    assert abs(bench.matcher_flops("lightglue", 2048, 9.0, 0) / 1e9 - 229.8) < 0.1
+    assert abs(bench.matcher_flops("superglue", 5000, 18, 100) / 1e9 - 1173.8) < 0.5

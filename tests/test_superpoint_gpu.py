@@ -429,3 +429,12 @@ def test_real_images_lund_door(engine):
         np.testing.assert_array_equal(xy.astype(np.int32), g[f"keypoints{i}"])
         np.testing.assert_allclose(sc, g[f"scores{i}"], rtol=0, atol=SCORE_TOL)
         np.testing.assert_allclose(de[:256], g[f"descriptors{i}_head"], rtol=0, atol=DESC_TOL)
+
+
+def test_end_to_end_matches_golden_config2_shape(engine):
+    """BASELINE config-2 shape (480x640): full keypoint list, scores and the first 256 descriptors vs the reference."""
+    g = np.load(GOLDEN / "config2_superpoint_480x640_s4.npz")
+    xy, sc, de = engine.detect(synthetic.synthetic_gray_image(480, 640, 4))
+    np.testing.assert_array_equal(xy.astype(np.int32), g["keypoints"])
+    np.testing.assert_allclose(sc, g["scores"], rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(de[:256], g["descriptors_head"], rtol=0, atol=DESC_TOL)
