@@ -234,6 +234,7 @@ def main() -> None:
     ap.add_argument("--keypoints", type=int, default=2048, help="keypoints kept per image (device top-k by response)")
     ap.add_argument("--sinkhorn", type=int, default=100, help="SuperGlue Sinkhorn iterations (GTSfM runs 20; BASELINE config 4 asks for 100)")
     ap.add_argument("--pair-chunk", type=int, default=32)
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the pair chunks alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -282,7 +283,7 @@ def main() -> None:
     imgs = np.stack([canvas[8 * i : 8 * i + h, 8 * ((7 * i) % n) : 8 * ((7 * i) % n) + w] for i in range(n)])
     images = torch.from_numpy(imgs).to(device)  # inputs resident in HBM before the timed region
     pairs = parallel.exhaustive_pairs(n)[: args.pairs] if matcher is not None else []
-    pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk)
+    pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams)
     shapes = [(h, w)] * n
     mk = {"sinkhorn_iterations": args.sinkhorn} if args.matcher == "superglue" else {}
 
@@ -346,6 +347,8 @@ def main() -> None:
                 "matches_per_pair": round(nmatch / max(1, len(pairs)), 1),
                 "weights": "seeded synthetic (gtsfm_amd.utils.synthetic)",
                 "parallelism": f"dp{world}: independent image sets / pair lists per rank, RCCL weight broadcast, no data-path collective",
+                "pair_chunk": args.pair_chunk,
+                "streams": args.streams,
             },
             "tflops": round(flops_step * world / (ms_per_step * 1e-3) / 1e12, 2),
         }

@@ -119,6 +119,13 @@ class _MatcherBase:
         return torch.from_numpy(host).to(self.device)
 
 
+    def workspace_bytes(self, n0: Sequence[int], n1: Sequence[int]) -> int:
+        a0 = np.ascontiguousarray(n0, dtype=np.int32)
+        a1 = np.ascontiguousarray(n1, dtype=np.int32)
+        fn = self._lib.gtsfm_sg_workspace_bytes if isinstance(self, SuperGlueEngine) else self._lib.gtsfm_lg_workspace_bytes
+        return int(fn(len(a0), a0.ctypes.data, a1.ctypes.data))
+
+
 class SuperGlueEngine(_MatcherBase):
     """Device-resident SuperGlue (superglue.py:228-283) for ragged batches of pairs."""
 
@@ -139,6 +146,7 @@ class SuperGlueEngine(_MatcherBase):
         sinkhorn_iterations: int = 20,
         match_threshold: float = 0.2,
         return_ot: bool = False,
+        workspace: Optional[torch.Tensor] = None,
     ) -> Dict[str, torch.Tensor]:
         """Token-major device inputs concatenated as pair0/img0, pair0/img1, pair1/img0, ...: kpts [T,2], scores [T],
         desc [T,256]; n0/n1 per-pair keypoint counts (all > 0); hw per pair (H0, W0, H1, W1).
@@ -152,7 +160,8 @@ class SuperGlueEngine(_MatcherBase):
         assert kpts.is_contiguous() and scores.is_contiguous() and desc.is_contiguous()
         assert kpts.dtype == scores.dtype == desc.dtype == torch.float32
         dsc = self._build_desc(True, n0, n1, hw)
-        ws = self._get_workspace(self._lib.gtsfm_sg_workspace_bytes(p, n0.ctypes.data, n1.ctypes.data))
+        need = self._lib.gtsfm_sg_workspace_bytes(p, n0.ctypes.data, n1.ctypes.data)
+        ws = workspace if workspace is not None and workspace.numel() >= need else self._get_workspace(need)
         matches = torch.empty(t, dtype=torch.int32, device=self.device)
         mscores = torch.empty(t, dtype=torch.float32, device=self.device)
         ot = None
@@ -272,6 +281,7 @@ class LightGlueEngine(_MatcherBase):
         filter_threshold: float = LIGHTGLUE_FILTER_THRESHOLD,
         pruning_threshold: Optional[int] = LIGHTGLUE_PRUNING_THRESHOLD,
         return_sim: bool = False,
+        workspace: Optional[torch.Tensor] = None,
     ) -> Dict[str, torch.Tensor]:
         """kpts [T,2], desc [T,256] concatenated as pair0/img0, pair0/img1, ...; returns matches [T] int32 in ORIGINAL
         keypoint indices, mscores [T], stop [P] (layers run), kept [2P] (keypoints alive at the final assignment)."""
@@ -283,7 +293,8 @@ class LightGlueEngine(_MatcherBase):
         assert kpts.shape == (t, 2) and desc.shape == (t, 256) and kpts.is_contiguous() and desc.is_contiguous()
         assert kpts.dtype == desc.dtype == torch.float32
         dsc = self._build_desc(False, n0, n1, hw)
-        ws = self._get_workspace(self._lib.gtsfm_lg_workspace_bytes(p, n0.ctypes.data, n1.ctypes.data))
+        need = self._lib.gtsfm_lg_workspace_bytes(p, n0.ctypes.data, n1.ctypes.data)
+        ws = workspace if workspace is not None and workspace.numel() >= need else self._get_workspace(need)
         matches = torch.empty(t, dtype=torch.int32, device=self.device)
         mscores = torch.empty(t, dtype=torch.float32, device=self.device)
         sim = None

@@ -9,6 +9,7 @@ pairs are matched from one resident feature table.
 
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -19,11 +20,16 @@ from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
 
 
 class FrontEndPipeline:
-    def __init__(self, detector: SuperPointEngine, matcher, max_keypoints: int = 5000, pair_chunk: int = 32):
+    def __init__(self, detector: SuperPointEngine, matcher, max_keypoints: int = 5000, pair_chunk: int = 32, num_streams: int = 2):
         self.detector = detector
         self.matcher = matcher
         self.max_keypoints = max_keypoints
         self.pair_chunk = pair_chunk
+        # pair chunks are independent: alternate them over HIP streams (each with its own workspace) so that one chunk's
+        # small / tail-heavy kernels overlap the other's MFMA-bound ones
+        self.num_streams = max(1, num_streams)
+        self._streams: List[torch.cuda.Stream] = []
+        self._stream_ws: List[Optional[torch.Tensor]] = []
 
     def detect(self, images: torch.Tensor, image_chunk: int = 16) -> Dict[str, torch.Tensor]:
         """images [n,H,W] (device, uint8 / float32) -> count [n], xy [n,K,2], scores [n,K], descriptors [n,K,256] with
@@ -42,27 +48,55 @@ class FrontEndPipeline:
             counts = feats["count"].cpu().numpy()
         results = []
         full = bool((counts == feats["xy"].shape[1]).all())
-        for c0 in range(0, len(pairs), self.pair_chunk):
+        device = feats["xy"].device
+        nstreams = min(self.num_streams, max(1, -(-len(pairs) // self.pair_chunk)))
+        if nstreams > 1 and len(self._streams) < nstreams:
+            self._streams = [torch.cuda.Stream(device) for _ in range(nstreams)]
+            self._stream_ws = [None] * nstreams
+        main = torch.cuda.current_stream(device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for ci, c0 in enumerate(range(0, len(pairs), self.pair_chunk)):
             chunk = list(pairs[c0 : c0 + self.pair_chunk])
-            idx = torch.tensor([i for p in chunk for i in p], dtype=torch.long, device=feats["xy"].device)
-            n0 = [int(counts[i]) for i, _ in chunk]
-            n1 = [int(counts[j]) for _, j in chunk]
-            hw = [[shapes[i][0], shapes[i][1], shapes[j][0], shapes[j][1]] for i, j in chunk]
-            if full:  # every image has exactly K keypoints: plain gathers
-                kp = feats["xy"].index_select(0, idx).reshape(-1, 2)
-                sc = feats["scores"].index_select(0, idx).reshape(-1)
-                de = feats["descriptors"].index_select(0, idx).reshape(-1, 256)
+            if nstreams > 1:
+                si = ci % nstreams
+                stream = self._streams[si]
+                if ci < nstreams:
+                    stream.wait_event(ready)  # features were produced on the caller's stream
+                need = self.matcher.workspace_bytes([int(counts[i]) for i, _ in chunk], [int(counts[j]) for _, j in chunk])
+                if self._stream_ws[si] is None or self._stream_ws[si].numel() < need:
+                    self._stream_ws[si] = torch.empty(int(need * 1.1) + 256, dtype=torch.uint8, device=device)
+                matcher_kwargs = dict(matcher_kwargs, workspace=self._stream_ws[si])
+                ctx = torch.cuda.stream(stream)
             else:
-                kp = torch.cat([feats["xy"][i, : counts[i]] for i in idx.tolist()], 0)
-                sc = torch.cat([feats["scores"][i, : counts[i]] for i in idx.tolist()], 0)
-                de = torch.cat([feats["descriptors"][i, : counts[i]] for i in idx.tolist()], 0)
-            if isinstance(self.matcher, SuperGlueEngine):
-                out = self.matcher.match_batch(kp, sc, de, n0, n1, hw, **matcher_kwargs)
-            else:
-                out = self.matcher.match_batch(kp, de, n0, n1, hw, **matcher_kwargs)
-            out["pairs"], out["n0"], out["n1"] = chunk, n0, n1
-            results.append(out)
+                ctx = contextlib.nullcontext()
+            with ctx:
+                results.append(self._match_chunk(feats, chunk, shapes, counts, full, matcher_kwargs))
+        if nstreams > 1:
+            for stream in self._streams[:nstreams]:
+                main.wait_stream(stream)  # the caller's stream sees every chunk's outputs
         return results
+
+    def _match_chunk(self, feats, chunk, shapes, counts, full, matcher_kwargs):
+        """One ragged multi-pair launch sequence on the current stream."""
+        idx = torch.tensor([i for p in chunk for i in p], dtype=torch.long, device=feats["xy"].device)
+        n0 = [int(counts[i]) for i, _ in chunk]
+        n1 = [int(counts[j]) for _, j in chunk]
+        hw = [[shapes[i][0], shapes[i][1], shapes[j][0], shapes[j][1]] for i, j in chunk]
+        if full:  # every image has exactly K keypoints: plain gathers
+            kp = feats["xy"].index_select(0, idx).reshape(-1, 2)
+            sc = feats["scores"].index_select(0, idx).reshape(-1)
+            de = feats["descriptors"].index_select(0, idx).reshape(-1, 256)
+        else:
+            kp = torch.cat([feats["xy"][i, : counts[i]] for i in idx.tolist()], 0)
+            sc = torch.cat([feats["scores"][i, : counts[i]] for i in idx.tolist()], 0)
+            de = torch.cat([feats["descriptors"][i, : counts[i]] for i in idx.tolist()], 0)
+        if isinstance(self.matcher, SuperGlueEngine):
+            out = self.matcher.match_batch(kp, sc, de, n0, n1, hw, **matcher_kwargs)
+        else:
+            out = self.matcher.match_batch(kp, de, n0, n1, hw, **matcher_kwargs)
+        out["pairs"], out["n0"], out["n1"] = chunk, n0, n1
+        return out
 
     @staticmethod
     def matches_to_numpy(results: List[Dict[str, torch.Tensor]], dtype=np.int64) -> Dict[Tuple[int, int], np.ndarray]:
