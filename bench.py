@@ -229,7 +229,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--images", type=int, default=46, help="images per rank per step (46 -> 1035 exhaustive pairs, first --pairs kept)")
     ap.add_argument("--pairs", type=int, default=1000, help="exhaustive (i<j) pairs matched per rank per step")
-    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--size", type=int, default=1024, help="square image side (overridden by --height / --width)")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--matcher", choices=["none", "lightglue", "superglue"], default="lightglue")
     ap.add_argument("--keypoints", type=int, default=2048, help="keypoints kept per image (device top-k by response)")
     ap.add_argument("--sinkhorn", type=int, default=100, help="SuperGlue Sinkhorn iterations (GTSfM runs 20; BASELINE config 4 asks for 100)")
@@ -275,7 +277,8 @@ def main() -> None:
         blob = matcher.weights if rank == 0 else None
         matcher.weights = parallel.broadcast_packed_weights(blob, matcher.weights.numel(), device)
 
-    h = w = args.size
+    h = args.height or args.size
+    w = args.width or args.size
     n = args.images
     # overlapping views: every image is a crop of one seeded canvas, shifted by multiples of the 8-px SuperPoint cell, so
     # that exhaustive pairs share content (non-trivial match lists) while every image is still detected independently
@@ -320,7 +323,7 @@ def main() -> None:
         nmatch = int(sum(int((r["matches"] > -1).sum()) for r in res)) // 2 if res else 0
         flops_step = superpoint_flops(h, w) * n + (matcher_flops(args.matcher, args.keypoints, layers, args.sinkhorn) * len(pairs) if res else 0)
         result = {
-            "metric": "images/sec (SuperPoint detect+describe) @1024px" if detect_only else "image-pairs/sec (detect+match) @1024px",
+            "metric": f"images/sec (SuperPoint detect+describe) @{h}x{w}" if detect_only else f"image-pairs/sec (detect+match) @{max(h, w)}px",
             "value": round(value, 2),
             "unit": "images/s" if detect_only else "image-pairs/s",
             "n_gpus": world,
