@@ -29,54 +29,52 @@ MODEL_WEIGHTS_PATH = (
 
 
 class SuperPointDetectorDescriptor(DetectorDescriptorBase):
-    """Superpoint Detector+Descriptor implementation (HIP / gfx950)."""
+    """SuperPoint on gfx950 behind the reference's detector-descriptor plugin interface."""
 
     def __init__(
         self, max_keypoints: int = 5000, use_cuda: bool = True, weights_path: Union[Path, str] = MODEL_WEIGHTS_PATH
     ) -> None:
         super().__init__(max_keypoints=max_keypoints)
-        self._use_cuda = use_cuda
-        self._config = {"weights_path": weights_path}
-        self._model = None  # lazy: created on the worker at first use
-        if not Path(weights_path).exists():
+        checkpoint = Path(weights_path)
+        if not checkpoint.exists():  # same failure point as the reference: construction, not first use
             raise FileNotFoundError(
-                f"SuperPoint weights not found at {weights_path}. "
-                f"Please run 'bash scripts/download_model_weights.sh' from the repo root."
+                f"no SuperPoint checkpoint at {checkpoint}; fetch it with scripts/download_model_weights.sh "
+                f"or pass weights_path="
             )
+        self._use_cuda = bool(use_cuda)
+        self._config = {"weights_path": checkpoint}
+        self._model = None  # SuperPointEngine, built in the process that first calls detect_and_describe
 
-    # device state never travels with the pickled object
     def __getstate__(self):
-        state = dict(self.__dict__)
-        state["_model"] = None
-        return state
+        # the packed weights live in HBM of one process; a pickled copy (Dask scatter) rebuilds its own
+        return {**self.__dict__, "_model": None}
 
     def _ensure_model_loaded(self) -> None:
-        if self._model is None:
-            import torch
+        if self._model is not None:
+            return
+        if not self._use_cuda:
+            raise RuntimeError(
+                "gtsfm_amd's SuperPointDetectorDescriptor runs on the GPU only (use_cuda=False requested); "
+                "use the reference implementation for CPU execution."
+            )
+        import torch
 
-            from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+        from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
 
-            if not self._use_cuda:
-                raise RuntimeError(
-                    "gtsfm_amd's SuperPointDetectorDescriptor runs on the GPU only (use_cuda=False requested); "
-                    "use the reference implementation for CPU execution."
-                )
-            state_dict = torch.load(str(self._config["weights_path"]), map_location="cpu")
-            self._model = SuperPointEngine(state_dict)
+        self._model = SuperPointEngine(torch.load(str(self._config["weights_path"]), map_location="cpu"))
 
     def detect_and_describe(self, image: Image) -> Tuple[Keypoints, np.ndarray]:
-        """Jointly generate keypoint detections and their associated descriptors from a single image."""
+        """Keypoints (with responses, no scales) and their (K, 256) float32 unit descriptors for one image."""
         self._ensure_model_loaded()
-        assert self._model is not None
         gray = rgb_to_gray_u8(image.value_array)
         if gray.dtype != np.uint8:  # the reference computes astype(float32) / 255.0 whatever the input dtype
             gray = gray.astype(np.float32) / 255.0
-        coordinates, scores, descriptors = self._model.detect(np.ascontiguousarray(gray))
-        keypoints = Keypoints(coordinates, scales=None, responses=scores)
+        xy, responses, descriptors = self._model.detect(np.ascontiguousarray(gray))
+        detections = Keypoints(xy, scales=None, responses=responses)
 
+        # selection on the host with the reference's own Keypoints methods -> identical ordering and ties
         if image.mask is not None:
-            keypoints, valid_idxs = keypoints.filter_by_mask(image.mask)
-            descriptors = descriptors[valid_idxs]
-        keypoints, selection_idxs = keypoints.get_top_k(self.max_keypoints)
-        descriptors = descriptors[selection_idxs]
-        return keypoints, descriptors
+            detections, inside = detections.filter_by_mask(image.mask)
+            descriptors = descriptors[inside]
+        detections, strongest = detections.get_top_k(self.max_keypoints)
+        return detections, descriptors[strongest]
