@@ -235,6 +235,9 @@ def main() -> None:
     ap.add_argument("--matcher", choices=["none", "lightglue", "superglue"], default="lightglue")
     ap.add_argument("--keypoints", type=int, default=2048, help="keypoints kept per image (device top-k by response)")
     ap.add_argument("--sinkhorn", type=int, default=100, help="SuperGlue Sinkhorn iterations (GTSfM runs 20; BASELINE config 4 asks for 100)")
+    ap.add_argument("--pair-definition", choices=["exhaustive", "independent"], default="exhaustive",
+                    help="exhaustive: (i<j) pairs of --images images, each detected once per step (the headline); independent: "
+                         "--pairs disjoint pairs, 2 fresh detections per pair (SURVEY.md section 8d asks for both rates)")
     ap.add_argument("--pair-chunk", type=int, default=32)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the pair chunks alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -286,6 +289,14 @@ def main() -> None:
     imgs = np.stack([canvas[8 * i : 8 * i + h, 8 * ((7 * i) % n) : 8 * ((7 * i) % n) + w] for i in range(n)])
     images = torch.from_numpy(imgs).to(device)  # inputs resident in HBM before the timed region
     pairs = parallel.exhaustive_pairs(n)[: args.pairs] if matcher is not None else []
+    independent = args.pair_definition == "independent" and matcher is not None
+    if independent:
+        # 2 P image slots, every slot detected afresh each step (slot s shows view (5 s) % n; nothing is cached or shared
+        # between slots), pair p = slots (2p, 2p + 1)
+        slots = torch.arange(2 * args.pairs, device=device)
+        images = images[(5 * slots) % n].contiguous()
+        n = 2 * args.pairs
+        pairs = [(2 * p, 2 * p + 1) for p in range(args.pairs)]
     pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams)
     shapes = [(h, w)] * n
     mk = {"sinkhorn_iterations": args.sinkhorn} if args.matcher == "superglue" else {}
@@ -338,10 +349,12 @@ def main() -> None:
             "config": {
                 "workload": (
                     f"SuperPoint-only: {n} synthetic {h}x{w} gray images per GPU per step" if detect_only else
+                    f"SuperPoint+{args.matcher}: {len(pairs)} independent pairs = {n} fresh detections of synthetic {h}x{w} gray images per GPU "
+                    f"per step, top-{args.keypoints} keypoints per image" if independent else
                     f"SuperPoint+{args.matcher}: {len(pairs)} exhaustive (i<j) pairs of {n} synthetic {h}x{w} gray images per GPU per step "
                     f"(each image detected once per step), top-{args.keypoints} keypoints per image"
                 ),
-                "pair_definition": "exhaustive",
+                "pair_definition": args.pair_definition if not detect_only else None,
                 "images_per_gpu_per_step": n,
                 "pairs_per_gpu_per_step": len(pairs),
                 "keypoints_per_image": [int(min(kcount)), int(max(kcount))],
