@@ -20,6 +20,26 @@
 #define AT_QB 128      // queries per workgroup
 #define AT_ROW 68      // LDS row stride (floats)
 #define AT_TILE (AT_KT * AT_ROW)
+#define AT_REBASE 8.0f  // rebase the softmax reference when the running maximum moved by more than this (base-2 units)
+
+// Developer timeline (tools/trace_attention.hip builds this file with -DGTSFM_TRACE; the product build has none of it):
+// per wave, shader-clock cycles summed over all key tiles for each segment of the tile loop. The stamps sit where the
+// LDS queue is empty anyway (s_memtime returns through lgkmcnt) and are fenced against instruction motion.
+#ifdef GTSFM_TRACE
+__device__ unsigned long long* g_attn_trace;  // [workgroup][wave][8]: S issue, softmax, PV issue, barrier 1, store + barrier 2, total, hw id, tiles
+#define TRACE_DECL unsigned t_prev = (unsigned)__builtin_amdgcn_s_memtime(); const unsigned t_begin = t_prev; unsigned seg[5] = {0, 0, 0, 0, 0};
+#define TRACE_SEG(k)                                                  \
+    {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        const unsigned t_now = (unsigned)__builtin_amdgcn_s_memtime(); \
+        seg[k] += t_now - t_prev;                                     \
+        t_prev = t_now;                                               \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    }
+#else
+#define TRACE_DECL
+#define TRACE_SEG(k)
+#endif
 
 __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnParams p) {
     // LDS: one K tile and one V tile ([key][d], row stride 68; 34 KiB -> three workgroups per CU, which keeps the matrix
@@ -65,7 +85,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnParams p) {
     f32x16 o0, o1;  // O^T: rows d 0..31 / 32..63, column q
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    float m = -__builtin_inff(), l = 0.f;
+    float m = 0.f, l = 0.f;  // m: lazy reference maximum (set by the first tile)
 
     const float* kbase = p.k + (size_t)pr.k_off * p.ldk + h * 64;
     const float* vbase = p.v + (size_t)pr.k_off * p.ldv + h * 64;
@@ -97,24 +117,27 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnParams p) {
     stage_load(0);
     stage_store(0);
     __syncthreads();
+    TRACE_DECL
     for (int t = 0; t < ntiles; ++t) {
         const int k0 = t * AT_KT;
         const float* Kt = Ks;
         const float* Vt = Vs;
         if (t + 1 < ntiles) stage_load(k0 + AT_KT);
 
-        // S^T = K Q^T  (two 32-key tiles)
+        // S^T = K Q^T  (two 32-key tiles). The accumulators start at -m (m = reference maximum of this query, see
+        // below), so the MFMA chain delivers s - m directly and the softmax needs no subtraction pass.
         f32x16 s0, s1;
+        const float neg_m = -m;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = neg_m;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Kt[j * AT_ROW + u * 8 + kh * 4]);
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Kt[(32 + j) * AT_ROW + u * 8 + kh * 4]);
             mt_step(s0, s1, a0, a1, qreg[u]);
         }
-        // mask (last tile only), online softmax (per query = per lane; the two lane halves hold different keys of the same
-        // query)
+        TRACE_SEG(0)
+        // mask (last tile only)
         if (k0 + AT_KT > nk) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -123,30 +146,44 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnParams p) {
                 if (key + 32 >= nk) s1[r] = -__builtin_inff();
             }
         }
-        float mloc = -__builtin_inff();
+        // Online softmax with a LAZY reference maximum (per query = per lane; the two lane halves hold different keys of
+        // the same query): m follows the running maximum only when that has moved by more than AT_REBASE (base-2 units),
+        // so exp2(s - m) <= 2^AT_REBASE stays far from overflow while most tiles skip the rebase (subtract + rescale of O
+        // and l) entirely. The VALU work of a tile -- which crawls while the other waves of the SIMD keep the matrix
+        // pipe busy -- drops from ~180 to ~90 instructions. out = O / l does not depend on the choice of m.
+        float mloc = fmaxf(s0[0], s1[0]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float mnew = fmaxf(m, mloc);  // finite: key k0 is always valid
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));  // finite on every tile: key k0 is always valid
+        const bool rebase = (t == 0) || (mloc > AT_REBASE);
+        if (__any(rebase)) {  // wave-uniform
+            const float d = rebase ? mloc : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] -= d;
+                s1[r] -= d;
+            }
+            if (t > 0) {  // (first tile: O = l = 0 and m = 0)
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                l *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
+            }
+            m += d;
+        }
         float lsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r] - mnew);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r] - mnew);
+            s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r]);
             lsum += s0[r] + s1[r];
         }
         lsum += __shfl_xor(lsum, 32, 64);
-        if (__any(mnew != m)) {  // wave-uniform: skip the rescale when no running maximum moved (alpha == 1 exactly)
-            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-            l *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o0[r] *= alpha;
-                o1[r] *= alpha;
-            }
-        }
         l += lsum;
-        m = mnew;
+        TRACE_SEG(1)
         // O^T += V^T P^T. Accumulator register r of S^T tile T holds key 32T + (r&3) + 8(r>>2) + 4kh, so it IS the B
         // operand of k-step r; the A operand V^T[d = lane][key] is a conflict-free row read of the row-major V tile.
 #pragma unroll
@@ -164,12 +201,24 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnParams p) {
                 mt_step(o0, o1, a0, a1, b);
             }
         }
+        TRACE_SEG(2)
         if (t + 1 < ntiles) {
             __syncthreads();
+            TRACE_SEG(3)
             stage_store(0);
             __syncthreads();
+            TRACE_SEG(4)
         }
     }
+#ifdef GTSFM_TRACE
+    if (lane == 0 && g_attn_trace) {
+        unsigned long long* o = g_attn_trace + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int k = 0; k < 5; ++k) o[k] = seg[k];
+        o[5] = (unsigned)__builtin_amdgcn_s_memtime() - t_begin;
+        o[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+        o[7] = ntiles;
+    }
+#endif
 
     if (!qvalid) return;
     const float inv = (l > 0.f) ? 1.0f / l : 0.f;
