@@ -137,6 +137,10 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnParams p) {
             mt_step(s0, s1, a0, a1, qreg[u]);
         }
         TRACE_SEG(0)
+        // Everything between the two MFMA phases is latency-bound VALU / LDS / barrier work that crawls when the other
+        // two waves of the SIMD win the issue arbitration with their MFMAs; while it lasts this wave offers the matrix
+        // pipe nothing. Run it at raised priority so the wave is back to feeding the pipe as soon as possible.
+        __builtin_amdgcn_s_setprio(3);
         // mask (last tile only)
         if (k0 + AT_KT > nk) {
 #pragma unroll
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnParams p) {
         }
         lsum += __shfl_xor(lsum, 32, 64);
         l += lsum;
+        __builtin_amdgcn_s_setprio(0);
         TRACE_SEG(1)
         // O^T += V^T P^T. Accumulator register r of S^T tile T holds key 32T + (r&3) + 8(r>>2) + 4kh, so it IS the B
         // operand of k-step r; the A operand V^T[d = lane][key] is a conflict-free row read of the row-major V tile.
@@ -203,10 +208,12 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnParams p) {
         }
         TRACE_SEG(2)
         if (t + 1 < ntiles) {
+            __builtin_amdgcn_s_setprio(3);
             __syncthreads();
             TRACE_SEG(3)
             stage_store(0);
             __syncthreads();
+            __builtin_amdgcn_s_setprio(0);
             TRACE_SEG(4)
         }
     }

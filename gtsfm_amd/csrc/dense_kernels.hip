@@ -19,6 +19,13 @@
 #define CV_TW 16
 #define CV_HW (CV_TW + 2)
 #define CV_HALO_PIX ((CV_TH + 2) * CV_HW)
+// LDS pitch of one halo row in floats: 18 pixels x 68 + 56 = 1280 = 0 (mod 64 banks). The 32 pixels a wave reads per
+// ds_read_b128 span two halo rows (16 + 16); with the natural pitch 18 x 68 = 8 (mod 64) the second row's lanes land on
+// banks the first row's lanes of the same 16-lane service group already use (46 % of the LDS-active cycles were
+// conflict cycles, SQ_LDS_BANK_CONFLICT); with pitch = 0 (mod 64) lane j of either row sits at bank 4 j like in the
+// uniformly strided GEMM / attention tiles.
+#define CV_ROW_PITCH (CV_HW * MT_LDS_ROW + 56)
+#define CV_HALO_FLOATS ((CV_TH + 2) * CV_ROW_PITCH)
 
 // FUSE_C1A: the input activation is not read from HBM but recomputed on the fly from the gray image: the halo tile of
 // conv1b's input IS relu(conv1a(image)) (superpoint.py:148-149), 9 fma per value in conv1a_kernel's tap order (bit-identical
@@ -52,17 +59,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
         acc1[r] = bias;
     }
 
-    const int a_base0 = ((4 * wm + (j >> 4)) * CV_HW + (j & 15)) * MT_LDS_ROW + kh * 4;
-    const int a_base1 = a_base0 + 2 * CV_HW * MT_LDS_ROW;
+    const int a_base0 = (4 * wm + (j >> 4)) * CV_ROW_PITCH + (j & 15) * MT_LDS_ROW + kh * 4;
+    const int a_base1 = a_base0 + 2 * CV_ROW_PITCH;
     const float* __restrict__ in_b = p.in + (size_t)b * p.H * p.W * p.in_stride + p.in_coff;
 
     int kstep = 0;
     f32x4 bcur = mt_load_b(wp, 0, wn, lane);
     for (int cc = 0; cc < nchunks; ++cc) {
+        // (raising the wave priority for staging / epilogue as in the GEMM and attention kernels was measured here and
+        // costs 2.5 points: 74.1 % vs 76.7 %)
         if (cc > 0) __syncthreads();
         // stage the halo tile of this 64-channel chunk: 180 pixels x 16 float4
         if (FUSE_C1A) {
-            float* w1 = lds + CV_HALO_PIX * MT_LDS_ROW;  // [9 taps][64] + [64] bias
+            float* w1 = lds + CV_HALO_FLOATS;  // [9 taps][64] + [64] bias
             for (int idx = tid; idx < 10 * 64 / 4; idx += 256)
                 *reinterpret_cast<f32x4*>(&w1[idx * 4]) = *reinterpret_cast<const f32x4*>((idx < 144 ? p.w1a : p.b1a - 576) + idx * 4);
             __syncthreads();
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
                     }
                     v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
                 }
-                *reinterpret_cast<f32x4*>(&lds[pix * MT_LDS_ROW + q * 4]) = v;
+                *reinterpret_cast<f32x4*>(&lds[(pix / CV_HW) * CV_ROW_PITCH + (pix % CV_HW) * MT_LDS_ROW + q * 4]) = v;
             }
         } else {
             for (int idx = tid; idx < CV_HALO_PIX * 16; idx += 256) {
@@ -100,12 +109,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
                     v = *reinterpret_cast<const f32x4*>(in_b + ((size_t)gy * p.W + gx) * p.in_stride + cc * 64 + q * 4);
-                *reinterpret_cast<f32x4*>(&lds[pix * MT_LDS_ROW + q * 4]) = v;
+                *reinterpret_cast<f32x4*>(&lds[(pix / CV_HW) * CV_ROW_PITCH + (pix % CV_HW) * MT_LDS_ROW + q * 4]) = v;
             }
         }
         __syncthreads();
         for (int tap = 0; tap < 9; ++tap) {
-            const int toff = ((tap / 3) * CV_HW + (tap % 3)) * MT_LDS_ROW;
+            const int toff = (tap / 3) * CV_ROW_PITCH + (tap % 3) * MT_LDS_ROW;
 #pragma unroll
             for (int c8 = 0; c8 < 8; ++c8) {
                 const int nxt = (kstep + 1 < total_steps) ? kstep + 1 : kstep;
@@ -167,7 +176,7 @@ int launch_conv3x3(const ConvParams& pin, hipStream_t stream) {
     p.tiles_x = ceil_div(p.W, CV_TW);
     p.tiles_y = ceil_div(p.H, CV_TH);
     dim3 grid(p.B * p.tiles_x * p.tiles_y, ceil_div(p.Cout, 64));
-    size_t lds_bytes = (size_t)CV_HALO_PIX * MT_LDS_ROW * sizeof(float);
+    size_t lds_bytes = (size_t)CV_HALO_FLOATS * sizeof(float);
     if (p.img) {
         GTSFM_CHECK_ARG(p.Cin == 64 && p.w1a && p.b1a, "conv3x3: the fused first layer needs Cin == 64 and conv1a weights");
         lds_bytes += 640 * sizeof(float);
@@ -202,6 +211,24 @@ __device__ __forceinline__ void gemm_step(f32x16& c00, f32x16& c01, f32x16& c10,
 }
 
 
+// Developer timeline (tools/trace_gemm.hip builds this file with -DGTSFM_TRACE; nothing of it is in the product build).
+#ifdef GTSFM_TRACE
+__device__ unsigned long long* g_gemm_trace;  // [workgroup][wave][8]
+#define GT_DECL unsigned gt_prev = (unsigned)__builtin_amdgcn_s_memtime(); const unsigned gt_begin = gt_prev; unsigned gseg[6] = {0, 0, 0, 0, 0, 0};
+#define GT_SEG(k)                                                      \
+    {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        const unsigned gt_now = (unsigned)__builtin_amdgcn_s_memtime(); \
+        gseg[k] += gt_now - gt_prev;                                   \
+        gt_prev = gt_now;                                              \
+        __builtin_amdgcn_sched_barrier(0);                             \
+    }
+#else
+#define GT_DECL
+#define GT_SEG(k)
+#endif
+
+template <bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmParams p) {
     // A workgroup owns a 128-row tile and walks p.nb_per_wg 128-column blocks of the output with ONE software
     // pipeline: the loop runs over (column block, 64-deep K chunk) pairs; while the waves run the MFMAs of one chunk
@@ -262,26 +289,43 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmParams p) {
         return mt_load_b(p.wpack + (size_t)nb * total_steps * MT_PACK_STEP_FLOATS, s, half, lane);
     };
 
+    __builtin_amdgcn_s_setprio(3);
+    // bias of this workgroup's columns -> LDS (zeros without a bias / beyond N; the array is padded to a multiple of 64)
+    float* bias_lds = lds + 2 * BUF;
+    for (int i = tid; i < ncb * 128; i += 256) {
+        const int col = cb0 * 128 + i;
+        bias_lds[i] = (p.bias && col < nblocks * 64) ? p.bias[col] : 0.f;
+    }
     stage_load(0);
     f32x4 b0c = ldb(0, 0), b1c = ldb(0, 1), b0n = ldb(1, 0), b1n = ldb(1, 1);
     stage_store(lds);
     __syncthreads();
     f32x16 c00, c01, c10, c11;
     int g = 0;
+    GT_DECL
     const int iters = ncb * nchunks;
     int it = 0;
     for (int cbi = 0; cbi < ncb; ++cbi) {
         const int nb = (cb0 + cbi) * 2 + wn;  // 64-column block of this wave
         const bool active = nb < nblocks;     // waves beyond N still help staging
         const int colb = nb * 64 + 4 * kh;  // + 32 * (column half) + 8 * (r >> 2) + (r & 3)
+        // accumulators start at the bias, read from the LDS copy made in the prologue: a global load here would queue
+        // behind the previous block's 16 stores (vmcnt is in order) and wait ~5 k cycles for their acknowledgement
+        {
+            const float* bl = bias_lds + cbi * 128 + wn * 64 + 4 * kh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cc = colb + 8 * (r >> 2) + (r & 3);
-            const float bb0 = (p.bias && active) ? p.bias[cc] : 0.f;  // bias is padded to a multiple of 64
-            const float bb1 = (p.bias && active) ? p.bias[cc + 32] : 0.f;
-            c00[r] = c10[r] = bb0;
-            c01[r] = c11[r] = bb1;
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b0v = *reinterpret_cast<const f32x4*>(bl + 8 * q);
+                const f32x4 b1v = *reinterpret_cast<const f32x4*>(bl + 32 + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    c00[4 * q + e] = c10[4 * q + e] = b0v[e];
+                    c01[4 * q + e] = c11[4 * q + e] = b1v[e];
+                }
+            }
         }
+        __builtin_amdgcn_s_setprio(0);
+        GT_SEG(4)
         for (int c = 0; c < nchunks; ++c, ++it) {
             const float* buf = lds + (it & 1) * BUF;
             if (it + 1 < iters) stage_load(((c + 1 < nchunks) ? c + 1 : 0) * 64);
@@ -289,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmParams p) {
             if (nsteps == 8) {
                 f32x4 a0 = *reinterpret_cast<const f32x4*>(&buf[a_base0]);
                 f32x4 a1 = *reinterpret_cast<const f32x4*>(&buf[a_base1]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // own group for the chunk's first two A reads: the per-step groups below stay aligned
 #pragma unroll
                 for (int c8 = 0; c8 < 8; ++c8) {
                     const f32x4 b0f = ldb(g + 2, 0), b1f = ldb(g + 2, 1);
@@ -318,51 +363,102 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmParams p) {
                     ++g;
                 }
             }
+            // Everything up to the next chunk's first MFMA (epilogue, LDS staging, barrier, accumulator re-initialisation)
+            // is VALU / memory-issue work that loses the issue arbitration against the MFMAs of the SIMD's other wave
+            // and crawls at ~40 cycles per instruction unless it runs at raised priority; while it lasts this wave
+            // feeds the matrix pipe nothing.
+            GT_SEG(c == 0 ? 1 : 0)
+            __builtin_amdgcn_s_setprio(3);
             if (c == nchunks - 1 && active && !(p.debug & 1)) {
                 // the row offsets are loop-invariant; keep the compiler from hoisting 64 addresses out of the column-block
                 // loop (they would live across the whole pipeline and spill): make the base opaque per block
                 int row_base = m0 + 64 * wm + j;
                 asm volatile("" : "+v"(row_base));
-                const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!p.res || (p.ldres & 3) == 0);
+                const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!HAS_RES || (p.ldres & 3) == 0);
+                // scale / ReLU as whole-tile passes under uniform branches (no per-element selects)
+                if (p.alpha != 1.0f) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {  // t = 2 * (row half) + (column half)
-                    const int row = row_base + 32 * (t >> 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (row >= M) continue;
+                    for (int r = 0; r < 16; ++r) c00[r] *= p.alpha, c01[r] *= p.alpha, c10[r] *= p.alpha, c11[r] *= p.alpha;
+                }
+                if (p.relu) {
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int col = colb + 32 * (t & 1) + 8 * gq;
-                        f32x4 v;
+                    for (int r = 0; r < 16; ++r)
+                        c00[r] = fmaxf(c00[r], 0.f), c01[r] = fmaxf(c01[r], 0.f), c10[r] = fmaxf(c10[r], 0.f), c11[r] = fmaxf(c11[r], 0.f);
+                }
+                if (vec_ok) {
+                    // 16 stores of 16 bytes per lane: group i = 4 t + q, t = 2 (row half) + (column half), q = 8-column step.
+                    // The plain and the residual variant are SEPARATE code: merged, the compiler guards every store with
+                    // s_waitcnt vmcnt(0) for the residual load that might precede it, and since stores count in vmcnt too,
+                    // each store then waits for the previous store's acknowledgement (22 k cycles per block instead of 2 k).
+                    auto group = [&](int i) -> f32x4 {
+                        const int t = i >> 2, q = i & 3;
+                        const f32x16& ct = (t == 0) ? c00 : (t == 1) ? c01 : (t == 2) ? c10 : c11;
+                        return f32x4{ct[4 * q], ct[4 * q + 1], ct[4 * q + 2], ct[4 * q + 3]};
+                    };
+                    auto gcol = [&](int i) { return colb + 32 * ((i >> 2) & 1) + 8 * (i & 3); };
+                    // one divergent region per row half (a lane = a row), straight-line loads / stores inside: exec-masked
+                    // branches around single accesses would again make the compiler wait for vmcnt(0) at every join
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x = (t == 0) ? c00[4 * gq + e] : (t == 1) ? c01[4 * gq + e] : (t == 2) ? c10[4 * gq + e] : c11[4 * gq + e];
-                            if (p.alpha != 1.0f) x *= p.alpha;
-                            if (p.relu) x = fmaxf(x, 0.f);
-                            v[e] = x;
-                        }
-                        float* cp = p.C + (size_t)row * p.ldc + p.c_coff + col;
-                        if (vec_ok) {
-                            if (col < p.N) {
-                                if (p.res) {
-                                    const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldres + col);
-                                    v = rr + v;
+                    for (int hrow = 0; hrow < 2; ++hrow) {
+                        const int row = row_base + 32 * hrow;
+                        if (row < M) {
+                            float* crow = p.C + (size_t)row * p.ldc + p.c_coff;
+                            if (!HAS_RES) {
+#pragma unroll
+                                for (int i = 8 * hrow; i < 8 * hrow + 8; ++i)
+                                    if (gcol(i) < p.N) *reinterpret_cast<f32x4*>(crow + gcol(i)) = group(i);
+                            } else {
+                                // residual loads run one group ahead of the stores: each wait covers one load that is older
+                                // than every store still in flight
+                                const float* rrow = p.res + (size_t)row * p.ldres;
+                                const int last_col = p.N - 4;  // clamp instead of predicating the load (uniform, always valid)
+                                f32x4 cur = *reinterpret_cast<const f32x4*>(rrow + min(gcol(8 * hrow), last_col));
+#pragma unroll
+                                for (int i = 8 * hrow; i < 8 * hrow + 8; ++i) {
+                                    f32x4 nxt = cur;
+                                    if (i + 1 < 8 * hrow + 8) nxt = *reinterpret_cast<const f32x4*>(rrow + min(gcol(i + 1), last_col));
+                                    const f32x4 v = cur + group(i);
+                                    if (gcol(i) < p.N) *reinterpret_cast<f32x4*>(crow + gcol(i)) = v;
+                                    cur = nxt;
                                 }
-                                *reinterpret_cast<f32x4*>(cp) = v;
                             }
-                        } else {
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int row = row_base + 32 * (t >> 1);
+                        if (row >= M) continue;
+                        const f32x16& ct = (t == 0) ? c00 : (t == 1) ? c01 : (t == 2) ? c10 : c11;
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const int col = colb + 32 * (t & 1) + 8 * gq;
+                            float* cp = p.C + (size_t)row * p.ldc + p.c_coff + col;
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (col + e < p.N) cp[e] = p.res ? p.res[(size_t)row * p.ldres + col + e] + v[e] : v[e];
+                                if (col + e < p.N) cp[e] = HAS_RES ? p.res[(size_t)row * p.ldres + col + e] + ct[4 * gq + e] : ct[4 * gq + e];
                         }
                     }
                 }
             }
+            GT_SEG(2)
             if (it + 1 < iters) {
                 stage_store(lds + ((it + 1) & 1) * BUF);
                 __syncthreads();
             }
+            GT_SEG(3)
+            if (c + 1 < nchunks) __builtin_amdgcn_s_setprio(0);  // (a new column block first re-initialises the accumulators)
         }
     }
+#ifdef GTSFM_TRACE
+    if (lane == 0 && g_gemm_trace) {
+        unsigned long long* o = g_gemm_trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        for (int k = 0; k < 5; ++k) o[k] = gseg[k];
+        o[5] = (unsigned)__builtin_amdgcn_s_memtime() - gt_begin;
+        o[6] = ncb;
+        o[7] = nchunks;
+    }
+#endif
 }
 
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
@@ -381,8 +477,13 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     static const char* dbg = getenv("GTSFM_GEMM_DEBUG");
     q.debug = dbg ? atoi(dbg) : 0;
     dim3 grid(ceil_div(ncb_total, nbw), mtiles);
-    const size_t lds_bytes = (size_t)2 * MT_TILE_M * MT_LDS_ROW * sizeof(float);
-    hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), lds_bytes, stream, q);
+    size_t lds_bytes = ((size_t)2 * MT_TILE_M * MT_LDS_ROW + (size_t)nbw * 128) * sizeof(float);  // two A chunks + the bias
+    static const char* pad = getenv("GTSFM_GEMM_LDS_PAD");  // developer switch: extra LDS bytes to force 1 workgroup per CU
+    if (pad) lds_bytes += (size_t)atoi(pad);
+    if (q.res)
+        hipLaunchKernelGGL(gemm_mfma_kernel<true>, grid, dim3(256), lds_bytes, stream, q);
+    else
+        hipLaunchKernelGGL(gemm_mfma_kernel<false>, grid, dim3(256), lds_bytes, stream, q);
     GTSFM_CHECK_LAUNCH("gemm_mfma_kernel");
     return GTSFM_OK;
 }
