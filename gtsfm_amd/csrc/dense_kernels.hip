@@ -65,6 +65,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
 
     int kstep = 0;
     f32x4 bcur = mt_load_b(wp, 0, wn, lane);
+    // weights run TWO k-steps ahead of their use: one step (512 cycles of this wave's MFMAs) does not cover the L2
+    // latency under load, 76.7 -> 81.6 % of peak; three steps ahead measured 76.7 % again (the schedule changes)
+    f32x4 bnxt = mt_load_b(wp, 1, wn, lane);  // total_steps >= 72
     for (int cc = 0; cc < nchunks; ++cc) {
         // (raising the wave priority for staging / epilogue as in the GEMM and attention kernels was measured here and
         // costs 2.5 points: 74.1 % vs 76.7 %)
@@ -117,12 +120,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
             const int toff = (tap / 3) * CV_ROW_PITCH + (tap % 3) * MT_LDS_ROW;
 #pragma unroll
             for (int c8 = 0; c8 < 8; ++c8) {
-                const int nxt = (kstep + 1 < total_steps) ? kstep + 1 : kstep;
+                const int nxt = (kstep + 2 < total_steps) ? kstep + 2 : total_steps - 1;
                 const f32x4 bnext = mt_load_b(wp, nxt, wn, lane);
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[a_base0 + toff + c8 * 8]);
                 const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[a_base1 + toff + c8 * 8]);
                 mt_step(acc0, acc1, a0, a1, bcur);
-                bcur = bnext;
+                bcur = bnxt;
+                bnxt = bnext;
                 ++kstep;
             }
         }
