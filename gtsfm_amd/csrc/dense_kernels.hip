@@ -118,16 +118,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
         __syncthreads();
         for (int tap = 0; tap < 9; ++tap) {
             const int toff = (tap / 3) * CV_ROW_PITCH + (tap % 3) * MT_LDS_ROW;
+            f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[a_base0 + toff]);
+            f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[a_base1 + toff]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
             for (int c8 = 0; c8 < 8; ++c8) {
                 const int nxt = (kstep + 2 < total_steps) ? kstep + 2 : total_steps - 1;
                 const f32x4 bnext = mt_load_b(wp, nxt, wn, lane);
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(&lds[a_base0 + toff + c8 * 8]);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&lds[a_base1 + toff + c8 * 8]);
+                f32x4 a0n = a0, a1n = a1;
+                if (c8 < 7) {
+                    a0n = *reinterpret_cast<const f32x4*>(&lds[a_base0 + toff + (c8 + 1) * 8]);
+                    a1n = *reinterpret_cast<const f32x4*>(&lds[a_base1 + toff + (c8 + 1) * 8]);
+                }
                 mt_step(acc0, acc1, a0, a1, bcur);
                 bcur = bnxt;
                 bnxt = bnext;
+                a0 = a0n, a1 = a1n;
                 ++kstep;
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (c8 < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
         }
     }
