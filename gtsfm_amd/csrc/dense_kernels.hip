@@ -65,9 +65,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
 
     int kstep = 0;
     f32x4 bcur = mt_load_b(wp, 0, wn, lane);
-    // weights run TWO k-steps ahead of their use: one step (512 cycles of this wave's MFMAs) does not cover the L2
-    // latency under load, 76.7 -> 81.6 % of peak; three steps ahead measured 76.7 % again (the schedule changes)
+    // Weights run THREE k-steps ahead of their use and the A fragments one, with the issue order of every k-step pinned
+    // (1 weight load, 2 LDS reads, 8 MFMAs). Measured on the SuperPoint conv stack, % of the fp32 MFMA peak: weights one
+    // step ahead, reads at use, free schedule 76.7 (162 VGPRs: the compiler hoists loads at will); weights two ahead
+    // 81.6; + A one ahead, pinned 84.8 (74 VGPRs); weights three ahead 86.0; four ahead 85.0.
     f32x4 bnxt = mt_load_b(wp, 1, wn, lane);  // total_steps >= 72
+    f32x4 bnx2 = mt_load_b(wp, 2, wn, lane);
     for (int cc = 0; cc < nchunks; ++cc) {
         // (raising the wave priority for staging / epilogue as in the GEMM and attention kernels was measured here and
         // costs 2.5 points: 74.1 % vs 76.7 %)
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
             for (int c8 = 0; c8 < 8; ++c8) {
-                const int nxt = (kstep + 2 < total_steps) ? kstep + 2 : total_steps - 1;
+                const int nxt = (kstep + 3 < total_steps) ? kstep + 3 : total_steps - 1;
                 const f32x4 bnext = mt_load_b(wp, nxt, wn, lane);
                 f32x4 a0n = a0, a1n = a1;
                 if (c8 < 7) {
@@ -132,7 +135,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
                 }
                 mt_step(acc0, acc1, a0, a1, bcur);
                 bcur = bnxt;
-                bnxt = bnext;
+                bnxt = bnx2;
+                bnx2 = bnext;
                 a0 = a0n, a1 = a1n;
                 ++kstep;
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
