@@ -159,3 +159,26 @@ def test_partitions_cover_everything_once():
         assert sorted(got) == pairs
         imgs = sum((parallel.partition_images(9, r, world) for r in range(world)), [])
         assert sorted(imgs) == list(range(9))
+
+
+def test_bench_flop_accounting_matches_survey():
+    """bench.py prices its TFLOP/s and rooflines with SURVEY.md section 8(a)/(d)'s algorithmic FLOP counts; pin them
+    to the figures quoted there (they are what `roofline.achieved` is computed from)."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("bench_for_test", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    # SuperPoint: 52.10 G @480x640, 177.85 G @1024x1024, 146.05 G @1135x760 (H x W = 760 x 1135 after the loader resize)
+    assert abs(bench.superpoint_flops(480, 640) / 1e9 - 52.10) < 0.01
+    assert abs(bench.superpoint_flops(1024, 1024) / 1e9 - 177.85) < 0.01
+    assert abs(bench.superpoint_flops(760, 1135) / 1e9 - 146.05) < 0.01
+    # SuperGlue dense FLOP per pair: 34.3 G @512, 88.2 G @1024, 254.8 G @2048, 1173.8 G @5000
+    for n, g in ((512, 34.3), (1024, 88.2), (2048, 254.8), (5000, 1173.8)):
+        assert abs(bench.matcher_flops("superglue", n, 18.0, 100) / 1e9 - g) < 0.06, n
+    # LightGlue, full depth (9 layers): 31.7 G @512, 80.5 G @1024, 229.8 G @2048, 1044.6 G @5000
+    for n, g in ((512, 31.7), (1024, 80.5), (2048, 229.8), (5000, 1044.6)):
+        assert abs(bench.matcher_flops("lightglue", n, 9.0, 0) / 1e9 - g) < 0.06, n
+    # early exit scales the per-layer term only
+    assert bench.matcher_flops("lightglue", 2048, 4.5, 0) < 0.51 * bench.matcher_flops("lightglue", 2048, 9.0, 0) + 1.2e9
