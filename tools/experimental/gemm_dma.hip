@@ -1,4 +1,6 @@
-// PROTOTYPE for round 2 (not part of libgtsfm_amd.so, never run on a GPU yet): fp32-MFMA GEMM C = A W^T + bias with BOTH
+// PROTOTYPE for round 2 (not part of libgtsfm_amd.so, first runs at the end of round 1: correct; 75.1 % / 81.0 % / 71.5 % of the fp32 MFMA peak on 131072 x 256->768 / 512->512 /
+// 256->256 (gemm_mfma_kernel: 72.2 / 77.2 / 70.5; vendor GEMM: 81.0 / 88.6 / 78.2) with nothing tuned but the XCD-aware
+// block order (+0.4) and raised priority outside the MFMA steps (+1)): fp32-MFMA GEMM C = A W^T + bias with BOTH
 // operands staged by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) into an XOR-swizzled
 // row-major LDS image, 128 x 128 x 32 stages, double-buffered, one barrier per stage. Motivation:
 // gemm_mfma_kernel sits at 70-77 % of the fp32 MFMA peak on the matcher's projection shapes where the vendor GEMM
@@ -43,7 +45,13 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(DmaGemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    // XCD-aware order (speed only): workgroup b runs on XCD b % 8; the column blocks of one row tile get consecutive
+    // slots of ONE XCD, so the A tile is fetched into one L2 and re-read there
+    const int ncb = p.N / 128, mtiles = (p.M + 127) / 128;
+    const int b = blockIdx.x, kx = b >> 3;
+    const int mt = (kx / ncb) * 8 + (b & 7), cb = kx % ncb;
+    if (mt >= mtiles) return;
+    const int m0 = mt * 128, n0 = cb * 128;
     const int j = lane & 31, kh = lane >> 5;
     const int nstages = p.K / KC;
 
@@ -85,7 +93,13 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(DmaGemmParams p) {
     for (int st = 0; st < nstages; ++st) {
         const float* sA = lds + (st & 1) * 2 * STAGE_FLOATS;
         const float* sW = sA + STAGE_FLOATS;
+#ifndef NO_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         if (st + 1 < nstages) stage_dma(st + 1, (st + 1) & 1);  // the other buffer was last read one stage ago
+#ifndef NO_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         const int ra = 64 * wm + j, rw = 64 * wn + j;
 #pragma unroll
         for (int s = 0; s < KC / 8; ++s) {
@@ -101,6 +115,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(DmaGemmParams p) {
 #undef GS
         }
         if (st + 1 < nstages) {
+#ifndef NO_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
             __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
             __syncthreads();
         }
@@ -134,7 +151,7 @@ int main(int argc, char** argv) {
     hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
     DmaGemmParams p{A, K, M, K, W, K, N, B, C, N};
-    const dim3 grid(N / 128, (M + 127) / 128);
+    const dim3 grid((((M + 127) / 128 + 7) / 8) * 8 * (N / 128));
     const size_t lds_bytes = (size_t)2 * 2 * STAGE_FLOATS * sizeof(float);  // 64 KiB: two workgroups per CU
     hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(256), lds_bytes, 0, p);
     if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
