@@ -1,6 +1,7 @@
 // PROTOTYPE for round 2 (not part of libgtsfm_amd.so, first runs at the end of round 1: correct; 75.1 % / 81.0 % / 71.5 % of the fp32 MFMA peak on 131072 x 256->768 / 512->512 /
 // 256->256 (gemm_mfma_kernel: 72.2 / 77.2 / 70.5; vendor GEMM: 81.0 / 88.6 / 78.2) with nothing tuned but the XCD-aware
-// block order (+0.4) and raised priority outside the MFMA steps (+1)): fp32-MFMA GEMM C = A W^T + bias with BOTH
+// block order (+0.4) and raised priority outside the MFMA steps (+1). -DTM256 (256 x 128 tile, 8 waves, one workgroup per
+// CU) measured 72.6 / 78.9 %: worse than two 128 x 128 workgroups per CU.): fp32-MFMA GEMM C = A W^T + bias with BOTH
 // operands staged by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) into an XOR-swizzled
 // row-major LDS image, 128 x 128 x 32 stages, double-buffered, one barrier per stage. Motivation:
 // gemm_mfma_kernel sits at 70-77 % of the fp32 MFMA peak on the matcher's projection shapes where the vendor GEMM
@@ -26,7 +27,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define KC 32                 // K depth of a stage
-#define STAGE_FLOATS (128 * KC)  // one operand of one stage
+#ifdef TM256                  // variant: 256 x 128 tile, 8 waves (4 x 2), one workgroup per CU: 6 DMA per wave and stage
+#define TM 256
+#define NWAVES 8
+#else
+#define TM 128
+#define NWAVES 4
+#endif
+#define A_FLOATS (TM * KC)
+#define W_FLOATS (128 * KC)
+#define STAGE_FLOATS (A_FLOATS + W_FLOATS)  // both operands of one stage
 
 struct DmaGemmParams {
     const float* A;  // [M][lda]
@@ -40,36 +50,37 @@ struct DmaGemmParams {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(DmaGemmParams p) {
+__global__ __launch_bounds__(NWAVES * 64, TM == 128 ? 2 : 1) void gemm_dma_kernel(DmaGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A 4096 | W 4096]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware order (speed only): workgroup b runs on XCD b % 8; the column blocks of one row tile get consecutive
     // slots of ONE XCD, so the A tile is fetched into one L2 and re-read there
-    const int ncb = p.N / 128, mtiles = (p.M + 127) / 128;
+    const int ncb = p.N / 128, mtiles = (p.M + TM - 1) / TM;
     const int b = blockIdx.x, kx = b >> 3;
     const int mt = (kx / ncb) * 8 + (b & 7), cb = kx % ncb;
     if (mt >= mtiles) return;
-    const int m0 = mt * 128, n0 = cb * 128;
+    const int m0 = mt * TM, n0 = cb * 128;
     const int j = lane & 31, kh = lane >> 5;
     const int nstages = p.K / KC;
 
     // DMA: a wave moves 4 instructions x 8 rows of A and of W per stage (rows 32 wave + 8 i + lane / 8)
     const int drow = lane >> 3, dpos = lane & 7;
     auto stage_dma = [&](int st, int buf) {
-        float* sA = lds + buf * 2 * STAGE_FLOATS;
-        float* sW = sA + STAGE_FLOATS;
+        float* sA = lds + buf * STAGE_FLOATS;
+        float* sW = sA + A_FLOATS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 32 * wave + 8 * i + drow;  // row of the 128-row stage; LDS position = r * 32 + dpos * 4 floats
-            const int c = swz(r, dpos);              // global chunk that belongs at this position
+        for (int i = 0; i < 4; ++i) {  // A: every wave moves 32 rows (4 instructions x 8 rows)
+            const int r = 32 * wave + 8 * i + drow;  // LDS position = r * 32 + dpos * 4 floats
             int ga = m0 + r;
-            ga = ga < p.M ? ga : p.M - 1;            // clamp: rows beyond M are computed and never stored
-            const float* srcA = p.A + (size_t)ga * p.lda + st * KC + c * 4;
-            const float* srcW = p.W + (size_t)(n0 + r) * p.ldw + st * KC + c * 4;
-            __builtin_amdgcn_global_load_lds(srcA, sA + (32 * wave + 8 * i) * KC, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(srcW, sW + (32 * wave + 8 * i) * KC, 16, 0, 0);
+            ga = ga < p.M ? ga : p.M - 1;  // clamp: rows beyond M are computed and never stored
+            __builtin_amdgcn_global_load_lds(p.A + (size_t)ga * p.lda + st * KC + swz(r, dpos) * 4, sA + (32 * wave + 8 * i) * KC, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 128 / (8 * NWAVES); ++i) {  // W: 128 rows over all waves
+            const int rb = (128 / NWAVES) * wave + 8 * i, r = rb + drow;
+            __builtin_amdgcn_global_load_lds(p.W + (size_t)(n0 + r) * p.ldw + st * KC + swz(r, dpos) * 4, sW + rb * KC, 16, 0, 0);
         }
     };
     auto frag = [&](const float* base, int row, int step) {  // 16-byte fragment: floats 8 step + 4 kh .. + 3 of `row`
@@ -91,8 +102,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(DmaGemmParams p) {
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA has landed ...
     __syncthreads();                     // ... and so has everybody else's
     for (int st = 0; st < nstages; ++st) {
-        const float* sA = lds + (st & 1) * 2 * STAGE_FLOATS;
-        const float* sW = sA + STAGE_FLOATS;
+        const float* sA = lds + (st & 1) * STAGE_FLOATS;
+        const float* sW = sA + A_FLOATS;
 #ifndef NO_PRIO
         __builtin_amdgcn_s_setprio(3);
 #endif
@@ -151,9 +162,9 @@ int main(int argc, char** argv) {
     hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
     DmaGemmParams p{A, K, M, K, W, K, N, B, C, N};
-    const dim3 grid((((M + 127) / 128 + 7) / 8) * 8 * (N / 128));
-    const size_t lds_bytes = (size_t)2 * 2 * STAGE_FLOATS * sizeof(float);  // 64 KiB: two workgroups per CU
-    hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(256), lds_bytes, 0, p);
+    const dim3 grid((((M + TM - 1) / TM + 7) / 8) * 8 * (N / 128));
+    const size_t lds_bytes = (size_t)2 * STAGE_FLOATS * sizeof(float);  // 64 KiB (two workgroups per CU) / 96 KiB (TM256)
+    hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(NWAVES * 64), lds_bytes, 0, p);
     if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
     hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
     double worst = 0;
@@ -169,10 +180,10 @@ int main(int argc, char** argv) {
     printf("self-check: max |error| over 4000 sampled entries = %.3e (%s)\n", worst, worst < 1e-4 ? "OK" : "FAILED");
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(256), lds_bytes, 0, p);  // warm clocks
+    for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(NWAVES * 64), lds_bytes, 0, p);  // warm clocks
     hipEventRecord(e0);
     const int reps = 20;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(256), lds_bytes, 0, p);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(NWAVES * 64), lds_bytes, 0, p);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
