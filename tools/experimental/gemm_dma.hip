@@ -1,13 +1,19 @@
-// PROTOTYPE for round 2 (not part of libgtsfm_amd.so; the full GemmParams contract -- ragged M / N from device memory, bias,
-// alpha, ReLU, residual, column offset, tile masks -- passes its fp64-checked feature sweep on an MI355X, first runs at the end of round 1: correct; 75.1 % / 81.0 % / 71.5 % of the fp32 MFMA peak on 131072 x 256->768 / 512->512 /
-// 256->256 (gemm_mfma_kernel: 72.2 / 77.2 / 70.5; vendor GEMM: 81.0 / 88.6 / 78.2) with nothing tuned but the XCD-aware
-// block order (+0.4) and raised priority outside the MFMA steps (+1). -DTM256 (256 x 128 tile, 8 waves, one workgroup per
-// CU) measured 72.6 / 78.9 %: worse than two 128 x 128 workgroups per CU.): fp32-MFMA GEMM C = A W^T + bias with BOTH
-// operands staged by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) into an XOR-swizzled
-// row-major LDS image, 128 x 128 x 32 stages, double-buffered, one barrier per stage. Motivation:
-// gemm_mfma_kernel sits at 70-77 % of the fp32 MFMA peak on the matcher's projection shapes where the vendor GEMM
-// reaches 78-89 %; its A rows travel global -> VGPR -> LDS, its weights are loaded per wave (every fragment twice per
-// workgroup), 24 vector-memory instructions per 128 MFMAs and wave. Here: 8 per 64 MFMAs, nothing loaded twice.
+// PROTOTYPE for round 2 -- not part of libgtsfm_amd.so.
+// fp32-MFMA GEMM C = res + act(alpha * (A W^T + bias)) with BOTH operands staged by LDS-DMA (global_load_lds_dwordx4: no
+// staging VGPRs, no ds_write pass) into an XOR-swizzled row-major LDS image, 128 x 128 x 32 stages, double-buffered,
+// one barrier per stage; the whole GemmParams contract of the shipped kernel (row / column counts from device memory,
+// bias, alpha, ReLU, residual, column offset, ragged-tile masks) with row-major weights.
+//
+// Motivation: gemm_mfma_kernel sits at 70-77 % of the fp32 MFMA peak on the matcher's projection
+// shapes where the vendor GEMM reaches 78-89 %; its A rows travel global -> VGPR -> LDS and its weights are loaded per
+// wave (every fragment twice per workgroup): 24 vector-memory instructions per 128 MFMAs and wave. Here: 8 per 64
+// MFMAs, nothing loaded twice.
+//
+// Status at the end of round 1 (MI355X): the fp64-checked feature sweep below is green; 131072 x 256->768 / 512->512 /
+// 256->256 run at 75.1 / 81.0 / 71.5 % of the peak in the bias-only form (73.7 % at 256->768 with the full contract
+// compiled in) against 72.2 / 77.2 / 70.5 % for gemm_mfma_kernel, with nothing tuned but the XCD-aware block order
+// (+0.4) and raised wave priority outside the MFMA steps (+1). -DTM256 (256 x 128 tile, 8 waves, one workgroup per CU)
+// measured 72.6 / 78.9 %: worse than two 128 x 128 workgroups per CU.
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/experimental/gemm_dma.hip -o tools/experimental/gemm_dma
 //   tools/experimental/gemm_dma [M K N]        self-check against a CPU fp64 reference on sampled entries, then timing
