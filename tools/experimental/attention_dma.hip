@@ -1,4 +1,6 @@
-// PROTOTYPE for round 2 -- not part of libgtsfm_amd.so; written at the end of round 1 and NOT YET RUN on a GPU.
+// PROTOTYPE for round 2 -- not part of libgtsfm_amd.so. Status at the end of round 1 (one run, in the round's last GPU
+// seconds): ragged self-check green (max error 4.8e-6), 84.8 % of the fp32 MFMA peak at 64 sequences x N = 2048 with TWO
+// workgroups per CU and nothing tuned (attention_mfma_kernel: 84.5 % with three).
 // fp32-MFMA flash attention (same contract and tiling as attention_mfma_kernel: head_dim 64, workgroup = 4 waves x 32
 // queries, 64-key tiles, transposed score tile S^T = K Q^T so that a query is a lane) with two structural changes that
 // the round-1 timeline asked for (per tile a wave has 8192 cycles of MFMA and ~4200 cycles of
