@@ -2,6 +2,8 @@
 # Round-2 opening moves on the GPU box (≈ 6 GPU-minutes): measure the two prototypes that ended round 1 green but untuned,
 # and gate the library integration of the LDS-DMA GEMM (git branch r2-gemm-dma) on the full parity suite.
 #   gpurun --timeout 900 -- 'bash tools/round2_first_steps.sh'
+# Branches prepared at the end of round 1: r2-gemm-dma (LDS-DMA GEMM in the library, row-major weights in the blobs, new entry
+# point gtsfm_linear_rowmajor_f32) and r2-sinkhorn (one hardware exponential per element in the Sinkhorn row sweep).
 # Run it from a checkout of r2-gemm-dma with the library built (python -m gtsfm_amd.csrc.build) to test the integration;
 # from main it only measures the prototypes.
 set -u
