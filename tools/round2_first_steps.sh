@@ -3,7 +3,8 @@
 # and gate the library integration of the LDS-DMA GEMM (git branch r2-gemm-dma) on the full parity suite.
 #   gpurun --timeout 900 -- 'bash tools/round2_first_steps.sh'
 # Branches prepared at the end of round 1: r2-gemm-dma (LDS-DMA GEMM in the library, row-major weights in the blobs, new entry
-# point gtsfm_linear_rowmajor_f32) and r2-sinkhorn (one hardware exponential per element in the Sinkhorn row sweep).
+# point gtsfm_linear_rowmajor_f32) r2-sinkhorn (one hardware exponential per element in the Sinkhorn row sweep) and r2-attention-dma (the attention
+# prototype inside the library, selected with GTSFM_ATTENTION=dma; default stays the shipped kernel).
 # Run it from a checkout of r2-gemm-dma with the library built (python -m gtsfm_amd.csrc.build) to test the integration;
 # from main it only measures the prototypes.
 set -u
@@ -17,4 +18,5 @@ timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee $OUT/pytest
 DBG_LIST=0 timeout 100 python tools/gpu_gemm_ablation.py | tee $OUT/gemm_library.txt
 GTSFM_GEMM=mfma DBG_LIST=0 timeout 100 python tools/gpu_gemm_ablation.py | sed 's/^/register-staged kernel: /' | tee -a $OUT/gemm_library.txt
 timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | tee $OUT/bench_lightglue.json | cut -c1-200
+GTSFM_ATTENTION=dma timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | sed 's/^/GTSFM_ATTENTION=dma (only on r2-attention-dma): /' | cut -c1-200
 timeout 300 python bench.py --matcher superglue --sinkhorn 100 --no-cpu-baseline 2>/dev/null | tail -1 | tee $OUT/bench_superglue100.json | cut -c1-200
