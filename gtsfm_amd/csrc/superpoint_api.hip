@@ -69,6 +69,20 @@ extern "C" int gtsfm_linear_f32(const float* a_dev, int lda, int m, const int32_
     return launch_gemm(p, (hipStream_t)stream);
 }
 
+extern "C" int gtsfm_linear_rowmajor_f32(const float* a_dev, int lda, int m, const int32_t* m_dev, int k, const float* w_dev, int ldw,
+                                         const float* bias_dev, int n, const int32_t* n_dev, float* c_dev, int ldc, int c_coff,
+                                         const float* res_dev, int ldres, float alpha, int relu, void* stream) {
+    GTSFM_CHECK_ARG(a_dev && w_dev && c_dev, "linear_rowmajor: null pointer");
+    GTSFM_CHECK_ARG(m >= 0 && n > 0, "linear_rowmajor: bad shape");
+    GTSFM_CHECK_ARG(gemm_uses_dma(k, ldw), "linear_rowmajor: needs k %% 32 == 0 and ldw %% 4 == 0 (got k = %d, ldw = %d)", k, ldw);
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = a_dev, p.lda = lda, p.M = m, p.K = k, p.m_dev = m_dev;
+    p.wraw = w_dev, p.ldw = ldw, p.n_dev = n_dev, p.bias = bias_dev, p.N = n;
+    p.C = c_dev, p.ldc = ldc, p.c_coff = c_coff, p.res = res_dev, p.ldres = ldres, p.alpha = alpha, p.relu = relu;
+    return launch_gemm(p, (hipStream_t)stream);
+}
+
 extern "C" int gtsfm_pack_rows_f32(const float* b_dev, int ldb, int n, const int32_t* n_dev, int k, float* packed_dev, void* stream) {
     GTSFM_CHECK_ARG(b_dev && packed_dev, "pack_rows: null pointer");
     return launch_pack_rows(b_dev, ldb, n, n_dev, k, packed_dev, (hipStream_t)stream);
