@@ -155,13 +155,21 @@ def measure_gemm_roofline(lib, device, rows: int, k: int, n: int, reps: int = 5)
     w = torch.randn(lib.gtsfm_packed_linear_floats(k, n), device=device) * 0.05
     bias = torch.zeros((n + 63) // 64 * 64, device=device)
     c = torch.empty((rows, n), device=device)
-    args = (a.data_ptr(), k, rows, None, k, w.data_ptr(), bias.data_ptr(), n, c.data_ptr(), n, 0, None, 0, 1.0, 0, stream.cuda_stream)
-    L.check(lib.gtsfm_linear_f32(*args), "linear")
+    # the matchers run their projections through the row-major (LDS-DMA) entry point when k % 32 == 0; GTSFM_GEMM=mfma
+    # measures the register-staged kernel instead
+    if k % 32 == 0 and os.environ.get("GTSFM_GEMM", "") != "mfma":
+        wr = torch.randn((n, k), device=device) * 0.05
+        fn = lib.gtsfm_linear_rowmajor_f32
+        args = (a.data_ptr(), k, rows, None, k, wr.data_ptr(), k, bias.data_ptr(), n, None, c.data_ptr(), n, 0, None, 0, 1.0, 0, stream.cuda_stream)
+    else:
+        fn = lib.gtsfm_linear_f32
+        args = (a.data_ptr(), k, rows, None, k, w.data_ptr(), bias.data_ptr(), n, c.data_ptr(), n, 0, None, 0, 1.0, 0, stream.cuda_stream)
+    L.check(fn(*args), "linear")
     torch.cuda.synchronize(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(reps):
-        L.check(lib.gtsfm_linear_f32(*args), "linear")
+        L.check(fn(*args), "linear")
     e1.record(stream)
     e1.synchronize()
     ms = e0.elapsed_time(e1) / reps

@@ -24,7 +24,10 @@ struct GemmParams {
     const float* A;  // [M][lda], first K columns are read
     int lda, M, K;
     const int* m_dev;  // optional: row count read from device memory (<= M)
-    const float* wpack;  // packed W[N][K] (pack_linear_weights / pack_rows)
+    const float* wpack;  // packed W[N][K] (pack_linear_weights / pack_rows); used when wraw is null or K % 32 != 0
+    const float* wraw;   // optional row-major W[N][ldw] (nn.Linear layout, or an activation matrix): LDS-DMA kernel
+    int ldw;
+    const int* n_dev;    // optional: column count read from device memory (<= N); LDS-DMA kernel only
     const float* bias;   // [ceil(N/64)*64] or null
     int N;
     float* C;  // [M][ldc], columns c_coff .. c_coff+N-1 are written
@@ -43,6 +46,7 @@ struct GemmParams {
 
 int launch_conv3x3(const ConvParams& p, hipStream_t stream);
 int launch_gemm(const GemmParams& p, hipStream_t stream);
+bool gemm_uses_dma(int K, int ldw);  // whether launch_gemm picks the LDS-DMA kernel for row-major weights of this shape
 int launch_pack_rows(const float* B, int ldb, int N, const int* n_dev, int K, float* out, hipStream_t stream);
 
 size_t packed_conv3x3_floats(int cin, int cout);

@@ -20,7 +20,8 @@
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight blobs: a sequence of entries, each 64-float aligned.
-//   kind 0 (linear): packed W[n][k_pad] (pack_linear_weights) followed by the bias padded to a multiple of 64
+//   kind 0 (linear): packed W[n][k_pad] (pack_linear_weights), the bias padded to a multiple of 64, then W once more
+//                    row-major [n][k_pad] for the LDS-DMA GEMM (k_pad = k rounded up to 8, zero-filled)
 //   kind 1 (raw)   : n floats copied verbatim
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -28,17 +29,18 @@ static size_t round64(size_t x) { return (x + 63) / 64 * 64; }
 static int kpad8(int k) { return (k + 7) / 8 * 8; }
 
 static size_t blob_entry_floats(int kind, int n, int k) {
-    if (kind == 0) return round64(packed_linear_floats(kpad8(k), n)) + round64(n);
+    if (kind == 0) return round64(packed_linear_floats(kpad8(k), n)) + round64(n) + round64((size_t)n * kpad8(k));
     return round64(n);
 }
 
 struct BlobCursor {
     const float* base;
     size_t off;
-    // linear entry -> (packed W, bias); advances
-    void linear(int n, int k, const float** w, const float** b) {
+    // linear entry -> (packed W, bias, row-major W); advances
+    void linear(int n, int k, const float** w, const float** b, const float** raw) {
         *w = base + off;
         *b = base + off + round64(packed_linear_floats(kpad8(k), n));
+        *raw = *b + round64(n);
         off += blob_entry_floats(0, n, k);
     }
     const float* raw(int n) {
@@ -65,7 +67,10 @@ extern "C" int gtsfm_pack_blob(int count, const int32_t* kinds, const int32_t* n
         if (kinds[i] == 0) {
             GTSFM_CHECK_ARG(n[i] > 0 && k[i] > 0, "pack_blob: entry %d has bad dims", i);
             pack_linear_weights(w[i], k[i], kpad8(k[i]), n[i], out + off);
-            if (b[i]) memcpy(out + off + round64(packed_linear_floats(kpad8(k[i]), n[i])), b[i], n[i] * sizeof(float));
+            float* bias_at = out + off + round64(packed_linear_floats(kpad8(k[i]), n[i]));
+            if (b[i]) memcpy(bias_at, b[i], n[i] * sizeof(float));
+            float* raw_at = bias_at + round64(n[i]);
+            for (int r = 0; r < n[i]; ++r) memcpy(raw_at + (size_t)r * kpad8(k[i]), w[i] + (size_t)r * k[i], k[i] * sizeof(float));
         } else {
             memcpy(out + off, w[i], n[i] * sizeof(float));
         }
@@ -293,11 +298,11 @@ extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_scor
 
     BlobCursor cur = {wts, 0};
     auto gemm = [&](const float* A, int lda, int K, int N, float* C, int ldc, int coff, const float* res, int ldres, int relu) -> int {
-        const float *w, *b;
-        cur.linear(N, K, &w, &b);
+        const float *w, *b, *raw;
+        cur.linear(N, K, &w, &b, &raw);
         GemmParams g;
         memset(&g, 0, sizeof(g));
-        g.A = A, g.lda = lda, g.M = T, g.K = kpad8(K), g.wpack = w, g.bias = b, g.N = N;
+        g.A = A, g.lda = lda, g.M = T, g.K = kpad8(K), g.wpack = w, g.wraw = raw, g.ldw = kpad8(K), g.bias = b, g.N = N;
         g.C = C, g.ldc = ldc, g.c_coff = coff, g.res = res, g.ldres = ldres, g.alpha = 1.0f, g.relu = relu;
         return launch_gemm(g, stream);
     };
@@ -330,10 +335,12 @@ extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_scor
         for (int p = 0; p < npairs; ++p) {
             const int r0 = row, r1 = row + n0[p];
             const int ld = z_ld(n1[p], 1);
-            TRY(launch_pack_rows(MD + (size_t)r1 * 256, 256, n1[p], nullptr, 256, PACK, stream));
+            const bool dma = gemm_uses_dma(256, 256);  // the LDS-DMA GEMM takes image 1's descriptor rows as they are
+            if (!dma) TRY(launch_pack_rows(MD + (size_t)r1 * 256, 256, n1[p], nullptr, 256, PACK, stream));
             GemmParams g;
             memset(&g, 0, sizeof(g));
             g.A = MD + (size_t)r0 * 256, g.lda = 256, g.M = n0[p], g.K = 256, g.wpack = PACK, g.bias = nullptr, g.N = n1[p];
+            if (dma) g.wraw = MD + (size_t)r1 * 256, g.ldw = 256;
             g.C = Z + zoff, g.ldc = ld, g.alpha = 0.0625f;
             TRY(launch_gemm(g, stream));
             zoff += (size_t)(n0[p] + 1) * ld;
@@ -476,11 +483,11 @@ extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* m
     // masked GEMM over the padded token rows; `cnt` selects which count array gates the tiles
     auto gemm = [&](const float* A, int lda, int K, int N, float* C, int ldc, int coff, const float* res, int ldres, float alpha,
                     const int* cnt) -> int {
-        const float *w, *b;
-        cur.linear(N, K, &w, &b);
+        const float *w, *b, *raw;
+        cur.linear(N, K, &w, &b, &raw);
         GemmParams g;
         memset(&g, 0, sizeof(g));
-        g.A = A, g.lda = lda, g.M = d.Tp, g.K = K, g.wpack = w, g.bias = b, g.N = N;
+        g.A = A, g.lda = lda, g.M = d.Tp, g.K = K, g.wpack = w, g.wraw = raw, g.ldw = K, g.bias = b, g.N = N;
         g.C = C, g.ldc = ldc, g.c_coff = coff, g.res = res, g.ldres = ldres, g.alpha = alpha, g.relu = 0;
         g.tile_cnt_idx = tile_idx, g.tile_row0 = tile_row0, g.live_counts = cnt;
         return launch_gemm(g, stream);
@@ -516,9 +523,9 @@ extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* m
         TRY(ffn(X));
 
         // adaptive depth / final assignment inputs
-        const float *w_fp, *b_fp;
+        const float *w_fp, *b_fp, *r_fp;
         size_t fp_off = cur.off;
-        cur.linear(256, 256, &w_fp, &b_fp);  // log_assignment[l].final_proj (consumed below through `gemm`)
+        cur.linear(256, 256, &w_fp, &b_fp, &r_fp);  // log_assignment[l].final_proj (consumed below through `gemm`)
         const float* w_match = cur.raw(256);
         const float* w_conf = (l < num_layers - 1) ? cur.raw(256) : nullptr;
         const float thr = (float)fmin(fmax(0.8 + 0.1 * exp(-4.0 * l / num_layers), 0.0), 1.0);
@@ -550,10 +557,12 @@ extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* m
         for (int p = 0; p < npairs; ++p) {
             const int r0 = row, r1 = row + cap128(n0[p]);
             const int ld = z_ld(n1[p], 0);
-            TRY(launch_pack_rows(MD + (size_t)r1 * 256, 256, n1[p], final_cnt + 2 * p + 1, 256, PACK, stream));
+            const bool dma = gemm_uses_dma(256, 256);
+            if (!dma) TRY(launch_pack_rows(MD + (size_t)r1 * 256, 256, n1[p], final_cnt + 2 * p + 1, 256, PACK, stream));
             GemmParams g;
             memset(&g, 0, sizeof(g));
             g.A = MD + (size_t)r0 * 256, g.lda = 256, g.M = n0[p], g.m_dev = final_cnt + 2 * p, g.K = 256, g.wpack = PACK, g.N = n1[p];
+            if (dma) g.wraw = MD + (size_t)r1 * 256, g.ldw = 256, g.n_dev = final_cnt + 2 * p + 1;
             g.C = Z + zoff, g.ldc = ld, g.alpha = 1.0f;
             TRY(launch_gemm(g, stream));
             zoff += (size_t)n0[p] * ld;

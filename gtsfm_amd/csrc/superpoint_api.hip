@@ -69,6 +69,20 @@ extern "C" int gtsfm_linear_f32(const float* a_dev, int lda, int m, const int32_
     return launch_gemm(p, (hipStream_t)stream);
 }
 
+extern "C" int gtsfm_linear_rowmajor_f32(const float* a_dev, int lda, int m, const int32_t* m_dev, int k, const float* w_dev, int ldw,
+                                         const float* bias_dev, int n, const int32_t* n_dev, float* c_dev, int ldc, int c_coff,
+                                         const float* res_dev, int ldres, float alpha, int relu, void* stream) {
+    GTSFM_CHECK_ARG(a_dev && w_dev && c_dev, "linear_rowmajor: null pointer");
+    GTSFM_CHECK_ARG(m >= 0 && n > 0, "linear_rowmajor: bad shape");
+    GTSFM_CHECK_ARG(gemm_uses_dma(k, ldw), "linear_rowmajor: needs k %% 32 == 0 and ldw %% 4 == 0 (got k = %d, ldw = %d)", k, ldw);
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = a_dev, p.lda = lda, p.M = m, p.K = k, p.m_dev = m_dev;
+    p.wraw = w_dev, p.ldw = ldw, p.n_dev = n_dev, p.bias = bias_dev, p.N = n;
+    p.C = c_dev, p.ldc = ldc, p.c_coff = c_coff, p.res = res_dev, p.ldres = ldres, p.alpha = alpha, p.relu = relu;
+    return launch_gemm(p, (hipStream_t)stream);
+}
+
 extern "C" int gtsfm_pack_rows_f32(const float* b_dev, int ldb, int n, const int32_t* n_dev, int k, float* packed_dev, void* stream) {
     GTSFM_CHECK_ARG(b_dev && packed_dev, "pack_rows: null pointer");
     return launch_pack_rows(b_dev, ldb, n, n_dev, k, packed_dev, (hipStream_t)stream);
@@ -94,6 +108,7 @@ struct SpBlob {
     size_t w[8], b[8];  // index by layer id for conv1b..conv4b (L1B..L4B)
     size_t wPD, bPD;    // convPa | convDa fused: 128 -> 512
     size_t wPb, bPb, wDb, bDb;
+    size_t rPb, rDb;    // convPb / convDb weights once more, row-major [cout][256], for the LDS-DMA GEMM
     size_t total;
 };
 
@@ -119,6 +134,8 @@ SpBlob sp_blob_layout() {
     L.bPb = take(pad64(65));
     L.wDb = take(packed_linear_floats(256, 256));
     L.bDb = take(256);
+    L.rPb = take(65 * 256);
+    L.rDb = take(256 * 256);
     L.total = o;
     return L;
 }
@@ -153,6 +170,8 @@ extern "C" int gtsfm_sp_pack_weights(const float* const* t, float* out) {
     memcpy(out + L.bPb, t[2 * LPB + 1], 65 * sizeof(float));
     pack_linear_weights(t[2 * LDB], 256, 256, 256, out + L.wDb);
     memcpy(out + L.bDb, t[2 * LDB + 1], 256 * sizeof(float));
+    memcpy(out + L.rPb, t[2 * LPB], (size_t)65 * 256 * sizeof(float));   // [65][256][1][1] is already row-major
+    memcpy(out + L.rDb, t[2 * LDB], (size_t)256 * 256 * sizeof(float));
     return GTSFM_OK;
 }
 
@@ -329,14 +348,14 @@ extern "C" int gtsfm_sp_forward(const float* wts, const void* image_dev, int ima
     {  // convPb: 1x1, 256 -> 65
         GemmParams g;
         memset(&g, 0, sizeof(g));
-        g.A = p0, g.lda = 512, g.M = cells, g.K = 256, g.wpack = wts + L.wPb, g.bias = wts + L.bPb, g.N = 65;
+        g.A = p0, g.lda = 512, g.M = cells, g.K = 256, g.wpack = wts + L.wPb, g.wraw = wts + L.rPb, g.ldw = 256, g.bias = wts + L.bPb, g.N = 65;
         g.C = logits, g.ldc = 65, g.alpha = 1.0f;
         SP_TRY(launch_gemm(g, stream));
     }
     {  // convDb: 1x1, 256 -> 256
         GemmParams g;
         memset(&g, 0, sizeof(g));
-        g.A = p0 + 256, g.lda = 512, g.M = cells, g.K = 256, g.wpack = wts + L.wDb, g.bias = wts + L.bDb, g.N = 256;
+        g.A = p0 + 256, g.lda = 512, g.M = cells, g.K = 256, g.wpack = wts + L.wDb, g.wraw = wts + L.rDb, g.ldw = 256, g.bias = wts + L.bDb, g.N = 256;
         g.C = dense, g.ldc = 256, g.alpha = 1.0f;
         SP_TRY(launch_gemm(g, stream));
     }

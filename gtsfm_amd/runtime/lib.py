@@ -41,6 +41,11 @@ SIGNATURES = {
         [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
          C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p],
     ),
+    "gtsfm_linear_rowmajor_f32": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+         C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p],
+    ),
     "gtsfm_pack_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gtsfm_sp_packed_weight_floats": (C.c_size_t, []),
     "gtsfm_sp_pack_weights": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),

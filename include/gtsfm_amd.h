@@ -68,6 +68,13 @@ int gtsfm_linear_f32(const float* a_dev, int lda, int m, const int32_t* m_dev, i
                      const float* bias_dev, int n, float* c_dev, int ldc, int c_coff, const float* res_dev, int ldres,
                      float alpha, int relu, void* stream);
 
+/* Same operation with the weights (or a second activation matrix) given row-major, W[n][ldw] as nn.Linear stores them:
+ * both operands then travel by LDS-DMA (k % 32 == 0 and ldw % 4 == 0 required). n_dev (optional): column count in
+ * device memory (<= n).                                                        same reference lines as gtsfm_linear_f32 */
+int gtsfm_linear_rowmajor_f32(const float* a_dev, int lda, int m, const int32_t* m_dev, int k, const float* w_dev, int ldw,
+                              const float* bias_dev, int n, const int32_t* n_dev, float* c_dev, int ldc, int c_coff,
+                              const float* res_dev, int ldres, float alpha, int relu, void* stream);
+
 /* Pack a device activation matrix B[n][k] (row stride ldb) as the "weight" operand of gtsfm_linear_f32, so that
  * A B^T products of two activation matrices (score matrices, SG:257) use the same kernel. */
 int gtsfm_pack_rows_f32(const float* b_dev, int ldb, int n, const int32_t* n_dev, int k, float* packed_dev, void* stream);

@@ -66,4 +66,6 @@ def test_superpoint_weight_packing(built_library):
     np.testing.assert_array_equal(blob[: 9 * 64].reshape(9, 64), sd["conv1a.weight"].numpy().reshape(64, 9).T)
     # total parameter mass is preserved (padding is zero)
     total = sum(float(v.double().abs().sum()) for v in sd.values())
+    # the two 1x1 convolutions are stored twice: packed for the register-staged GEMM and row-major for the LDS-DMA GEMM
+    total += sum(float(sd[k].double().abs().sum()) for k in ("convPb.weight", "convDb.weight"))
     assert abs(float(np.abs(blob.astype(np.float64)).sum()) - total) < 1e-6 * total

@@ -145,6 +145,35 @@ def test_linear_matches_aten(lib, gpu_device, m, k, n, relu, res):
     assert float((got[:, 2 : n + 2] - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("m,k,n,relu,res,m_live,n_live", [(300, 256, 65, 0, 0, 300, 65), (129, 256, 256, 1, 0, 129, 256), (1, 512, 256, 0, 1, 1, 256),
+                                                          (700, 32, 64, 1, 1, 700, 64), (513, 64, 200, 0, 0, 400, 200), (260, 256, 300, 0, 0, 260, 257)])
+def test_linear_rowmajor_matches_aten(lib, gpu_device, m, k, n, relu, res, m_live, n_live):
+    """The LDS-DMA GEMM (row-major weights; the matchers' projections and score products): same contract as
+    gtsfm_linear_f32, plus the device-side column count used after LightGlue's point pruning."""
+    gen = torch.Generator().manual_seed(m + k + n)
+    a = torch.randn((m, k), generator=gen)
+    w = torch.randn((n, k), generator=gen) / k**0.5
+    b = torch.randn((n,), generator=gen)
+    r = torch.randn((m, n), generator=gen)
+    ref = F.linear(a, w, b) * 0.5
+    if relu:
+        ref = F.relu(ref)
+    if res:
+        ref = r + ref
+    ad, wd, rd = a.to(gpu_device), w.to(gpu_device), r.to(gpu_device)
+    out = torch.full((m, n + 3), -5.0, device=gpu_device)  # ldc = n + 3 and c_coff = 2: scalar stores
+    bp = _pad64(b, gpu_device)
+    md = torch.tensor([m_live], dtype=torch.int32, device=gpu_device)
+    nd = torch.tensor([n_live], dtype=torch.int32, device=gpu_device)
+    _check(lib, lib.gtsfm_linear_rowmajor_f32(ad.data_ptr(), k, m, md.data_ptr() if m_live < m else None, k, wd.data_ptr(), k, bp.data_ptr(), n,
+                                              nd.data_ptr() if n_live < n else None, out.data_ptr(), n + 3, 2, rd.data_ptr() if res else None, n,
+                                              0.5, relu, _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert torch.all(got[:, :2] == -5.0) and torch.all(got[:, n_live + 2 :] == -5.0) and torch.all(got[m_live:] == -5.0)
+    assert float((got[:m_live, 2 : n_live + 2] - ref[:m_live, :n_live]).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_linear_with_packed_activation_operand(lib, gpu_device):
     """A B^T of two activation matrices through pack_rows (score GEMM, superglue.py:257-258)."""
     a, b = torch.randn((150, 256)), torch.randn((90, 256))
