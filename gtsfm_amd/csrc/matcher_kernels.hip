@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__
     // The workgroup's R rows are staged ONCE into LDS (coalesced 16-byte loads, all in flight together); the row
     // log-sum-exp (phase A) and the column partials (phase B) both run out of LDS, so Z is read from HBM exactly once
     // per Sinkhorn iteration.
-    extern __shared__ __attribute__((aligned(16))) float zs[];  // [R][ld] + u[R]
+    extern __shared__ __attribute__((aligned(16))) float zs[];  // [R][ld] + v[ld] + c[R]
     const int p = blockIdx.y;
     const PairDesc pd = pairs[p];
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__
     const float norm = SG ? -logf((float)m + (float)n) : 0.f;
     const float NEG = neg_inf();
     float* v_s = zs + (size_t)R * ld;  // staged column vector (SuperGlue's v)
-    float* u_s = v_s + ld;
+    float* c_s = v_s + ld;  // per-row exponent offsets of the e values (phase A -> phase B)
     if (SG)
         for (int j = threadIdx.x * 4; j < cols; j += 1024) *reinterpret_cast<f32x4*>(v_s + j) = *reinterpret_cast<const f32x4*>(colvec + vec1 + j);
     // stage: the nr rows are contiguous in memory (row stride ld), nr * ld4 float4 in total
@@ -249,10 +249,15 @@ __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__
         }
     }
     __syncthreads();
-    // phase A: wave w reduces rows w, w+4, ... (two passes over LDS: max, then sum of exp -- as torch.logsumexp does)
+    // phase A: wave w reduces rows w, w+4, ... : row maximum, then e_ij = exp(z_ij + v_j - mx_i) written back IN PLACE
+    // (LDS copy only) and summed. One hardware exponential (v_exp_f32 on a pre-scaled argument) per element; the column
+    // pass below reuses e_ij instead of exponentiating again:
+    //     exp(z_ij + u_i) = e_ij * exp(-v_j) * exp(c_i),   c_i = u_i + mx_i        (SuperGlue; LightGlue: c_i = mx_i, v = 0)
+    // (round 1 spent two library expf per element here and was VALU-bound)
+    constexpr float LOG2E = 1.44269504088896340736f;
     for (int rr = wave; rr < nr; rr += 4) {
         const int i = r0 + rr;
-        const float* zr = zs + (size_t)rr * ld;
+        float* zr = zs + (size_t)rr * ld;
         float mx = NEG;
 #pragma unroll 4
         for (int j = lane * 4; j < cols; j += 256) {
@@ -269,10 +274,13 @@ __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__
         for (int j = lane * 4; j < cols; j += 256) {
             f32x4 z = *reinterpret_cast<const f32x4*>(zr + j);
             if (SG) z = z + *reinterpret_cast<const f32x4*>(v_s + j);
-            sum += expf(z.x - mx);
-            if (j + 1 < cols) sum += expf(z.y - mx);
-            if (j + 2 < cols) sum += expf(z.z - mx);
-            if (j + 3 < cols) sum += expf(z.w - mx);
+            f32x4 e;
+            e.x = __builtin_amdgcn_exp2f((z.x - mx) * LOG2E);
+            e.y = (j + 1 < cols) ? __builtin_amdgcn_exp2f((z.y - mx) * LOG2E) : 0.f;
+            e.z = (j + 2 < cols) ? __builtin_amdgcn_exp2f((z.z - mx) * LOG2E) : 0.f;
+            e.w = (j + 3 < cols) ? __builtin_amdgcn_exp2f((z.w - mx) * LOG2E) : 0.f;
+            sum += (e.x + e.y) + (e.z + e.w);
+            *reinterpret_cast<f32x4*>(zr + j) = e;
         }
         sum = wave_sum(sum);
         const float lse = logf(sum) + mx;
@@ -285,34 +293,25 @@ __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__
         }
         if (lane == 0) {
             rowvec[vec0 + i] = ui;
-            u_s[rr] = ui;
+            c_s[rr] = SG ? ui + mx : mx;
         }
     }
     __syncthreads();
-    // phase B: column partials (max, sum) of Z + u over this block's rows, 4 columns per thread, from LDS
+    // phase B: column partials of this block's rows as (M_b, sum_i e_ij exp(c_i - M_b)), M_b = max_i c_i: the same
+    // (max, sum) pairs lse_cols_kernel combines; SuperGlue's exp(-v_j) factor is applied there
+    float mb = NEG;
+    for (int rr = 0; rr < nr; ++rr) mb = fmaxf(mb, c_s[rr]);
     float* part = partials + pd.part_off + (size_t)blockIdx.x * ld * 2;
     for (int j = threadIdx.x * 4; j < cols; j += 1024) {
-        f32x4 mx = {NEG, NEG, NEG, NEG};
-        for (int rr = 0; rr < nr; ++rr) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(zs + (size_t)rr * ld + j);
-            if (SG) {
-                const float u = u_s[rr];
-                v.x += u, v.y += u, v.z += u, v.w += u;
-            }
-            mx.x = fmaxf(mx.x, v.x), mx.y = fmaxf(mx.y, v.y), mx.z = fmaxf(mx.z, v.z), mx.w = fmaxf(mx.w, v.w);
-        }
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         for (int rr = 0; rr < nr; ++rr) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(zs + (size_t)rr * ld + j);
-            if (SG) {
-                const float u = u_s[rr];
-                v.x += u, v.y += u, v.z += u, v.w += u;
-            }
-            sum.x += expf(v.x - mx.x), sum.y += expf(v.y - mx.y), sum.z += expf(v.z - mx.z), sum.w += expf(v.w - mx.w);
+            const f32x4 e = *reinterpret_cast<const f32x4*>(zs + (size_t)rr * ld + j);
+            const float w = __builtin_amdgcn_exp2f((c_s[rr] - mb) * LOG2E);
+            sum.x = fmaf(e.x, w, sum.x), sum.y = fmaf(e.y, w, sum.y), sum.z = fmaf(e.z, w, sum.z), sum.w = fmaf(e.w, w, sum.w);
         }
         // columns beyond `cols` (row padding) produce garbage partials that are never read
-        *reinterpret_cast<f32x4*>(part + (size_t)j * 2) = f32x4{mx.x, sum.x, mx.y, sum.y};
-        *reinterpret_cast<f32x4*>(part + (size_t)j * 2 + 4) = f32x4{mx.z, sum.z, mx.w, sum.w};
+        *reinterpret_cast<f32x4*>(part + (size_t)j * 2) = f32x4{mb, sum.x, mb, sum.y};
+        *reinterpret_cast<f32x4*>(part + (size_t)j * 2 + 4) = f32x4{mb, sum.z, mb, sum.w};
     }
 }
 
@@ -354,12 +353,14 @@ __global__ __launch_bounds__(256) void lse_cols_kernel(const PairDesc* __restric
         if (nm != neg_inf()) sum = sum * expf(mx - nm) + os * expf(om - nm);
         mx = nm;
     }
-    const float lse = logf(sum) + mx;
+    // the partial sums carry exp(v_j) (SuperGlue): log sum_i exp(z_ij + u_i) = log(sum) + mx - v_j. A column whose terms
+    // all underflowed (> 87 below their rows' maxima) gets the smallest normal number instead of log(0).
+    const float lse = logf(fmaxf(sum, 1.17549435e-38f)) + mx;
     const int vec1 = vec_off(s1, 2 * p + 1);
     if (SG) {
         const float norm = -logf((float)m + (float)n);
         const float log_nu = (j < n) ? norm : logf((float)m) + norm;
-        colvec[vec1 + j] = log_nu - lse;
+        colvec[vec1 + j] = log_nu - (lse - colvec[vec1 + j]);
     } else {
         colvec[vec1 + j] = lse;
     }
