@@ -1,15 +1,25 @@
 """Benchmark of the MI355X deep front-end (BASELINE.json: image-pairs/sec, detect+match @1024 px).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 re-launches itself, one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W               (the driver's form; RANK / WORLD_SIZE come from the env)
 
-One "step" = one pass of the hot path over one batch of synthetic input resident in HBM: ``--images`` seeded
-1024x1024 gray images are detected + described (SuperPoint) and all ``images*(images-1)/2`` exhaustive pairs are
-matched (``--matcher``). Every rank processes its own batch (weak scaling, no data-path collective: images and pairs
-are independent units); weights are packed on rank 0 and broadcast over RCCL. Rank 0 prints
-ONE JSON line with the whole-job rate, the roofline of the dominant kernel (measured live with HIP events on the
-launch stream) and a CPU baseline (the oracle, timed on a bounded sample of the same workload).
+One "step" = one pass of the hot path over one batch of synthetic input resident in HBM.
+
+``--mode replica`` (default; BASELINE config 3): every rank owns ``--images`` seeded 1024x1024 gray views, detects +
+describes them (SuperPoint) and matches the first ``--pairs`` exhaustive (i<j) pairs (``--matcher``). Weak scaling, no
+data-path collective (images and pairs are independent units); the packed weights are broadcast
+from rank 0 over RCCL.
+
+``--mode scene`` (BASELINE config 4): ONE scene of ``--images`` (101) views / ``--pairs`` (5000) exhaustive pairs is
+sharded over the ranks: cyclic image ownership for detection, one RCCL all-gather of the feature table, 2-D
+block-cyclic pair ownership for matching (SuperGlue, 100 Sinkhorn iterations by default), ragged gather of the match
+lists. Strong scaling: ``value`` = the scene's pairs / max-over-ranks time.
+
+Rank 0 prints ONE JSON line: the whole-job rate, the roofline of the dominant kernel (measured live with HIP events
+on the launch stream), at N = 1 a CPU baseline (the oracle, timed on a bounded sample of the same workload), a
+``parity_check`` of the GPU result against that oracle run on the same two images, and ``secondary`` rates (GTSfM's
+5000-keypoint cap; independent pairs).
 """
 
 from __future__ import annotations
@@ -17,6 +27,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -30,7 +42,12 @@ sys.path.insert(0, str(REPO))
 from gtsfm_amd.utils import synthetic  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0          # same guide: HBM3E spec peak (6.3 TB/s is what a streaming copy reaches)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Work formulas
+# ------------------------------------------------------------------------------------------------------------------
 
 
 def superpoint_conv3x3_layers(h: int, w: int):
@@ -52,18 +69,45 @@ def superpoint_flops(h: int, w: int) -> float:
     return float(total)
 
 
+def matcher_flops(matcher: str, n: int, layers: float, sinkhorn: int) -> float:
+    """SURVEY.md section 8(d) per-pair dense FLOP (N = M keypoints)."""
+    if matcher == "superglue":
+        return 2 * 217280 * n + 36 * (1310720 * n + 1024 * n * n) + 262144 * n + 512 * n * n
+    return layers * 2 * (2490368 * n + 1792 * n * n) + 262144 * n + 512 * n * n
+
+
 def pmc_traffic(kernel: str):
     """HBM bytes per launch measured with rocprofv3 PMC passes and committed under profiles/ (bench.py cannot collect
-    counters itself); None when the file is missing."""
-    path = REPO / "profiles" / "r01_pmc_traffic.json"
-    try:
-        return json.loads(path.read_text()).get(kernel)
-    except (OSError, ValueError):
-        return None
+    counters itself); None when no file holds the kernel."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            entry = json.loads((REPO / "profiles" / name).read_text()).get(kernel)
+        except (OSError, ValueError):
+            entry = None
+        if entry is not None:
+            return dict(entry, source=f"profiles/{name}")
+    return None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Per-kernel rooflines, measured live with HIP events on the launch stream
+# ------------------------------------------------------------------------------------------------------------------
+
+
+def _time_launches(fn, stream, reps: int) -> float:
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def measure_conv_roofline(lib, device, batch: int, h: int, w: int, reps: int = 5):
-    """Times the dominant kernel (conv3x3_mfma_kernel) launch by launch with HIP events on the launch stream."""
+    """conv3x3_mfma_kernel launch by launch over the SuperPoint stack."""
     from gtsfm_amd.runtime import lib as L
 
     stream = torch.cuda.current_stream(device)
@@ -76,39 +120,25 @@ def measure_conv_roofline(lib, device, batch: int, h: int, w: int, reps: int = 5
         bias = torch.zeros((cout + 63) // 64 * 64, device=device)
         args = (x.data_ptr(), cin, 0, y.data_ptr(), cout, 0, wp.data_ptr(), bias.data_ptr(), batch, hh, ww, cin, cout, 1, pool,
                 stream.cuda_stream)
-        L.check(lib.gtsfm_conv3x3_f32(*args), "conv3x3")
-        torch.cuda.synchronize(device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(reps):
-            L.check(lib.gtsfm_conv3x3_f32(*args), "conv3x3")
-        e1.record(stream)
-        e1.synchronize()
-        total_ms += e0.elapsed_time(e1) / reps
+        total_ms += _time_launches(lambda: L.check(lib.gtsfm_conv3x3_f32(*args), "conv3x3"), stream, reps)
         total_flops += 2.0 * 9 * cin * cout * hh * ww * batch
         launches += 1
         del x, y, wp
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     t = pmc_traffic("conv3x3_mfma_kernel") if (h, w) == (1024, 1024) else None
     return {
-        "bound": "mfma",
-        "kernel": "conv3x3_mfma_kernel",
-        "achieved": round(achieved, 2),
-        "peak": FP32_MFMA_PEAK_TFLOPS,
-        "unit": "TFLOP/s",
+        "bound": "mfma", "kernel": "conv3x3_mfma_kernel", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
         "traffic": None if t is None else (t["fetch_bytes_per_image"] + t["write_bytes_per_image"]) * batch,
-        "traffic_note": None if t is None else "HBM bytes per launch (avg over the 8 launches), rocprofv3 PMC, profiles/r01_pmc_traffic.json",
-        "launches_per_step": launches,
-        "avg_launch_ms": round(total_ms / launches, 4),
-        "flops_per_step": total_flops,
+        "traffic_note": None if t is None else f"HBM bytes per launch (avg over the 8 launches), rocprofv3 PMC, {t['source']}",
+        "launches_per_step": launches, "avg_launch_ms": round(total_ms / launches, 4), "flops_per_step": total_flops,
     }
 
 
 def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5):
-    """Dominant kernel of the detect+match workload (attention_mfma_kernel, ~50 % of GPU time): one launch = the self
-    attention of `npairs` pairs (2 sequences x 4 heads each) at N = n, timed with HIP events on the launch stream.
-    Algorithmic work: 1024 * N^2 FLOP per sequence per layer."""
+    """Dominant kernel of the detect+match workload (~50 % of GPU time): one launch = the self attention of `npairs`
+    pairs (2 sequences x 4 heads each) at N = n. Algorithmic work: 1024 * N^2 FLOP per sequence per layer (SURVEY.md
+    section 8a rows a23 / a36)."""
     from gtsfm_amd.runtime import lib as L
 
     stream = torch.cuda.current_stream(device)
@@ -119,128 +149,189 @@ def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5):
     counts = torch.full((nseq,), n, dtype=torch.int32, device=device)
     args = (qkv.data_ptr(), 768, qkv.data_ptr() + 256 * 4, 768, qkv.data_ptr() + 512 * 4, 768, out.data_ptr(), 256, probs.data_ptr(),
             counts.data_ptr(), nseq, n, 4, 0.125, stream.cuda_stream)
-    L.check(lib.gtsfm_attention_f32(*args), "attention")
-    torch.cuda.synchronize(device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(reps):
-        L.check(lib.gtsfm_attention_f32(*args), "attention")
-    e1.record(stream)
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ms = _time_launches(lambda: L.check(lib.gtsfm_attention_f32(*args), "attention"), stream, reps)
     flops = 1024.0 * n * n * nseq
     achieved = flops / (ms * 1e-3) / 1e12
     t = pmc_traffic("attention_mfma_kernel") if (n, nseq) == (2048, 64) else None
     return {
-        "bound": "mfma",
-        "kernel": "attention_mfma_kernel",
-        "achieved": round(achieved, 2),
-        "peak": FP32_MFMA_PEAK_TFLOPS,
-        "unit": "TFLOP/s",
+        "bound": "mfma", "kernel": "attention_mfma_kernel", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
         "traffic": None if t is None else t["fetch_bytes"] + t["write_bytes"],
-        "traffic_note": None if t is None else "HBM bytes per launch, rocprofv3 PMC, profiles/r01_pmc_traffic.json",
-        "avg_launch_ms": round(ms, 4),
-        "flops_per_launch": flops,
+        "traffic_note": None if t is None else f"HBM bytes per launch, rocprofv3 PMC, {t['source']}",
+        "avg_launch_ms": round(ms, 4), "flops_per_launch": flops,
         "launch_shape": f"{nseq} sequences x 4 heads, N = {n} queries = keys, head_dim 64",
     }
 
 
 def measure_gemm_roofline(lib, device, rows: int, k: int, n: int, reps: int = 5):
-    """gemm_mfma_kernel at one of the matcher's projection shapes (rows x k -> n)."""
+    """The matchers' projection GEMM at one of their shapes (rows x k -> n), row-major weights (LDS-DMA kernel)."""
     from gtsfm_amd.runtime import lib as L
 
     stream = torch.cuda.current_stream(device)
     a = torch.randn((rows, k), device=device)
-    w = torch.randn(lib.gtsfm_packed_linear_floats(k, n), device=device) * 0.05
+    w = torch.randn((n, k), device=device) * 0.05
     bias = torch.zeros((n + 63) // 64 * 64, device=device)
     c = torch.empty((rows, n), device=device)
-    # the matchers run their projections through the row-major (LDS-DMA) entry point when k % 32 == 0; GTSFM_GEMM=mfma
-    # measures the register-staged kernel instead
-    if k % 32 == 0 and os.environ.get("GTSFM_GEMM", "") != "mfma":
-        wr = torch.randn((n, k), device=device) * 0.05
-        fn = lib.gtsfm_linear_rowmajor_f32
-        args = (a.data_ptr(), k, rows, None, k, wr.data_ptr(), k, bias.data_ptr(), n, None, c.data_ptr(), n, 0, None, 0, 1.0, 0, stream.cuda_stream)
-    else:
-        fn = lib.gtsfm_linear_f32
-        args = (a.data_ptr(), k, rows, None, k, w.data_ptr(), bias.data_ptr(), n, c.data_ptr(), n, 0, None, 0, 1.0, 0, stream.cuda_stream)
-    L.check(fn(*args), "linear")
-    torch.cuda.synchronize(device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(reps):
-        L.check(fn(*args), "linear")
-    e1.record(stream)
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    args = (a.data_ptr(), k, rows, None, k, w.data_ptr(), k, bias.data_ptr(), n, None, c.data_ptr(), n, 0, None, 0, 1.0, 0, stream.cuda_stream)
+    ms = _time_launches(lambda: L.check(lib.gtsfm_linear_rowmajor_f32(*args), "linear_rowmajor"), stream, reps)
     achieved = 2.0 * rows * k * n / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_mfma_kernel", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 4), "launch_shape": f"{rows} x {k} -> {n}"}
+    t = pmc_traffic(f"gemm_dma_kernel_{k}x{n}") if rows == 131072 else None
+    return {
+        "bound": "mfma", "kernel": "gemm_dma_kernel", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 4), "launch_shape": f"{rows} x {k} -> {n}",
+        "algorithmic_bytes": 4 * (rows * k + n * k + rows * n),
+        "traffic": None if t is None else t["fetch_bytes"] + t["write_bytes"],
+        "traffic_note": None if t is None else f"HBM bytes per launch, rocprofv3 PMC, {t['source']}",
+    }
 
 
-def cpu_baseline(h: int, w: int, n_images: int, matcher: str, n_keypoints: int, sinkhorn_iters: int):
+def measure_sinkhorn_roofline(lib, device, n: int, npairs: int, iters: int = 20):
+    """One Sinkhorn iteration (row sweep + column combine) over the (N+1) x (N+1) couplings matrices of `npairs` pairs.
+    HBM-bound: algorithmic bytes = one read of Z per iteration = 4 (N+1)^2 B per pair (SURVEY.md section 8a row a29:
+    8 (N+1)^2 unfused)."""
+    from gtsfm_amd.runtime import lib as L
+
+    if not hasattr(lib, "gtsfm_sinkhorn_f32"):
+        return None
+    stream = torch.cuda.current_stream(device)
+    ld = (n + 1 + 3) // 4 * 4
+    z = torch.randn((npairs, n + 1, ld), device=device)
+    m = torch.full((npairs,), n, dtype=torch.int32)
+    ws = torch.empty(int(lib.gtsfm_sinkhorn_workspace_bytes(npairs, m.data_ptr(), m.data_ptr())), dtype=torch.uint8, device=device)
+    u = torch.empty((npairs, n + 1), device=device)
+    v = torch.empty((npairs, n + 1), device=device)
+
+    def run(it):
+        L.check(lib.gtsfm_sinkhorn_f32(z.data_ptr(), npairs, m.data_ptr(), m.data_ptr(), 1.0, it, ws.data_ptr(), ws.numel(), u.data_ptr(),
+                                       v.data_ptr(), stream.cuda_stream), "sinkhorn")
+
+    t1 = _time_launches(lambda: run(iters), stream, 3)
+    t2 = _time_launches(lambda: run(2 * iters), stream, 3)
+    ms_iter = (t2 - t1) / iters  # the fixed part (dustbin fill, descriptor upload) cancels
+    bytes_iter = 4.0 * (n + 1) * (n + 1) * npairs
+    achieved = bytes_iter / (ms_iter * 1e-3) / 1e9
+    t = pmc_traffic("sinkhorn_rows_kernel") if (n, npairs) == (2048, 32) else None
+    return {
+        "bound": "hbm", "kernel": "sinkhorn_rows_kernel + sinkhorn_cols_kernel (one iteration)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_iteration_ms": round(ms_iter, 4), "algorithmic_bytes": bytes_iter,
+        "launch_shape": f"{npairs} pairs, ({n}+1) x ({n}+1) couplings", "traffic": None if t is None else t["fetch_bytes"] + t["write_bytes"],
+        "traffic_note": None if t is None else f"HBM bytes per iteration, rocprofv3 PMC, {t['source']}",
+    }
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle) and the parity check of the timed workload against it
+# ------------------------------------------------------------------------------------------------------------------
+
+
+def cpu_baseline(views: np.ndarray, matcher: str, n_keypoints: int, sinkhorn_iters: int):
     """The oracle (kind "port": restatement of the reference's torch CPU path, bit-exact with it in the build
-    container) on a bounded sample: ``n_images`` detections and one pair match, on all host cores."""
+    container) on a bounded sample: the two views of the workload's first pair are detected and matched once, on the
+    host cores. Returns (baseline dict, oracle outputs for parity_check)."""
     from oracle import superpoint_oracle
 
     cores = min(os.cpu_count() or 1, int(os.environ.get("GTSFM_CPU_BASELINE_THREADS", "16")))
     torch.set_num_threads(cores)
+    h, w = views.shape[1:]
     sd = synthetic.synthetic_superpoint_state_dict()
-    t_det = []
-    feats = []
-    for i in range(n_images):
-        gray = synthetic.synthetic_gray_image(h, w, 1000 + i)
+    t_det, feats = [], []
+    for gray in views:
         t0 = time.perf_counter()
-        c, s, d = superpoint_oracle.detect_and_describe(sd, gray, max_keypoints=n_keypoints)
+        c, s, d = superpoint_oracle.detect_and_describe(sd, gray, max_keypoints=1 << 30)  # the model's full row-major list
+        sel = synthetic.topk_detection_order(s, n_keypoints)  # top-k by response, kept in detection order
         t_det.append(time.perf_counter() - t0)
-        feats.append((c, s, d))
+        feats.append((c[sel], s[sel], d[sel]))
     det_s = float(np.median(t_det))
     out = {"detect_s_per_image": round(det_s, 3), "cores": cores, "kind": "port"}
+    oracle_out = {"features": feats}
     if matcher == "none":
-        out.update(value=round(1.0 / det_s, 4), unit="images/s", sample=f"{n_images} x SuperPoint {h}x{w} (oracle, fp32)")
-        return out
-    (c0, s0, d0), (c1, s1, d1) = feats[0], feats[1]
+        out.update(value=round(1.0 / det_s, 4), unit="images/s", sample=f"{len(views)} x SuperPoint {h}x{w} (oracle, fp32)")
+        return out, oracle_out
+    (c0, s0, d0), (c1, s1, d1) = feats
+    T = torch.from_numpy
     t0 = time.perf_counter()
-    if matcher == "superglue":
-        from oracle import superglue_oracle
+    with torch.no_grad():
+        if matcher == "superglue":
+            from oracle import superglue_oracle
 
-        sg = synthetic.synthetic_superglue_state_dict()
-        superglue_oracle.match(sg, c0, c1, s0, s1, d0, d1, (h, w, 1), (h, w, 1), sinkhorn_iterations=sinkhorn_iters)
-    else:
-        from oracle import lightglue_oracle
+            sg = synthetic.synthetic_superglue_state_dict()
+            res = superglue_oracle.superglue_forward(sg, T(c0)[None], T(c1)[None], T(s0)[None], T(s1)[None], T(d0).T[None].contiguous(),
+                                                     T(d1).T[None].contiguous(), (h, w), (h, w), sinkhorn_iterations=sinkhorn_iters)
+        else:
+            from oracle import lightglue_oracle
 
-        lg = synthetic.synthetic_lightglue_state_dict()
-        lightglue_oracle.match(lg, c0, c1, d0, d1, (h, w, 1), (h, w, 1))
+            lg = synthetic.synthetic_lightglue_state_dict()
+            res = lightglue_oracle.lightglue_forward(lg, T(c0)[None], T(c1)[None], T(d0)[None], T(d1)[None], (h, w), (h, w), return_intermediates=True)
     match_s = time.perf_counter() - t0
+    oracle_out.update(matches0=res["matches0"][0].numpy(), matching_scores0=res["matching_scores0"][0].numpy())
     # independent-pair cost on the CPU path: 2 detections + 1 match
     out.update(
-        match_s_per_pair=round(match_s, 3),
-        value=round(1.0 / (2 * det_s + match_s), 4),
-        unit="image-pairs/s",
-        sample=f"{n_images} x SuperPoint {h}x{w} + 1 x {matcher} pair at N={len(c0)},{len(c1)} (oracle, fp32); "
-        "rate = 1 / (2 detect + 1 match)",
+        match_s_per_pair=round(match_s, 3), value=round(1.0 / (2 * det_s + match_s), 4), unit="image-pairs/s",
+        sample=f"2 x SuperPoint {h}x{w} + 1 x {matcher} pair at N={len(c0)},{len(c1)} (oracle, fp32); rate = 1 / (2 detect + 1 match)",
     )
+    return out, oracle_out
+
+
+def parity_check(oracle_out, gpu_feats, gpu_rows, gpu_match):
+    """GPU result of the timed workload vs the oracle on the SAME two images (the first pair of the step): keypoints
+    bit-exact, scores / descriptors / match scores within 1e-4, match indices bit-exact."""
+    out = {}
+    kp_equal, dscore, ddesc = True, 0.0, 0.0
+    for (c, s, d), row in zip(oracle_out["features"], gpu_rows):
+        k = int(gpu_feats["count"][row])
+        xy = gpu_feats["xy"][row, :k].cpu().numpy()
+        same = xy.shape == c.shape and bool(np.array_equal(xy, c))
+        kp_equal &= same
+        if same:
+            dscore = max(dscore, float(np.abs(gpu_feats["scores"][row, :k].cpu().numpy() - s).max()))
+            ddesc = max(ddesc, float(np.abs(gpu_feats["descriptors"][row, :k].cpu().numpy() - d).max()))
+    out.update(keypoints_equal=bool(kp_equal), keypoints=[len(f[0]) for f in oracle_out["features"]],
+               max_dscore_keypoints=dscore, max_ddescriptor=ddesc)
+    if gpu_match is not None and "matches0" in oracle_out:
+        m0, ms0 = gpu_match
+        ref = oracle_out["matches0"]
+        equal = m0.shape == ref.shape and bool(np.array_equal(m0.astype(np.int64), ref.astype(np.int64)))
+        out.update(matches_equal=equal, matches=int((ref > -1).sum()),
+                   max_dscore=float(np.abs(ms0 - oracle_out["matching_scores0"]).max()) if equal else None)
+        out["within_tolerance"] = bool(kp_equal and equal and dscore < 1e-4 and ddesc < 1e-4 and out["max_dscore"] < 1e-4)
+    else:
+        out["within_tolerance"] = bool(kp_equal and dscore < 1e-4 and ddesc < 1e-4)
     return out
 
 
-def matcher_flops(matcher: str, n: int, layers: float, sinkhorn: int) -> float:
-    """SURVEY.md section 8(d) per-pair dense FLOP (N = M keypoints)."""
-    if matcher == "superglue":
-        return 2 * 217280 * n + 36 * (1310720 * n + 1024 * n * n) + 262144 * n + 512 * n * n
-    return layers * 2 * (2490368 * n + 1792 * n * n) + 262144 * n + 512 * n * n
+# ------------------------------------------------------------------------------------------------------------------
+# Launch plumbing
+# ------------------------------------------------------------------------------------------------------------------
 
 
-def main() -> None:
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relaunch_one_process_per_gpu(gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) and hand their output through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--images", type=int, default=46, help="images per rank per step (46 -> 1035 exhaustive pairs, first --pairs kept)")
-    ap.add_argument("--pairs", type=int, default=1000, help="exhaustive (i<j) pairs matched per rank per step")
+    ap.add_argument("--mode", choices=["replica", "scene"], default="replica",
+                    help="replica: every rank owns its own image set / pair list (BASELINE config 3, weak scaling); scene: one scene "
+                         "sharded over the ranks (BASELINE config 4, strong scaling)")
+    ap.add_argument("--images", type=int, default=None, help="images per step: per rank (replica, default 46 -> 1035 exhaustive pairs) or of the scene (default 101)")
+    ap.add_argument("--pairs", type=int, default=None, help="exhaustive (i<j) pairs matched per step: per rank (replica, default 1000) or of the scene (default 5000)")
     ap.add_argument("--size", type=int, default=1024, help="square image side (overridden by --height / --width)")
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--width", type=int, default=0)
-    ap.add_argument("--matcher", choices=["none", "lightglue", "superglue"], default="lightglue")
+    ap.add_argument("--matcher", choices=["none", "lightglue", "superglue"], default=None, help="default: lightglue (replica), superglue (scene)")
     ap.add_argument("--keypoints", type=int, default=2048, help="keypoints kept per image (device top-k by response)")
     ap.add_argument("--sinkhorn", type=int, default=100, help="SuperGlue Sinkhorn iterations (GTSfM runs 20; BASELINE config 4 asks for 100)")
     ap.add_argument("--pair-definition", choices=["exhaustive", "independent"], default="exhaustive",
@@ -249,82 +340,173 @@ def main() -> None:
     ap.add_argument("--pair-chunk", type=int, default=32)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the pair chunks alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates (cap 5000; independent pairs)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help='"nccl" = RCCL; "gloo" only with --plumbing-only')
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="no GPU work: random features / matches stand in for the kernels so that the launcher, partitioning, collectives "
+                         "and timing protocol can be exercised on CPU (gloo); the printed line is marked and is NOT a measurement")
+    args = ap.parse_args(argv)
+    scene = args.mode == "scene"
+    args.images = args.images if args.images is not None else (101 if scene else 46)
+    args.pairs = args.pairs if args.pairs is not None else (5000 if scene else 1000)
+    args.matcher = args.matcher if args.matcher is not None else ("superglue" if scene else "lightglue")
+    if scene and args.matcher == "none":
+        ap.error("--mode scene needs a matcher")
+    if scene and args.pair_definition != "exhaustive":
+        ap.error("--mode scene matches the exhaustive pairs of one scene")
+    if args.plumbing_only:
+        args.backend = "gloo"
+    return args
 
+
+class _FakePipeline:
+    """--plumbing-only stand-in for FrontEndPipeline: random features, synthetic match lists (CPU tensors)."""
+
+    def __init__(self, k: int):
+        self.k = k
+
+    def detect(self, images):
+        n = images.shape[0]
+        g = torch.Generator().manual_seed(int(images[:, 0, 0].sum()) + n)
+        return {"count": torch.full((n,), self.k, dtype=torch.int32), "xy": torch.rand((n, self.k, 2), generator=g),
+                "scores": torch.rand((n, self.k), generator=g), "descriptors": torch.rand((n, self.k, 256), generator=g)}
+
+    def match(self, feats, pairs, shapes, counts=None, **kw):
+        res = []
+        for c0 in range(0, len(pairs), 32):
+            chunk = list(pairs[c0 : c0 + 32])
+            m = torch.full((len(chunk) * 2 * self.k,), -1, dtype=torch.int32)
+            for q, (i, j) in enumerate(chunk):  # keypoint t of image i <-> keypoint t of image j for t < (i + j) % k
+                t = torch.arange((i + j) % self.k, dtype=torch.int32)
+                m[q * 2 * self.k : q * 2 * self.k + len(t)] = t
+                m[q * 2 * self.k + self.k : q * 2 * self.k + self.k + len(t)] = t
+            res.append({"matches": m, "mscores": torch.zeros(m.shape), "pairs": chunk, "n0": [self.k] * len(chunk), "n1": [self.k] * len(chunk)})
+        return res
+
+
+def matches_to_numpy(results):
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+
+    return FrontEndPipeline.matches_to_numpy(results)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+
+
+def main() -> None:
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_one_process_per_gpu(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X visible to PyTorch-ROCm (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    plumbing = args.plumbing_only
+    if plumbing:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X visible to PyTorch-ROCm (no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     dist = None
     # GTSFM_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, weight broadcast, barrier, max-reduce) on one GPU
     if world > 1 or os.environ.get("GTSFM_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if plumbing:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=device)
 
     from gtsfm_amd import parallel
-    from gtsfm_amd.runtime import lib as L
-    from gtsfm_amd.runtime import matcher_engine as ME
-    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
-    from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine, pack_superpoint_weights
-
-    lib = L.load()
-    # weights: packed once on rank 0, broadcast over RCCL (xGMI)
-    packed = None
-    if rank == 0:
-        packed = torch.from_numpy(pack_superpoint_weights(synthetic.synthetic_superpoint_state_dict())).to(device)
-    detector = SuperPointEngine.from_packed(parallel.broadcast_packed_weights(packed, int(lib.gtsfm_sp_packed_weight_floats()), device))
-    matcher = None
-    if args.matcher == "superglue":
-        matcher = ME.SuperGlueEngine(synthetic.synthetic_superglue_state_dict(), device)
-    elif args.matcher == "lightglue":
-        matcher = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(), device)
-    if matcher is not None and dist is not None:
-        blob = matcher.weights if rank == 0 else None
-        matcher.weights = parallel.broadcast_packed_weights(blob, matcher.weights.numel(), device)
 
     h = args.height or args.size
     w = args.width or args.size
+    scene = args.mode == "scene"
+    lib = detector = matcher = None
+    if plumbing:
+        pipe = _FakePipeline(min(args.keypoints, 32))
+    else:
+        from gtsfm_amd.runtime import lib as L
+        from gtsfm_amd.runtime import matcher_engine as ME
+        from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+        from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine, pack_superpoint_weights
+
+        lib = L.load()
+        # weights: packed once on rank 0, broadcast over RCCL (xGMI)
+        packed = None
+        if rank == 0:
+            packed = torch.from_numpy(pack_superpoint_weights(synthetic.synthetic_superpoint_state_dict())).to(device)
+        detector = SuperPointEngine.from_packed(parallel.broadcast_packed_weights(packed, int(lib.gtsfm_sp_packed_weight_floats()), device))
+        if args.matcher == "superglue":
+            matcher = ME.SuperGlueEngine(synthetic.synthetic_superglue_state_dict(), device)
+        elif args.matcher == "lightglue":
+            matcher = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(), device)
+        if matcher is not None and dist is not None:
+            blob = matcher.weights if rank == 0 else None
+            matcher.weights = parallel.broadcast_packed_weights(blob, matcher.weights.numel(), device)
+        pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams)
+    have_matcher = args.matcher != "none"
+    mk = {"sinkhorn_iterations": args.sinkhorn} if (args.matcher == "superglue" and not plumbing) else {}
+
     n = args.images
-    # overlapping views: every image is a crop of one seeded canvas, shifted by multiples of the 8-px SuperPoint cell, so
-    # that exhaustive pairs share content (non-trivial match lists) while every image is still detected independently
-    canvas = synthetic.synthetic_gray_image(h + 8 * n, w + 8 * n, 1000 + rank)
-    imgs = np.stack([canvas[8 * i : 8 * i + h, 8 * ((7 * i) % n) : 8 * ((7 * i) % n) + w] for i in range(n)])
-    images = torch.from_numpy(imgs).to(device)  # inputs resident in HBM before the timed region
-    pairs = parallel.exhaustive_pairs(n)[: args.pairs] if matcher is not None else []
-    independent = args.pair_definition == "independent" and matcher is not None
-    if independent:
-        # 2 P image slots, every slot detected afresh each step (slot s shows view (5 s) % n; nothing is cached or shared
-        # between slots), pair p = slots (2p, 2p + 1)
-        slots = torch.arange(2 * args.pairs, device=device)
-        images = images[(5 * slots) % n].contiguous()
-        n = 2 * args.pairs
-        pairs = [(2 * p, 2 * p + 1) for p in range(args.pairs)]
-    pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams)
-    shapes = [(h, w)] * n
-    mk = {"sinkhorn_iterations": args.sinkhorn} if args.matcher == "superglue" else {}
+    # overlapping views of one seeded canvas: exhaustive pairs share content (true correspondences) while every view is
+    # detected independently. Replica mode: every rank has its own canvas; scene mode: one canvas for the job.
+    if plumbing:
+        views_np = np.random.default_rng(1000 + (0 if scene else rank)).integers(0, 256, (n, 8, 8)).astype(np.uint8)
+    else:
+        views_np = synthetic.synthetic_overlapping_views(n, h, w, 1000 + (0 if scene else rank))
+    independent = args.pair_definition == "independent" and have_matcher
+    my_images = list(range(n))
+    if scene:
+        all_pairs = parallel.exhaustive_pairs(n)[: args.pairs]
+        my_images = parallel.partition_images(n, rank, world)
+        my_pairs = parallel.partition_pairs_2d(all_pairs, rank, world)
+        images = torch.from_numpy(views_np[my_images]).to(device)  # this rank's views, resident before the timed region
+        pairs = [(parallel.table_index(i, n, world), parallel.table_index(j, n, world)) for i, j in my_pairs]
+        shapes = [(h, w)] * (world * (-(-n // world)))
+    else:
+        images = torch.from_numpy(views_np).to(device)  # inputs resident in HBM before the timed region
+        all_pairs = my_pairs = pairs = parallel.exhaustive_pairs(n)[: args.pairs] if have_matcher else []
+        if independent:
+            # 2 P image slots, every slot detected afresh each step (slot s shows view (5 s) % n; nothing is cached or shared
+            # between slots), pair p = slots (2p, 2p + 1)
+            slots = torch.arange(2 * args.pairs, device=device)
+            images = images[(5 * slots) % n].contiguous()
+            n = 2 * args.pairs
+            all_pairs = my_pairs = pairs = [(2 * p, 2 * p + 1) for p in range(args.pairs)]
+        shapes = [(h, w)] * n
 
     def step():
         feats = pipe.detect(images)
-        res = pipe.match(feats, pairs, shapes, **mk) if matcher is not None else []
-        return feats, res
+        gathered = None
+        if scene:
+            feats = parallel.all_gather_feature_table(feats, args.images)  # RCCL all-gather: the one exchange step of the path
+            counts = feats["count"].cpu().numpy()
+            res = pipe.match(feats, pairs, shapes, counts=counts, **mk)
+            local = matches_to_numpy(res)
+            gathered = parallel.gather_matches({my: local[t] for my, t in zip(my_pairs, pairs)}, device)
+        else:
+            res = pipe.match(feats, pairs, shapes, **mk) if have_matcher else []
+        return feats, res, gathered
 
     def sync():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        if not plumbing:
+            torch.cuda.synchronize(device)
 
+    feats = res = gathered = None
     for _ in range(args.warmup):
-        feats, res = step()
+        feats, res, gathered = step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        feats, res = step()
+        feats, res, gathered = step()
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -332,15 +514,44 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    detect_only = matcher is None
-    units_per_step = (n if detect_only else len(pairs)) * world
+    detect_only = not have_matcher
+    if scene:
+        units_per_step = len(all_pairs)
+        assert gathered is not None and sorted(gathered) == sorted(all_pairs), "the gathered match lists do not cover the scene's pairs"
+    else:
+        units_per_step = (n if detect_only else len(pairs)) * world
     value = units_per_step / (ms_per_step * 1e-3)
 
     if rank == 0:
         kcount = feats["count"].tolist()
-        layers = float(torch.cat([r["stop"] for r in res]).float().mean()) if args.matcher == "lightglue" else 18.0
+        if scene:
+            kcount = [int(feats["count"][parallel.table_index(i, args.images, world)]) for i in range(args.images)]
         nmatch = int(sum(int((r["matches"] > -1).sum()) for r in res)) // 2 if res else 0
-        flops_step = superpoint_flops(h, w) * n + (matcher_flops(args.matcher, args.keypoints, layers, args.sinkhorn) * len(pairs) if res else 0)
+        layers, kept_frac = 18.0, 1.0
+        if args.matcher == "lightglue" and not plumbing and res:
+            layers = float(torch.cat([r["stop"] for r in res]).float().mean())
+            kept_frac = float(torch.cat([r["kept"] for r in res]).float().mean()) / max(1, args.keypoints)
+        n_img_total = args.images if scene else n * world
+        flops_step = superpoint_flops(h, w) * n_img_total
+        if res:
+            flops_step += matcher_flops(args.matcher, args.keypoints, layers, args.sinkhorn) * units_per_step
+        if detect_only:
+            workload = f"SuperPoint-only: {n} synthetic {h}x{w} gray images per GPU per step"
+        elif scene:
+            workload = (f"SuperPoint+{args.matcher}, ONE scene sharded over {world} GPU(s): {len(all_pairs)} exhaustive (i<j) pairs of {args.images} "
+                        f"synthetic {h}x{w} gray images per step (cyclic image ownership, RCCL feature all-gather, 2-D block-cyclic pair ownership, "
+                        f"match lists gathered), top-{args.keypoints} keypoints per image")
+        elif independent:
+            workload = (f"SuperPoint+{args.matcher}: {len(pairs)} independent pairs = {n} fresh detections of synthetic {h}x{w} gray images per GPU "
+                        f"per step, top-{args.keypoints} keypoints per image")
+        else:
+            workload = (f"SuperPoint+{args.matcher}: {len(pairs)} exhaustive (i<j) pairs of {n} synthetic {h}x{w} gray images per GPU per step "
+                        f"(each image detected once per step), top-{args.keypoints} keypoints per image")
+        if scene:
+            par = (f"scene sharded over {world} rank(s) on a {'x'.join(map(str, parallel.process_grid(world)))} process grid; rank 0 matches "
+                   f"{len(my_pairs)} pairs touching {len(parallel.images_touched(my_pairs))} of {args.images} images")
+        else:
+            par = f"dp{world}: independent image sets / pair lists per rank, RCCL weight broadcast, no data-path collective"
         result = {
             "metric": f"images/sec (SuperPoint detect+describe) @{h}x{w}" if detect_only else f"image-pairs/sec (detect+match) @{max(h, w)}px",
             "value": round(value, 2),
@@ -350,47 +561,109 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if scene else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (
-                    f"SuperPoint-only: {n} synthetic {h}x{w} gray images per GPU per step" if detect_only else
-                    f"SuperPoint+{args.matcher}: {len(pairs)} independent pairs = {n} fresh detections of synthetic {h}x{w} gray images per GPU "
-                    f"per step, top-{args.keypoints} keypoints per image" if independent else
-                    f"SuperPoint+{args.matcher}: {len(pairs)} exhaustive (i<j) pairs of {n} synthetic {h}x{w} gray images per GPU per step "
-                    f"(each image detected once per step), top-{args.keypoints} keypoints per image"
-                ),
+                "workload": workload,
+                "mode": args.mode,
                 "pair_definition": args.pair_definition if not detect_only else None,
-                "images_per_gpu_per_step": n,
-                "pairs_per_gpu_per_step": len(pairs),
+                "images_per_gpu_per_step": len(my_images) if scene else n,
+                "pairs_per_gpu_per_step": len(my_pairs),
                 "keypoints_per_image": [int(min(kcount)), int(max(kcount))],
                 "matcher_layers_run": layers,
                 "sinkhorn_iterations": args.sinkhorn if args.matcher == "superglue" else None,
                 "matches_per_pair": round(nmatch / max(1, len(pairs)), 1),
                 "weights": "seeded synthetic (gtsfm_amd.utils.synthetic)",
-                "parallelism": f"dp{world}: independent image sets / pair lists per rank, RCCL weight broadcast, no data-path collective",
+                "parallelism": par,
                 "pair_chunk": args.pair_chunk,
                 "streams": args.streams,
             },
-            "tflops": round(flops_step * world / (ms_per_step * 1e-3) / 1e12, 2),
+            "tflops": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2),
         }
-        conv_roof = measure_conv_roofline(lib, device, min(n, 16), h, w)
-        if detect_only:
-            result["roofline"] = conv_roof
-        else:  # dominant kernel of this workload first; the other two MFMA kernels alongside
-            result["roofline"] = measure_attention_roofline(lib, device, args.keypoints, min(args.pair_chunk, max(1, len(pairs))))
-            result["roofline_other"] = [
-                measure_gemm_roofline(lib, device, 2 * min(args.pair_chunk, max(1, len(pairs))) * args.keypoints, 256, 768),
-                conv_roof,
-            ]
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
-            result["cpu_baseline"] = cpu_baseline(h, w, 2, args.matcher, args.keypoints, args.sinkhorn)
+        if kept_frac < 1.0:
+            result["tflops_note"] = (f"upper bound: counted at full width N = {args.keypoints} in every layer; point pruning left "
+                                     f"{kept_frac:.3f} of the keypoints alive at the final assignment")
+        if plumbing:
+            result["plumbing_only"] = True
+            result["data"] = "NONE (plumbing only: no kernels ran, not a measurement)"
+        else:
+            conv_roof = measure_conv_roofline(lib, device, min(16, len(views_np)), h, w)
+            if detect_only:
+                result["roofline"] = conv_roof
+            else:  # dominant kernel of this workload first; the other kernels alongside
+                chunk_pairs = min(args.pair_chunk, max(1, len(pairs)))
+                result["roofline"] = measure_attention_roofline(lib, device, args.keypoints, chunk_pairs)
+                rows = 2 * chunk_pairs * args.keypoints
+                other = [measure_gemm_roofline(lib, device, rows, k, nn) for k, nn in ((256, 768), (512, 512), (512, 256))]
+                if args.matcher == "superglue":
+                    other.append(measure_sinkhorn_roofline(lib, device, args.keypoints, chunk_pairs))
+                result["roofline_other"] = [r for r in other if r is not None] + [conv_roof]
+            if world == 1 and not args.no_secondary and not detect_only and not scene and args.pair_definition == "exhaustive":
+                result["secondary"] = secondary_rates(args, detector, matcher, device, h, w, mk)
+            if world == 1 and not args.no_cpu_baseline:  # rank 0 at N = 1 only
+                first = all_pairs[0] if all_pairs else (0, min(1, len(views_np) - 1))
+                view_of = (lambda s: (5 * s) % args.images) if independent else (lambda s: s)  # noqa: E731
+                sample_views = np.stack([views_np[view_of(first[0])], views_np[view_of(first[1])]])
+                base, ora = cpu_baseline(sample_views, args.matcher, args.keypoints, args.sinkhorn)
+                result["cpu_baseline"] = base
+                gpu_match = None
+                if res:
+                    a = res[0]["n0"][0]
+                    gpu_match = (res[0]["matches"][:a].cpu().numpy(), res[0]["mscores"][:a].cpu().numpy())
+                rows_ = [pairs[0][0], pairs[0][1]] if pairs else [0, min(1, n - 1)]
+                result["parity_check"] = parity_check(ora, feats, rows_, gpu_match)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def secondary_rates(args, detector, matcher, device, h, w, mk):
+    """The two rates SURVEY.md section 8(d) asks for next to the headline, each with its own timed region (N = 1):
+    exhaustive pairs at GTSfM's default cap of 5000 keypoints (gtsfm/configs/deep_front_end.yaml:29) and independent
+    pairs (two fresh detections per pair) at the headline's cap."""
+    from gtsfm_amd import parallel
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+
+    out = {}
+
+    def timed(pipe, images, pairs, shapes, steps, warmup):
+        def step():
+            feats = pipe.detect(images)
+            return feats, pipe.match(feats, pairs, shapes, **mk)
+
+        for _ in range(warmup):
+            feats, res = step()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            feats, res = step()
+        torch.cuda.synchronize(device)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        kc = feats["count"].tolist()
+        nm = int(sum(int((r["matches"] > -1).sum()) for r in res)) // 2
+        return {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+                "pairs_per_step": len(pairs), "images_per_step": int(images.shape[0]), "keypoints_per_image": [int(min(kc)), int(max(kc))],
+                "matches_per_pair": round(nm / max(1, len(pairs)), 1)}
+
+    # (1) GTSfM's cap: 21 views -> 210 exhaustive pairs, first 200; top-5000 keypoints per image
+    views = torch.from_numpy(synthetic.synthetic_overlapping_views(21, h, w, 2000)).to(device)
+    pairs = parallel.exhaustive_pairs(21)[:200]
+    pipe = FrontEndPipeline(detector, matcher, max_keypoints=5000, pair_chunk=8, num_streams=args.streams)
+    out["exhaustive_cap5000"] = dict(timed(pipe, views, pairs, [(h, w)] * 21, 2, 1), workload=(
+        f"SuperPoint+{args.matcher}: 200 exhaustive pairs of 21 synthetic {h}x{w} views, top-5000 keypoints per image (GTSfM's default cap)"))
+    del pipe, views
+    # (2) independent pairs: 2 fresh detections per pair, nothing shared between pairs
+    base = torch.from_numpy(synthetic.synthetic_overlapping_views(46, h, w, 1000)).to(device)
+    p = 500
+    images = base[(5 * torch.arange(2 * p, device=device)) % 46].contiguous()
+    pairs = [(2 * q, 2 * q + 1) for q in range(p)]
+    pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams)
+    out["independent_pairs"] = dict(timed(pipe, images, pairs, [(h, w)] * (2 * p), 1, 1), workload=(
+        f"SuperPoint+{args.matcher}: {p} independent pairs = {2 * p} fresh detections of synthetic {h}x{w} views, top-{args.keypoints} keypoints per image"))
+    return out
 
 
 if __name__ == "__main__":

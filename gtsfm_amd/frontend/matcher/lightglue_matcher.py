@@ -6,7 +6,8 @@ responses, output = ``matches["matches"]`` as a (K, 2) ``int64`` array in image-
 
 The reference obtains the model from the un-vendored ``thirdparty/LightGlue`` submodule, which also downloads the
 ``superpoint_lightglue`` checkpoint; offline, ``weights_path`` (extension over the reference signature) points at an
-upstream-format ``state_dict``. LightGlue parity is UNPINNED: the HIP path is checked against
+upstream-format ``state_dict`` -- either key layout: the published file's ``self_attn.{i}.*`` / ``cross_attn.{i}.*`` or
+the in-memory ``transformers.{i}.*`` names (``normalize_lightglue_state_dict``). LightGlue parity is UNPINNED: the HIP path is checked against
 ``oracle/lightglue_oracle.py``, a restatement of the published algorithm.
 """
 
@@ -21,7 +22,17 @@ from gtsfm_amd.common.keypoints import Keypoints
 from gtsfm_amd.frontend.matcher.matcher_base import MatcherBase
 
 ROOT_PATH = Path(__file__).resolve().parent.parent.parent.parent
+# Upstream LightGlue fetches "superpoint_lightglue.pth" (release v0.1_arxiv) into the torch.hub checkpoint cache under
+# the name below; a copy next to the (un-vendored) submodule is looked up first.
+HUB_FILE_NAME = "superpoint_lightglue_v0-1_arxiv.pth"
 DEFAULT_WEIGHTS = {"superpoint": ROOT_PATH / "thirdparty" / "LightGlue" / "weights" / "superpoint_lightglue.pth"}
+
+
+def _default_weight_candidates(features: str):
+    import os
+
+    hub = Path(os.environ.get("TORCH_HOME", Path.home() / ".cache" / "torch")) / "hub" / "checkpoints"
+    return [DEFAULT_WEIGHTS[features], hub / HUB_FILE_NAME.replace("superpoint", features)]
 
 
 class LightGlueMatcher(MatcherBase):
@@ -49,9 +60,10 @@ class LightGlueMatcher(MatcherBase):
                 raise ValueError(f"gtsfm_amd's LightGlueMatcher supports features='superpoint' only (got {self._features!r}).")
             if not self._use_cuda:
                 raise RuntimeError("gtsfm_amd's LightGlueMatcher runs on the GPU only (use_cuda=False requested).")
-            path = Path(self._weights_path) if self._weights_path is not None else DEFAULT_WEIGHTS[self._features]
-            if not path.exists():
-                raise FileNotFoundError(f"LightGlue weights not found at {path}.")
+            candidates = [Path(self._weights_path)] if self._weights_path is not None else _default_weight_candidates(self._features)
+            path = next((c for c in candidates if c.exists()), None)
+            if path is None:
+                raise FileNotFoundError(f"LightGlue weights not found at {' or '.join(str(c) for c in candidates)}.")
             self._model = LightGlueEngine(torch.load(str(path), map_location="cpu"))
 
     def match(

@@ -221,11 +221,32 @@ LIGHTGLUE_PRUNING_THRESHOLD = 1536
 NO_PRUNING = 2**31 - 1
 
 
+def normalize_lightglue_state_dict(sd: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Accept both key layouts of upstream ``cvg/LightGlue`` checkpoints. The published ``superpoint_lightglue.pth``
+    (v0.1_arxiv, the file the reference's ``LightGlue(features="superpoint")`` downloads,
+    gtsfm/frontend/matcher/lightglue_matcher.py:41) stores ``self_attn.{i}.*`` / ``cross_attn.{i}.*``; upstream renames
+    them to ``transformers.{i}.self_attn.*`` / ``transformers.{i}.cross_attn.*`` when loading ("rename old state dict
+    entries"). The same renames are applied here; already-renamed dicts pass through unchanged."""
+    out: Dict[str, torch.Tensor] = {}
+    for key, value in sd.items():
+        parts = key.split(".")
+        if len(parts) > 2 and parts[0] in ("self_attn", "cross_attn") and parts[1].isdigit():
+            key = ".".join(["transformers", parts[1], parts[0]] + parts[2:])
+        out[key] = value
+    if not any(k.startswith("transformers.") for k in out):
+        raise KeyError(
+            "LightGlue state_dict holds neither 'transformers.{i}.*' nor 'self_attn.{i}.*' / 'cross_attn.{i}.*' entries "
+            f"(first keys: {sorted(sd)[:4]})"
+        )
+    return out
+
+
 def lightglue_num_layers(sd: Mapping[str, torch.Tensor]) -> int:
-    return 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("transformers."))
+    return 1 + max(int(k.split(".")[1]) for k in normalize_lightglue_state_dict(sd) if k.startswith("transformers."))
 
 
 def lightglue_entries(sd: Mapping[str, torch.Tensor]) -> Tuple[List[Entry], np.ndarray, np.ndarray]:
+    sd = normalize_lightglue_state_dict(sd)
     n_layers = lightglue_num_layers(sd)
     qkv_perm = np.array([(r % 256 // 64) * 192 + (r % 64) * 3 + r // 256 for r in range(768)])  # new j*256+h*64+d <- old h*192+d*3+j
     entries: List[Entry] = [(1, _f64(sd["posenc.Wr.weight"]).reshape(-1), None)]

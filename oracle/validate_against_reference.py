@@ -47,6 +47,15 @@ SUPERGLUE_CASES = [
     (1, 5, (64, 64), (64, 64), 13, 20),
 ]
 SUPERGLUE_LAYERS_GOLDEN = 18
+# The benchmark's own shapes (parity was unproven exactly where the headline number is taken): full
+# depth, N = M = 2048 with GTSfM's 20 and BASELINE config 4's 100 Sinkhorn iterations, and GTSfM's 5000-keypoint cap.
+# (n0, n1, shape0, shape1, seed, sinkhorn iterations, stride of the stored sample of the log-OT matrix)
+SUPERGLUE_BENCH_CASES = [
+    (2048, 2048, (1024, 1024), (1024, 1024), 14, 20, 16),
+    (2048, 2048, (1024, 1024), (1024, 1024), 14, 100, 16),
+    (5000, 4800, (1024, 1024), (1024, 1024), 15, 20, 40),
+]
+BENCH_VIEWS = (46, 1024, 1024, 1000)  # bench.py's images: synthetic_overlapping_views(n, h, w, seed)
 
 
 def _import_by_path(name: str, path: Path):
@@ -138,9 +147,32 @@ def check_superpoint_large(write: bool) -> None:
             )
 
 
-def check_superglue(write: bool) -> None:
+def check_superpoint_bench(write: bool) -> None:
+    """bench.py's first two 1024x1024 views through the reference SuperPoint: keypoints and scores in full, the
+    descriptors of the first 256 keypoints."""
+    sd = synthetic.synthetic_superpoint_state_dict()
+    model = reference_superpoint(sd)
+    n, h, w, seed = BENCH_VIEWS
+    views = synthetic.synthetic_overlapping_views(n, h, w, seed)
+    for v in (0, 1):
+        img = superpoint_oracle.gray_u8_to_tensor(views[v])
+        with torch.no_grad(), _force_align_corners():
+            ref = model({"image": img})
+            ora = superpoint_oracle.superpoint_forward(sd, img)
+        kp, sc, de = ref["keypoints"][0], ref["scores"][0], ref["descriptors"][0]
+        assert torch.equal(kp, ora["keypoints"]) and torch.equal(sc, ora["scores"]) and torch.equal(de, ora["descriptors"])
+        print(f"superpoint bench view {v} ({h}x{w}): K={kp.shape[0]} restatement bit-exact with reference")
+        if write:
+            np.savez_compressed(
+                GOLDEN / f"bench_superpoint_{h}x{w}_view{v}.npz", height=h, width=w, view=v, views=n, seed=seed,
+                keypoints=kp.numpy().astype(np.int16), scores=sc.numpy(), descriptors_head=de.numpy().T[:256].copy(),
+            )
+
+
+def check_superglue(write: bool, bench: bool = False) -> None:
     sd = synthetic.synthetic_superglue_state_dict(num_layers=SUPERGLUE_LAYERS_GOLDEN)
-    for n0, n1, shp0, shp1, seed, iters in SUPERGLUE_CASES:
+    cases = SUPERGLUE_BENCH_CASES if bench else [c + (3,) for c in SUPERGLUE_CASES]
+    for n0, n1, shp0, shp1, seed, iters, ot_stride in cases:
         model = reference_superglue(sd, iters)
         k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(n0, n1, shp0, shp1, seed=seed)
         data = {
@@ -162,13 +194,15 @@ def check_superglue(write: bool) -> None:
         print(f"superglue n=({n0},{n1}) iters={iters}: {nm} matches, restatement bit-exact with reference")
         if write:
             np.savez_compressed(
-                GOLDEN / f"superglue_{n0}x{n1}_s{seed}_it{iters}.npz",
+                GOLDEN / f"{'bench_' if bench else ''}superglue_{n0}x{n1}_s{seed}_it{iters}.npz",
                 n0=n0, n1=n1, shape0=shp0, shape1=shp1, seed=seed, iters=iters,
                 matches0=ref["matches0"][0].numpy(), matches1=ref["matches1"][0].numpy(),
                 matching_scores0=ref["matching_scores0"][0].numpy(),
                 matching_scores1=ref["matching_scores1"][0].numpy(),
-                ot_sample=ora["ot"][0, ::3, ::3].numpy().copy(),
+                ot_sample=ora["ot"][0, ::ot_stride, ::ot_stride].numpy().copy(), ot_stride=ot_stride,
             )
+    if bench:
+        return
     # empty-input early-out (superglue.py:233-240)
     model = reference_superglue(sd, 20)
     data = {
@@ -244,6 +278,7 @@ def check_lund_door(write: bool) -> None:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", action="store_true", help="(re)write tests/golden/*.npz")
+    ap.add_argument("--skip-bench-shapes", action="store_true", help="skip the 1024x1024 / N = 2048 / N = 5000 cases (minutes of CPU)")
     args = ap.parse_args()
     if not MODELS.exists():
         raise SystemExit(f"reference model files not found under {MODELS}")
@@ -253,6 +288,9 @@ def main() -> None:
     check_superpoint_large(args.write)
     check_superglue(args.write)
     check_lund_door(args.write)
+    if not args.skip_bench_shapes:
+        check_superpoint_bench(args.write)
+        check_superglue(args.write, bench=True)
     print("OK")
 
 

@@ -1,0 +1,63 @@
+"""CPU: bench.py's launcher, sharding and collective plumbing.
+
+``python bench.py --gpus N`` must start N ranks by itself; ``--mode scene`` shards ONE scene (BASELINE config 4) over
+the ranks. ``--plumbing-only`` replaces the kernels with stand-ins so that everything around them -- self-launch under
+torch.distributed.run, gloo rendezvous on 127.0.0.1, cyclic / 2-D block-cyclic ownership, the feature all-gather, the
+ragged gather of the match lists, barrier + max-over-ranks timing, the one JSON line of rank 0 -- runs here."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from gtsfm_amd import parallel
+from tests.conftest import REPO
+
+
+def _run_bench(*flags, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, str(REPO / "bench.py"), *flags], capture_output=True, text=True, timeout=600, env=e, cwd=str(REPO))
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+def test_bench_self_launches_and_shards_a_scene_over_two_ranks():
+    p, lines = _run_bench("--gpus", "2", "--mode", "scene", "--plumbing-only", "--images", "9", "--pairs", "30", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["plumbing_only"] is True and r["steps"] == 2 and r["warmup"] == 1
+    assert r["config"]["mode"] == "scene" and r["config"]["images_per_gpu_per_step"] == 5
+    assert r["config"]["pairs_per_gpu_per_step"] == len(parallel.partition_pairs_2d(parallel.exhaustive_pairs(9)[:30], 0, 2))
+    assert r["value"] > 0 and r["unit"] == "image-pairs/s"
+
+
+def test_bench_replica_mode_self_launch_weak_scaling():
+    p, lines = _run_bench("--gpus", "2", "--plumbing-only", "--images", "5", "--pairs", "8", "--steps", "1", "--warmup", "0")
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["pairs_per_gpu_per_step"] == 8
+
+
+def test_bench_rejects_a_mismatched_launcher():
+    p, lines = _run_bench("--gpus", "2", "--plumbing-only", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout) and not lines
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_scene_partitions_cover_every_pair_once(world):
+    pairs = parallel.exhaustive_pairs(101)[:5000]
+    parts = [parallel.partition_pairs_2d(pairs, r, world) for r in range(world)]
+    assert sorted(p for part in parts for p in part) == sorted(pairs)
+    assert max(len(p) for p in parts) <= 1.06 * len(pairs) / world  # balanced: BASELINE config 4's heaviest rank
+    rows, cols = parallel.process_grid(world)
+    assert rows * cols == world and rows <= cols
+    if world == 8:  # 2 x 4 grid: a rank touches ~ n/2 + n/4 of the images, not all of them
+        assert max(len(parallel.images_touched(p)) for p in parts) <= 76
+    rows_of = sorted(parallel.table_index(i, 101, world) for i in range(101))
+    assert len(set(rows_of)) == 101 and rows_of[-1] < world * (-(-101 // world))

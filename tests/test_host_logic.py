@@ -90,6 +90,28 @@ def test_lightglue_weight_preparation_regroups_qkv(built_library):
     np.testing.assert_allclose(new[:, 512:].reshape(5, 4, 64), qkv[..., 2], atol=1e-12)
 
 
+def test_lightglue_loader_accepts_published_key_layout(built_library):
+    """The published superpoint_lightglue.pth stores self_attn.{i}.* / cross_attn.{i}.*; upstream renames them to
+    transformers.{i}.* at load time. Both layouts must pack to the same blob."""
+    from gtsfm_amd.runtime.matcher_engine import lightglue_entries, lightglue_num_layers, normalize_lightglue_state_dict, pack_blob
+
+    sd = synthetic.synthetic_lightglue_state_dict(num_layers=3)
+    old_style = {}
+    for k, v in sd.items():
+        parts = k.split(".")
+        if parts[0] == "transformers":
+            k = ".".join([parts[2], parts[1]] + parts[3:])  # transformers.i.self_attn.x -> self_attn.i.x
+        old_style[k] = v
+    assert not any(k.startswith("transformers.") for k in old_style) and "self_attn.2.Wqkv.weight" in old_style
+    assert lightglue_num_layers(old_style) == 3
+    assert sorted(normalize_lightglue_state_dict(old_style)) == sorted(sd)
+    e_new, mb_new, cb_new = lightglue_entries(sd)
+    e_old, mb_old, cb_old = lightglue_entries(old_style)
+    assert np.array_equal(pack_blob(e_new), pack_blob(e_old)) and np.array_equal(mb_new, mb_old) and np.array_equal(cb_new, cb_old)
+    with pytest.raises(KeyError, match="neither"):
+        lightglue_num_layers({"posenc.Wr.weight": sd["posenc.Wr.weight"]})
+
+
 def _free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
