@@ -47,12 +47,25 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         return LIB
     OBJ_DIR.mkdir(exist_ok=True)
 
+    headers = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "gtsfm_amd.h"]
+
     def compile_one(src: Path) -> Path:
+        """One object per source, rebuilt only when the source, a header or the flags changed (dense_kernels.hip alone
+        takes minutes)."""
         obj = OBJ_DIR / (src.stem + ".o")
-        cmd = [HIPCC, *FLAGS, *PER_FILE_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
+        flags = [*FLAGS, *PER_FILE_FLAGS.get(src.name, [])]
+        h = hashlib.sha256(" ".join(flags).encode())
+        for f in [src, *headers]:
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+        obj_stamp = OBJ_DIR / (src.stem + ".digest")
+        if not force and obj.exists() and obj_stamp.exists() and obj_stamp.read_text() == h.hexdigest():
+            return obj
+        cmd = [HIPCC, *flags, "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        obj_stamp.write_text(h.hexdigest())
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:

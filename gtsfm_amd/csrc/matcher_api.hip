@@ -360,6 +360,82 @@ extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_scor
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Stand-alone Sinkhorn (parity tests against torch.logsumexp iterations; bench.py's roofline of the sweep kernels)
+// ---------------------------------------------------------------------------------------------------------------
+
+namespace {
+
+struct SkWorkspace {
+    size_t desc, part, uv_row, uv_col, total;
+};
+
+SkWorkspace sk_workspace_layout(int P, const int32_t* m, const int32_t* n) {
+    const BatchDims d = batch_dims(P, m, n, 1);
+    SkWorkspace w;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t r = o;
+        o += align_up(bytes, 256);
+        return r;
+    };
+    w.desc = take(desc_layout(P, 0).total * sizeof(int32_t));
+    w.part = take(d.part_floats * 4);
+    w.uv_row = take(((size_t)d.T + 16 * P + 8) * 4);
+    w.uv_col = take(((size_t)d.T + 16 * P + 8) * 4);
+    w.total = o;
+    return w;
+}
+
+__global__ void sk_copy_vectors_kernel(const SeqDesc* __restrict__ seqs, const int* __restrict__ counts, const float* __restrict__ rowvec,
+                                       const float* __restrict__ colvec, int stride_u, int stride_v, float* __restrict__ u, float* __restrict__ v) {
+    const int p = blockIdx.y;
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int vec0 = vec_off(s0, 2 * p), vec1 = vec_off(s1, 2 * p + 1);
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= max(m, n); t += gridDim.x * blockDim.x) {
+        if (t <= m) u[(size_t)p * stride_u + t] = rowvec[vec0 + t];
+        if (t <= n) v[(size_t)p * stride_v + t] = colvec[vec1 + t];
+    }
+}
+
+}  // namespace
+
+extern "C" size_t gtsfm_sinkhorn_workspace_bytes(int npairs, const int32_t* m, const int32_t* n) {
+    if (npairs <= 0 || !m || !n) return 256;
+    return sk_workspace_layout(npairs, m, n).total;
+}
+
+extern "C" int gtsfm_sinkhorn_f32(float* z_dev, int npairs, const int32_t* m, const int32_t* n, float bin_score, int iters,
+                                  void* workspace_dev, size_t workspace_bytes, float* u_dev, float* v_dev, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GTSFM_CHECK_ARG(z_dev && m && n && workspace_dev && u_dev && v_dev, "sinkhorn: null pointer");
+    GTSFM_CHECK_ARG(npairs > 0 && iters >= 0, "sinkhorn: bad arguments");
+    const SkWorkspace ws = sk_workspace_layout(npairs, m, n);
+    if (workspace_bytes < ws.total) {
+        gtsfm_set_error("sinkhorn: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.total);
+        return GTSFM_ERR_WORKSPACE;
+    }
+    const BatchDims d = batch_dims(npairs, m, n, 1);
+    const DescLayout DL = desc_layout(npairs, 0);
+    std::vector<int32_t> host(DL.total), hw((size_t)4 * npairs, 1);
+    TRY(gtsfm_match_build_desc(1, npairs, m, n, hw.data(), host.data()));
+    char* wsp = (char*)workspace_dev;
+    int32_t* desc_dev = (int32_t*)(wsp + ws.desc);
+    if (hipMemcpyAsync(desc_dev, host.data(), DL.total * sizeof(int32_t), hipMemcpyHostToDevice, stream) != hipSuccess) return GTSFM_ERR_HIP;
+    if (hipStreamSynchronize(stream) != hipSuccess) return GTSFM_ERR_HIP;  // `host` goes out of scope below
+    SweepArgs sa;
+    sa.pairs = (const PairDesc*)(desc_dev + DL.pairs), sa.seqs = (const SeqDesc*)(desc_dev + DL.seqs), sa.counts = desc_dev + DL.live;
+    sa.npairs = npairs, sa.max_m = d.max_n0, sa.max_n = d.max_n1;
+    sa.zbuf = z_dev, sa.rowvec = (float*)(wsp + ws.uv_row), sa.colvec = (float*)(wsp + ws.uv_col), sa.partials = (float*)(wsp + ws.part);
+    if (hipMemsetAsync(sa.rowvec, 0, ((size_t)d.T + 16 * npairs + 8) * 4, stream) != hipSuccess) return GTSFM_ERR_HIP;  // u = 0 for iters = 0
+    TRY(launch_sinkhorn(sa, bin_score, iters, stream));
+    hipLaunchKernelGGL(sk_copy_vectors_kernel, dim3(ceil_div((d.max_n0 > d.max_n1 ? d.max_n0 : d.max_n1) + 1, 256), npairs), dim3(256), 0, stream,
+                       sa.seqs, sa.counts, sa.rowvec, sa.colvec, d.max_n0 + 1, d.max_n1 + 1, u_dev, v_dev);
+    GTSFM_CHECK_LAUNCH("sk_copy_vectors_kernel");
+    return GTSFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LightGlue (features = "superpoint": 9 layers, 4 heads x 64, descriptor_dim 256)
 // ---------------------------------------------------------------------------------------------------------------
 

@@ -29,6 +29,24 @@ struct SweepArgs {
     float* partials;
 };
 
+#ifdef __HIPCC__
+__device__ __forceinline__ float neg_inf() { return -__builtin_inff(); }
+
+// Row / column vectors of a pair live at a 16-byte-aligned offset per sequence (float4 loads of v in the row sweeps).
+__device__ __forceinline__ int vec_off(const SeqDesc& sq, int s) { return ((sq.row_off + 3) & ~3) + 8 * s; }
+
+// Element value of the final assignment matrix.
+//   SG: ((Z + u_i) + v_j) - norm                                   (superglue.py:147,169)
+//   LG: ((sim - rowlse_i) + (sim - collse_j)) + (c0_i + c1_j)      (sigmoid_log_double_softmax)
+template <bool SG>
+__device__ __forceinline__ float assign_value(float z, float a_i, float b_j, float norm, float c_i, float c_j) {
+    if (SG) return ((z + a_i) + b_j) - norm;
+    return ((z - a_i) + (z - b_j)) + (c_i + c_j);
+}
+
+__device__ __forceinline__ float logsigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+#endif
+
 int launch_sg_encode_input(const float* kpts, const float* scores, const SeqDesc* seqs, const int* counts, int nseq, int max_n,
                            float* enc_in, hipStream_t stream);
 int launch_lg_posenc(const float* kpts, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* Wr, float* enc,
@@ -39,9 +57,18 @@ int launch_layernorm_gelu(float* x, int ld, const SeqDesc* seqs, const int* coun
                           const float* beta, hipStream_t stream);
 int launch_rowdot(const float* x, int ld, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* w, float b, int act,
                   float* out, hipStream_t stream);
+// Score-matrix sweeps (sweep_kernels.hip): register-resident rows for up to 2048 columns, LDS-staged rows beyond
 int launch_sinkhorn(const SweepArgs& a, float bin_score, int iters, hipStream_t stream);
 int launch_double_softmax_lse(const SweepArgs& a, hipStream_t stream);
 int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogit, float threshold, float* max0, int* idx0, int* idx1,
                            int* matches, float* mscores, hipStream_t stream);
+// LDS-staged forms (matcher_kernels.hip): any number of columns
+int launch_sinkhorn_lds(const SweepArgs& a, float bin_score, int iters, hipStream_t stream);
+int launch_double_softmax_lse_lds(const SweepArgs& a, hipStream_t stream);
+int launch_extract_matches_lds(const SweepArgs& a, int superglue, const float* zlogit, float threshold, float* max0, int* idx0, int* idx1,
+                               int* matches, float* mscores, hipStream_t stream);
+int launch_sg_fill_bins(const SweepArgs& a, float bin_score, hipStream_t stream);
+int launch_mutual_matches(const SweepArgs& a, float threshold, const float* max0, const int* idx0, const int* idx1, int* matches,
+                          float* mscores, hipStream_t stream);
 int launch_materialize_assignment(const SweepArgs& a, int superglue, const float* zlogit, float* out, hipStream_t stream);
 int sweep_rows_per_block(int max_cols);  // rows of the score matrix one workgroup of the row sweep owns

@@ -10,8 +10,6 @@
 
 #include "matcher_kernels.h"
 
-__device__ __forceinline__ float neg_inf() { return -__builtin_inff(); }
-
 // ---------------------------------------------------------------------------------------------------------------
 // Keypoint inputs
 // ---------------------------------------------------------------------------------------------------------------
@@ -204,9 +202,6 @@ int sweep_rows_per_block(int max_cols) {
     return r < 1 ? 1 : (r > 16 ? 16 : r);
 }
 
-// Row / column vectors of a pair live at a 16-byte-aligned offset per sequence (float4 loads of v in the row sweep).
-__device__ __forceinline__ int vec_off(const SeqDesc& sq, int s) { return ((sq.row_off + 3) & ~3) + 8 * s; }
-
 template <bool SG>
 __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                        const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
@@ -315,6 +310,119 @@ __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__
     }
 }
 
+// Round-1 form of the row sweep: two passes per reduction and a second exponential in the column pass. Exact for any
+// value range, so LightGlue's double log-softmax (no dustbin row that bounds the column sums; similarities of +-100)
+// keeps it: reusing the row exponentials for the column sums underflows when a column's largest entries lie > 87
+// below their rows' maxima (8 LightGlue parity tests caught exactly that on the first GPU run of round 2).
+template <bool SG>
+__global__ __launch_bounds__(256) void lse_rows_twopass_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+                                                       const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
+                                                       float* __restrict__ rowvec, const float* __restrict__ colvec,
+                                                       float* __restrict__ partials, int R) {
+    // The workgroup's R rows are staged ONCE into LDS (coalesced 16-byte loads, all in flight together); the row
+    // log-sum-exp (phase A) and the column partials (phase B) both run out of LDS, so Z is read from HBM exactly once
+    // per Sinkhorn iteration.
+    extern __shared__ __attribute__((aligned(16))) float zs[];  // [R][ld] + u[R]
+    const int p = blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int rows = m + (SG ? 1 : 0), cols = n + (SG ? 1 : 0);
+    const int r0 = blockIdx.x * R;
+    if (r0 >= rows) return;
+    const int nr = min(R, rows - r0);
+    const int ld = pd.ld, ld4 = ld >> 2;
+    const float* Z = zbuf + pd.z_off + (size_t)r0 * ld;
+    const int vec0 = vec_off(s0, 2 * p), vec1 = vec_off(s1, 2 * p + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float norm = SG ? -logf((float)m + (float)n) : 0.f;
+    const float NEG = neg_inf();
+    float* v_s = zs + (size_t)R * ld;  // staged column vector (SuperGlue's v)
+    float* u_s = v_s + ld;
+    if (SG)
+        for (int j = threadIdx.x * 4; j < cols; j += 1024) *reinterpret_cast<f32x4*>(v_s + j) = *reinterpret_cast<const f32x4*>(colvec + vec1 + j);
+    // stage: the nr rows are contiguous in memory (row stride ld), nr * ld4 float4 in total
+    for (int base = 0; base < nr * ld4; base += 256 * 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = base + e * 256 + threadIdx.x;
+            t[e] = (idx < nr * ld4) ? reinterpret_cast<const f32x4*>(Z)[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = base + e * 256 + threadIdx.x;
+            if (idx < nr * ld4) reinterpret_cast<f32x4*>(zs)[idx] = t[e];
+        }
+    }
+    __syncthreads();
+    // phase A: wave w reduces rows w, w+4, ... (two passes over LDS: max, then sum of exp -- as torch.logsumexp does)
+    for (int rr = wave; rr < nr; rr += 4) {
+        const int i = r0 + rr;
+        const float* zr = zs + (size_t)rr * ld;
+        float mx = NEG;
+#pragma unroll 4
+        for (int j = lane * 4; j < cols; j += 256) {
+            f32x4 z = *reinterpret_cast<const f32x4*>(zr + j);
+            if (SG) z = z + *reinterpret_cast<const f32x4*>(v_s + j);
+            mx = fmaxf(mx, z.x);
+            if (j + 1 < cols) mx = fmaxf(mx, z.y);
+            if (j + 2 < cols) mx = fmaxf(mx, z.z);
+            if (j + 3 < cols) mx = fmaxf(mx, z.w);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll 4
+        for (int j = lane * 4; j < cols; j += 256) {
+            f32x4 z = *reinterpret_cast<const f32x4*>(zr + j);
+            if (SG) z = z + *reinterpret_cast<const f32x4*>(v_s + j);
+            sum += expf(z.x - mx);
+            if (j + 1 < cols) sum += expf(z.y - mx);
+            if (j + 2 < cols) sum += expf(z.z - mx);
+            if (j + 3 < cols) sum += expf(z.w - mx);
+        }
+        sum = wave_sum(sum);
+        const float lse = logf(sum) + mx;
+        float ui;
+        if (SG) {
+            const float log_mu = (i < m) ? norm : logf((float)n) + norm;
+            ui = log_mu - lse;
+        } else {
+            ui = lse;
+        }
+        if (lane == 0) {
+            rowvec[vec0 + i] = ui;
+            u_s[rr] = ui;
+        }
+    }
+    __syncthreads();
+    // phase B: column partials (max, sum) of Z + u over this block's rows, 4 columns per thread, from LDS
+    float* part = partials + pd.part_off + (size_t)blockIdx.x * ld * 2;
+    for (int j = threadIdx.x * 4; j < cols; j += 1024) {
+        f32x4 mx = {NEG, NEG, NEG, NEG};
+        for (int rr = 0; rr < nr; ++rr) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(zs + (size_t)rr * ld + j);
+            if (SG) {
+                const float u = u_s[rr];
+                v.x += u, v.y += u, v.z += u, v.w += u;
+            }
+            mx.x = fmaxf(mx.x, v.x), mx.y = fmaxf(mx.y, v.y), mx.z = fmaxf(mx.z, v.z), mx.w = fmaxf(mx.w, v.w);
+        }
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int rr = 0; rr < nr; ++rr) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(zs + (size_t)rr * ld + j);
+            if (SG) {
+                const float u = u_s[rr];
+                v.x += u, v.y += u, v.z += u, v.w += u;
+            }
+            sum.x += expf(v.x - mx.x), sum.y += expf(v.y - mx.y), sum.z += expf(v.z - mx.z), sum.w += expf(v.w - mx.w);
+        }
+        // columns beyond `cols` (row padding) produce garbage partials that are never read
+        *reinterpret_cast<f32x4*>(part + (size_t)j * 2) = f32x4{mx.x, sum.x, mx.y, sum.y};
+        *reinterpret_cast<f32x4*>(part + (size_t)j * 2 + 4) = f32x4{mx.z, sum.z, mx.w, sum.w};
+    }
+}
+
 // Combine the row-block partials of 64 columns: 4 thread groups stride over the blocks, then merge through LDS.
 template <bool SG>
 __global__ __launch_bounds__(256) void lse_cols_kernel(const PairDesc* __restrict__ pairs, const SeqDesc* __restrict__ seqs,
@@ -383,17 +491,6 @@ __global__ void sg_fill_bins_kernel(float* __restrict__ zbuf, const PairDesc* __
         }
     }
 }
-
-// Element value of the final assignment matrix.
-//   SG: ((Z + u_i) + v_j) - norm                                   (superglue.py:147,169)
-//   LG: ((sim - rowlse_i) + (sim - collse_j)) + (c0_i + c1_j)      (sigmoid_log_double_softmax)
-template <bool SG>
-__device__ __forceinline__ float assign_value(float z, float a_i, float b_j, float norm, float c_i, float c_j) {
-    if (SG) return ((z + a_i) + b_j) - norm;
-    return ((z - a_i) + (z - b_j)) + (c_i + c_j);
-}
-
-__device__ __forceinline__ float logsigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
 
 // Row-wise max / first-argmax over the inner m x n block. One wave per row.
 template <bool SG>
@@ -561,26 +658,46 @@ static int sweep_impl(const SweepArgs& a, int iters, hipStream_t stream) {
     dim3 grid_rows(ceil_div(a.max_m + ext, R), a.npairs);
     dim3 grid_cols(ceil_div(a.max_n + ext, 64), a.npairs);
     for (int it = 0; it < iters; ++it) {
-        hipLaunchKernelGGL(lse_rows_kernel<SG>, grid_rows, dim3(256), lds_bytes, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec,
-                           a.colvec, a.partials, R);
+        if (SG)
+            hipLaunchKernelGGL(lse_rows_kernel<true>, grid_rows, dim3(256), lds_bytes, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec,
+                               a.colvec, a.partials, R);
+        else
+            hipLaunchKernelGGL(lse_rows_twopass_kernel<false>, grid_rows, dim3(256), lds_bytes, stream, a.zbuf, a.pairs, a.seqs, a.counts,
+                               a.rowvec, a.colvec, a.partials, R);
         hipLaunchKernelGGL(lse_cols_kernel<SG>, grid_cols, dim3(256), 0, stream, a.pairs, a.seqs, a.counts, a.partials, a.colvec, R);
     }
     GTSFM_CHECK_LAUNCH("lse_rows/cols_kernel");
     return GTSFM_OK;
 }
 
-int launch_sinkhorn(const SweepArgs& a, float bin_score, int iters, hipStream_t stream) {
+int launch_sinkhorn_lds(const SweepArgs& a, float bin_score, int iters, hipStream_t stream) {
+    if (a.npairs <= 0) return GTSFM_OK;
+    int rc = launch_sg_fill_bins(a, bin_score, stream);
+    if (rc != GTSFM_OK) return rc;
+    return sweep_impl<true>(a, iters, stream);
+}
+
+int launch_sg_fill_bins(const SweepArgs& a, float bin_score, hipStream_t stream) {
     if (a.npairs <= 0) return GTSFM_OK;
     hipLaunchKernelGGL(sg_fill_bins_kernel, dim3(ceil_div(max(a.max_m, a.max_n) + 1, 256), a.npairs), dim3(256), 0, stream, a.zbuf, a.pairs,
                        a.seqs, a.counts, bin_score, a.colvec);
     GTSFM_CHECK_LAUNCH("sg_fill_bins_kernel");
-    return sweep_impl<true>(a, iters, stream);
+    return GTSFM_OK;
 }
 
-int launch_double_softmax_lse(const SweepArgs& a, hipStream_t stream) { return sweep_impl<false>(a, 1, stream); }
+int launch_mutual_matches(const SweepArgs& a, float threshold, const float* max0, const int* idx0, const int* idx1, int* matches,
+                          float* mscores, hipStream_t stream) {
+    if (a.npairs <= 0 || a.max_m <= 0 || a.max_n <= 0) return GTSFM_OK;
+    hipLaunchKernelGGL(mutual_matches_kernel, dim3(ceil_div(max(a.max_m, a.max_n), 256), a.npairs), dim3(256), 0, stream, a.seqs, a.counts,
+                       max0, idx0, idx1, threshold, matches, mscores);
+    GTSFM_CHECK_LAUNCH("mutual_matches_kernel");
+    return GTSFM_OK;
+}
 
-int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogit, float threshold, float* max0, int* idx0, int* idx1,
-                           int* matches, float* mscores, hipStream_t stream) {
+int launch_double_softmax_lse_lds(const SweepArgs& a, hipStream_t stream) { return sweep_impl<false>(a, 1, stream); }
+
+int launch_extract_matches_lds(const SweepArgs& a, int superglue, const float* zlogit, float threshold, float* max0, int* idx0, int* idx1,
+                               int* matches, float* mscores, hipStream_t stream) {
     if (a.npairs <= 0 || a.max_m <= 0 || a.max_n <= 0) return GTSFM_OK;
     dim3 gr(ceil_div(a.max_m, 4), a.npairs), gc(ceil_div(a.max_n, 64), a.npairs);
     if (superglue) {
@@ -590,8 +707,6 @@ int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogi
         hipLaunchKernelGGL(best_rows_kernel<false>, gr, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, zlogit, max0, idx0);
         hipLaunchKernelGGL(best_cols_kernel<false>, gc, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, zlogit, idx1);
     }
-    hipLaunchKernelGGL(mutual_matches_kernel, dim3(ceil_div(max(a.max_m, a.max_n), 256), a.npairs), dim3(256), 0, stream, a.seqs, a.counts,
-                       max0, idx0, idx1, threshold, matches, mscores);
-    GTSFM_CHECK_LAUNCH("extract_matches kernels");
-    return GTSFM_OK;
+    GTSFM_CHECK_LAUNCH("best_rows / best_cols kernels");
+    return launch_mutual_matches(a, threshold, max0, idx0, idx1, matches, mscores, stream);
 }

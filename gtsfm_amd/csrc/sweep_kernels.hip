@@ -1,0 +1,542 @@
+// Score-matrix sweeps with register-resident rows: Sinkhorn iterations (superglue.py:141-147), LightGlue's double
+// log-softmax, and the match extraction (superglue.py:266-276, LightGlue filter_matches) fused into ONE pass over Z.
+//
+// Round 1 staged 6-16 rows of Z in a 49-64 KiB LDS slab per workgroup and went through three barrier-separated phases
+// (stage, row reductions, column partials) with two library expf per element: 303 + 38 us per iteration for 537 MB of
+// couplings matrices = 1.8 TB/s, VALU / latency-bound. Here a row never touches LDS:
+//   * a WAVE owns a row: 64 lanes x NCH float4 (NCH = 8 covers 2048 columns) = 32 values per lane, loaded with one
+//     fully coalesced 1 KiB request per float4 and reduced with two wave shuffles trees (max, sum);
+//   * the next row of the wave is already in flight (second register buffer) while the current one is reduced: 12 waves
+//     per CU x 8 KiB outstanding, no barrier anywhere in the row loop;
+//   * ONE hardware exponential per element (v_exp_f32 on a pre-scaled argument). SuperGlue's column sums reuse the row
+//     exponentials: exp(z_ij + u_i + v_j) = e_ij * mu_i / s_i with e_ij = exp(z_ij + v_j - max_i), s_i = sum_j e_ij,
+//     every term <= mu_i < 1 (no running maximum needed) and the dustbin row gives every column a term of healthy
+//     size; v_j' = log nu_j - (log sum_i(...) - v_j). The dustbin row and column are the constant bin_score
+//     (superglue.py:156-160) and are never read from memory;
+//   * a wave accumulates the column partials of its 8 rows in registers; the workgroup's 4 waves are combined through LDS
+//     once, after the loop; a small second kernel sums the row-block partials in a fixed order (deterministic).
+// LightGlue's double softmax has no dustbin bounding the column sums and similarities of +-100, so its column statistics
+// are kept as online (max, sum) pairs per lane-column with their own exponentials (it runs once per forward pass).
+// The extraction sweep reads Z once more and produces the row arg-maxima (wave reduction) and the column arg-maxima
+// (per-lane running best over the wave's rows, combined across waves / row blocks), replacing round 1's two separate
+// sweeps (best_rows + best_cols = 0.93 ms per 32-pair chunk at N = 2048).
+// Score matrices wider than 2048 columns (GTSfM's 5000-keypoint cap) take the LDS-staged kernels of
+// matcher_kernels.hip. Built with -ffp-contract=off.
+
+#include <stdlib.h>
+
+#include "matcher_kernels.h"
+
+#define SW_ROWS 32        // rows per workgroup: 4 waves x 8 rows (wave w owns rows r0 + w, r0 + w + 4, ...)
+#define SW_MAX_COLS 2048  // widest register-resident row
+
+constexpr float SW_LOG2E = 1.44269504088896340736f;
+constexpr float SW_FLT_MIN = 1.17549435e-38f;
+
+__device__ __forceinline__ float sw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int NCH>
+__device__ __forceinline__ void sw_load_row(const float* __restrict__ zr, int n, int lane, f32x4 (&dst)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        if (col < n) dst[c] = *reinterpret_cast<const f32x4*>(zr + col);  // col < n implies col + 3 < ld (ld = n rounded up to 4)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SuperGlue: one Sinkhorn iteration = sinkhorn_rows_kernel + sinkhorn_cols_kernel
+// ---------------------------------------------------------------------------------------------------------------
+
+// 168 registers (3 waves per SIMD) spill 33 of them at NCH = 8; 2 waves per SIMD still keep 64 KiB of rows in flight per CU
+template <int NCH>
+__global__ __launch_bounds__(256, NCH >= 8 ? 2 : 3) void sinkhorn_rows_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+                                                               const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
+                                                               float* __restrict__ rowvec, const float* __restrict__ colvec,
+                                                               float* __restrict__ partials, float alpha, int pair0) {
+    __shared__ __attribute__((aligned(16))) float red[4][NCH * 256];
+    __shared__ float red_bin[4];
+    const int p = pair0 + blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int rows = m + 1;
+    const int r0 = blockIdx.x * SW_ROWS;
+    if (r0 >= rows) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ld = pd.ld;
+    const float* Z = zbuf + pd.z_off;
+    const int vec0 = vec_off(s0, 2 * p), vec1 = vec_off(s1, 2 * p + 1);
+    const float NEG = neg_inf();
+    const float mn = (float)m + (float)n;
+    const float norm = -logf(mn);
+    const float inv_mn = 1.0f / mn;
+    f32x4 v[NCH], acc[NCH], za[NCH], zb[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < n) v[c] = *reinterpret_cast<const f32x4*>(colvec + vec1 + col);
+        acc[c] = za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float t_bin = alpha + colvec[vec1 + n];  // dustbin column: Z[i][n] = bin_score for every row
+    float acc_bin = 0.f;
+
+    auto load = [&](int i, f32x4(&dst)[NCH]) {
+        if (i < m) {
+            sw_load_row<NCH>(Z + (size_t)i * ld, n, lane, dst);
+        } else {  // dustbin row: Z[m][j] = bin_score
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) dst[c] = f32x4{alpha, alpha, alpha, alpha};
+        }
+    };
+    auto process = [&](int i, f32x4(&zz)[NCH]) {
+        float mx = t_bin;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = 4 * (lane + 64 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = (col + e < n) ? zz[c][e] + v[c][e] : NEG;
+                zz[c][e] = t;
+                mx = fmaxf(mx, t);
+            }
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ev = sw_exp2((zz[c][e] - mx) * SW_LOG2E);  // exp2(-inf) = 0 for the masked columns
+                zz[c][e] = ev;
+                s += ev;
+            }
+        }
+        s = wave_sum(s);
+        const float e_bin = sw_exp2((t_bin - mx) * SW_LOG2E);
+        s += e_bin;
+        const float lse = logf(s) + mx;
+        const float log_mu = (i < m) ? norm : logf((float)n) + norm;
+        if (lane == 0) rowvec[vec0 + i] = log_mu - lse;  // u_i (superglue.py:145)
+        // exp(u_i + max_i) = mu_i / s_i: weight of this row's exponentials in the column sums
+        const float w = ((i < m) ? inv_mn : (float)n * inv_mn) / s;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[c][e] = fmaf(zz[c][e], w, acc[c][e]);
+        }
+        acc_bin = fmaf(e_bin, w, acc_bin);
+    };
+
+    int i = r0 + wave;
+    if (i < rows) load(i, za);
+#pragma unroll 1
+    for (int k = 0; k < SW_ROWS / 4; k += 2) {
+        if (i >= rows) break;
+        if (i + 4 < rows) load(i + 4, zb);  // k + 1 < 8 always holds here
+        process(i, za);
+        i += 4;
+        if (i >= rows) break;
+        if (i + 4 < rows && k + 2 < SW_ROWS / 4) load(i + 4, za);
+        process(i, zb);
+        i += 4;
+    }
+
+    // column partials of the block's 32 rows: sum of the 4 waves, in a fixed order
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *reinterpret_cast<f32x4*>(&red[wave][4 * (lane + 64 * c)]) = acc[c];
+    if (lane == 0) red_bin[wave] = acc_bin;
+    __syncthreads();
+    float* part = partials + pd.part_off + (size_t)blockIdx.x * ld;
+    const float bin_sum = ((red_bin[0] + red_bin[1]) + red_bin[2]) + red_bin[3];
+    for (int f = threadIdx.x; f <= NCH * 64; f += 256) {  // one float4 more than a row holds: the dustbin column when n = 256 NCH
+        const int col = 4 * f;
+        if (col > n) continue;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        if (f < NCH * 64) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&red[0][col]), a1 = *reinterpret_cast<const f32x4*>(&red[1][col]);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(&red[2][col]), a3 = *reinterpret_cast<const f32x4*>(&red[3][col]);
+            sum = ((a0 + a1) + a2) + a3;
+        }
+        const int d = n - col;  // the dustbin column sits inside this float4 when 0 <= d < 4
+        if (d == 0) sum.x = bin_sum;
+        if (d == 1) sum.y = bin_sum;
+        if (d == 2) sum.z = bin_sum;
+        if (d == 3) sum.w = bin_sum;
+        *reinterpret_cast<f32x4*>(part + col) = sum;  // col <= n, col % 4 == 0 -> col + 3 < ld
+    }
+}
+
+// v_j = log nu_j - logsumexp_i(Z_ij + u_i) from the row-block partials sum_i exp(z_ij + u_i + v_j_old) (superglue.py:146)
+__global__ __launch_bounds__(256) void sinkhorn_cols_kernel(const PairDesc* __restrict__ pairs, const SeqDesc* __restrict__ seqs,
+                                                            const int* __restrict__ counts, const float* __restrict__ partials,
+                                                            float* __restrict__ colvec, int pair0) {
+    const int p = pair0 + blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j > n) return;
+    const int nblk = ceil_div(m + 1, SW_ROWS);
+    const float* part = partials + pd.part_off + j;
+    const size_t bs = (size_t)pd.ld;
+    float s0a = 0.f, s1a = 0.f, s2a = 0.f, s3a = 0.f;
+    int b = 0;
+    for (; b + 4 <= nblk; b += 4) {
+        s0a += part[(b + 0) * bs];
+        s1a += part[(b + 1) * bs];
+        s2a += part[(b + 2) * bs];
+        s3a += part[(b + 3) * bs];
+    }
+    for (; b < nblk; ++b) s0a += part[b * bs];
+    const float sum = (s0a + s1a) + (s2a + s3a);
+    const int vec1 = vec_off(s1, 2 * p + 1);
+    const float norm = -logf((float)m + (float)n);
+    const float log_nu = (j < n) ? norm : logf((float)m) + norm;
+    // a column whose terms all underflowed gets the smallest normal number instead of log(0)
+    colvec[vec1 + j] = log_nu - (logf(fmaxf(sum, SW_FLT_MIN)) - colvec[vec1 + j]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LightGlue: row log-sum-exp + online column (max, sum) statistics in one pass (sigmoid_log_double_softmax)
+// ---------------------------------------------------------------------------------------------------------------
+
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void lg_rows_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+                                                         const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
+                                                         float* __restrict__ rowvec, float* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) float red_m[4][NCH * 256];
+    __shared__ __attribute__((aligned(16))) float red_s[4][NCH * 256];
+    const int p = blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int r0 = blockIdx.x * SW_ROWS;
+    if (r0 >= m) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ld = pd.ld;
+    const float* Z = zbuf + pd.z_off;
+    const int vec0 = vec_off(s0, 2 * p);
+    const float NEG = neg_inf();
+    f32x4 cm[NCH], cs[NCH], za[NCH], zb[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        cm[c] = f32x4{NEG, NEG, NEG, NEG};
+        cs[c] = za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto process = [&](int i, f32x4(&zz)[NCH]) {
+        float mx = NEG;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = 4 * (lane + 64 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = (col + e < n) ? zz[c][e] : NEG;
+                zz[c][e] = t;
+                mx = fmaxf(mx, t);
+            }
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = zz[c][e];
+                s += sw_exp2((t - mx) * SW_LOG2E);
+                // online column statistics: the masked columns (t = -inf) keep (max, sum) = (-inf, 0)
+                const float nm = fmaxf(cm[c][e], t);
+                const float keep = (nm == NEG) ? 0.f : sw_exp2((cm[c][e] - nm) * SW_LOG2E);
+                const float add = (nm == NEG) ? 0.f : sw_exp2((t - nm) * SW_LOG2E);
+                cs[c][e] = cs[c][e] * keep + add;
+                cm[c][e] = nm;
+            }
+        }
+        s = wave_sum(s);
+        if (lane == 0) rowvec[vec0 + i] = logf(s) + mx;
+    };
+    int i = r0 + wave;
+    if (i < m) sw_load_row<NCH>(Z + (size_t)i * ld, n, lane, za);
+#pragma unroll 1
+    for (int k = 0; k < SW_ROWS / 4; k += 2) {
+        if (i >= m) break;
+        if (i + 4 < m) sw_load_row<NCH>(Z + (size_t)(i + 4) * ld, n, lane, zb);
+        process(i, za);
+        i += 4;
+        if (i >= m) break;
+        if (i + 4 < m && k + 2 < SW_ROWS / 4) sw_load_row<NCH>(Z + (size_t)(i + 4) * ld, n, lane, za);
+        process(i, zb);
+        i += 4;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        *reinterpret_cast<f32x4*>(&red_m[wave][4 * (lane + 64 * c)]) = cm[c];
+        *reinterpret_cast<f32x4*>(&red_s[wave][4 * (lane + 64 * c)]) = cs[c];
+    }
+    __syncthreads();
+    // block partial per column: plane 0 = max, plane 1 = sum of exp(. - max), at part_off + block * 2 ld
+    float* part = partials + pd.part_off + (size_t)blockIdx.x * 2 * ld;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        float M = red_m[0][j];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) M = fmaxf(M, red_m[w][j]);
+        float S = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = red_m[w][j];
+            if (mw != NEG) S += red_s[w][j] * sw_exp2((mw - M) * SW_LOG2E);
+        }
+        part[j] = M;
+        part[ld + j] = S;
+    }
+}
+
+__global__ __launch_bounds__(256) void lg_cols_kernel(const PairDesc* __restrict__ pairs, const SeqDesc* __restrict__ seqs,
+                                                      const int* __restrict__ counts, const float* __restrict__ partials,
+                                                      float* __restrict__ colvec) {
+    const int p = blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int nblk = ceil_div(m, SW_ROWS);
+    const float* part = partials + pd.part_off + j;
+    const size_t bs = (size_t)pd.ld * 2;
+    float M = neg_inf();
+    for (int b = 0; b < nblk; ++b) M = fmaxf(M, part[b * bs]);
+    float S = 0.f;
+    for (int b = 0; b < nblk; ++b) S += part[b * bs + pd.ld] * sw_exp2((part[b * bs] - M) * SW_LOG2E);
+    colvec[vec_off(s1, 2 * p + 1) + j] = logf(S) + M;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Match extraction: ONE pass over the inner m x n block gives the row arg-maxima and the column arg-maxima of the final
+// assignment matrix (assign_value), first index on ties as torch.max does.
+// ---------------------------------------------------------------------------------------------------------------
+
+#define SW_NO_INDEX 0x7fffffff
+
+template <bool SG, int NCH>
+__global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+                                                              const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
+                                                              const float* __restrict__ rowvec, const float* __restrict__ colvec,
+                                                              const float* __restrict__ zlogit, float* __restrict__ max0,
+                                                              int* __restrict__ idx0, float* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) float red_v[4][NCH * 256];
+    __shared__ __attribute__((aligned(16))) int red_i[4][NCH * 256];
+    const int p = blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int r0 = blockIdx.x * SW_ROWS;
+    if (r0 >= m) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ld = pd.ld;
+    const float* Z = zbuf + pd.z_off;
+    const int vec0 = vec_off(s0, 2 * p), vec1 = vec_off(s1, 2 * p + 1);
+    const float NEG = neg_inf();
+    const float norm = SG ? -logf((float)m + (float)n) : 0.f;
+    f32x4 bj[NCH], cj[NCH], cbv[NCH], za[NCH], zb[NCH];
+    int cbi[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        bj[c] = cj[c] = za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cbv[c] = f32x4{NEG, NEG, NEG, NEG};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cbi[c][e] = SW_NO_INDEX;
+            if (col + e < n) {
+                bj[c][e] = colvec[vec1 + col + e];
+                if (!SG) cj[c][e] = logsigmoid(zlogit[s1.row_off + col + e]);
+            }
+        }
+    }
+    auto process = [&](int i, const f32x4(&zz)[NCH]) {
+        const float a_i = rowvec[vec0 + i];
+        const float c_i = SG ? 0.f : logsigmoid(zlogit[s0.row_off + i]);
+        float best = NEG;
+        int bidx = SW_NO_INDEX;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = 4 * (lane + 64 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (col + e < n) {
+                    const float val = assign_value<SG>(zz[c][e], a_i, bj[c][e], norm, c_i, cj[c][e]);
+                    if (val > best) {  // columns ascend within a lane: the first maximum wins
+                        best = val;
+                        bidx = col + e;
+                    }
+                    if (val > cbv[c][e]) {  // rows ascend within a wave
+                        cbv[c][e] = val;
+                        cbi[c][e] = i;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int oj = __shfl_xor(bidx, off, 64);
+            if (ob > best || (ob == best && oj < bidx)) {
+                best = ob;
+                bidx = oj;
+            }
+        }
+        if (lane == 0) {
+            max0[s0.row_off + i] = best;
+            idx0[s0.row_off + i] = (bidx == SW_NO_INDEX) ? 0 : bidx;  // all-NaN row: stay in range
+        }
+    };
+    int i = r0 + wave;
+    if (i < m) sw_load_row<NCH>(Z + (size_t)i * ld, n, lane, za);
+#pragma unroll 1
+    for (int k = 0; k < SW_ROWS / 4; k += 2) {
+        if (i >= m) break;
+        if (i + 4 < m) sw_load_row<NCH>(Z + (size_t)(i + 4) * ld, n, lane, zb);
+        process(i, za);
+        i += 4;
+        if (i >= m) break;
+        if (i + 4 < m && k + 2 < SW_ROWS / 4) sw_load_row<NCH>(Z + (size_t)(i + 4) * ld, n, lane, za);
+        process(i, zb);
+        i += 4;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        *reinterpret_cast<f32x4*>(&red_v[wave][4 * (lane + 64 * c)]) = cbv[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red_i[wave][4 * (lane + 64 * c) + e] = cbi[c][e];
+    }
+    __syncthreads();
+    // block partial per column: plane 0 = best value, plane 1 = its row (as int bits), at part_off + block * 2 ld
+    float* part = partials + pd.part_off + (size_t)blockIdx.x * 2 * ld;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        float bv = red_v[0][j];
+        int bi = red_i[0][j];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ov = red_v[w][j];
+            const int oi = red_i[w][j];
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        part[j] = bv;
+        reinterpret_cast<int*>(part)[ld + j] = bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void extract_cols_kernel(const PairDesc* __restrict__ pairs, const SeqDesc* __restrict__ seqs,
+                                                           const int* __restrict__ counts, const float* __restrict__ partials,
+                                                           int* __restrict__ idx1) {
+    const int p = blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int nblk = ceil_div(m, SW_ROWS);
+    const float* part = partials + pd.part_off + j;
+    const size_t bs = (size_t)pd.ld * 2;
+    float bv = neg_inf();
+    int bi = SW_NO_INDEX;
+    for (int b = 0; b < nblk; ++b) {
+        const float ov = part[b * bs];
+        const int oi = reinterpret_cast<const int*>(part)[b * bs + pd.ld];
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    idx1[s1.row_off + j] = (bi == SW_NO_INDEX) ? 0 : bi;  // all-NaN column: stay in range
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------------------------------------------
+
+// GTSFM_SWEEP=lds forces the LDS-staged kernels for every width (A/B measurements)
+static bool use_register_rows(int max_n) {
+    static const char* which = getenv("GTSFM_SWEEP");
+    return max_n <= SW_MAX_COLS && !(which && which[0] == 'l');
+}
+
+static int chunks_for(int max_n) { return max_n <= 256 ? 1 : max_n <= 512 ? 2 : max_n <= 1024 ? 4 : 8; }
+
+#define SW_DISPATCH(nch, LAUNCH)    \
+    switch (nch) {                  \
+        case 1: { LAUNCH(1); break; } \
+        case 2: { LAUNCH(2); break; } \
+        case 4: { LAUNCH(4); break; } \
+        default: { LAUNCH(8); break; } \
+    }
+
+int launch_sinkhorn(const SweepArgs& a, float bin_score, int iters, hipStream_t stream) {
+    if (a.npairs <= 0) return GTSFM_OK;
+    if (!use_register_rows(a.max_n)) return launch_sinkhorn_lds(a, bin_score, iters, stream);
+    int rc = launch_sg_fill_bins(a, bin_score, stream);  // also sets v = 0 (superglue.py:143); the `ot` output reads the bins
+    if (rc != GTSFM_OK) return rc;
+    // All pairs of the batch go through one launch per iteration. Iterating groups of pairs whose couplings matrices fit
+    // the 256 MiB Infinity Cache together was measured (GTSFM_SINKHORN_GROUP_MB = 64 / 100 / 160 / 220 MiB at N = 2048,
+    // 32 pairs): 0.288 / 0.174 / 0.161 / 0.129 ms per iteration against 0.123 ms ungrouped -- the smaller grids leave CUs
+    // idle and pay the launch gaps more often than the cache saves. The switch stays for experiments.
+    static const char* env = getenv("GTSFM_SINKHORN_GROUP_MB");
+    const double budget_mb = env ? atof(env) : 0.0;
+    const double z_mb = (double)(a.max_m + 1) * ((a.max_n + 1 + 3) / 4 * 4) * 4.0 / (1024.0 * 1024.0);
+    int group = a.npairs;
+    if (budget_mb > 0.0) {
+        group = (int)(budget_mb / z_mb);
+        group = group < 1 ? 1 : (group > a.npairs ? a.npairs : group);
+    }
+    const int nch = chunks_for(a.max_n);
+    for (int pair0 = 0; pair0 < a.npairs; pair0 += group) {
+        const int g = (a.npairs - pair0 < group) ? a.npairs - pair0 : group;
+        const dim3 grid_rows(ceil_div(a.max_m + 1, SW_ROWS), g), grid_cols(ceil_div(a.max_n + 1, 256), g);
+        for (int it = 0; it < iters; ++it) {
+#define SW_LAUNCH_SINKHORN(N)                                                                                                          \
+    hipLaunchKernelGGL((sinkhorn_rows_kernel<N>), grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, \
+                       a.partials, bin_score, pair0)
+            SW_DISPATCH(nch, SW_LAUNCH_SINKHORN)
+            hipLaunchKernelGGL(sinkhorn_cols_kernel, grid_cols, dim3(256), 0, stream, a.pairs, a.seqs, a.counts, a.partials, a.colvec, pair0);
+        }
+    }
+    GTSFM_CHECK_LAUNCH("sinkhorn_rows/cols_kernel");
+    return GTSFM_OK;
+}
+
+int launch_double_softmax_lse(const SweepArgs& a, hipStream_t stream) {
+    if (a.npairs <= 0 || a.max_m <= 0 || a.max_n <= 0) return GTSFM_OK;
+    if (!use_register_rows(a.max_n)) return launch_double_softmax_lse_lds(a, stream);
+    const dim3 grid_rows(ceil_div(a.max_m, SW_ROWS), a.npairs), grid_cols(ceil_div(a.max_n, 256), a.npairs);
+#define SW_LAUNCH_LG(N) \
+    hipLaunchKernelGGL((lg_rows_kernel<N>), grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.partials)
+    SW_DISPATCH(chunks_for(a.max_n), SW_LAUNCH_LG)
+    hipLaunchKernelGGL(lg_cols_kernel, grid_cols, dim3(256), 0, stream, a.pairs, a.seqs, a.counts, a.partials, a.colvec);
+    GTSFM_CHECK_LAUNCH("lg_rows/cols_kernel");
+    return GTSFM_OK;
+}
+
+int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogit, float threshold, float* max0, int* idx0, int* idx1,
+                           int* matches, float* mscores, hipStream_t stream) {
+    if (a.npairs <= 0 || a.max_m <= 0 || a.max_n <= 0) return GTSFM_OK;
+    if (!use_register_rows(a.max_n)) return launch_extract_matches_lds(a, superglue, zlogit, threshold, max0, idx0, idx1, matches, mscores, stream);
+    const dim3 grid_rows(ceil_div(a.max_m, SW_ROWS), a.npairs), grid_cols(ceil_div(a.max_n, 256), a.npairs);
+#define SW_LAUNCH_EXTRACT_SG(N)                                                                                                         \
+    hipLaunchKernelGGL((extract_rows_kernel<true, N>), grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, \
+                       zlogit, max0, idx0, a.partials)
+#define SW_LAUNCH_EXTRACT_LG(N)                                                                                                          \
+    hipLaunchKernelGGL((extract_rows_kernel<false, N>), grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, \
+                       zlogit, max0, idx0, a.partials)
+    if (superglue) {
+        SW_DISPATCH(chunks_for(a.max_n), SW_LAUNCH_EXTRACT_SG)
+    } else {
+        SW_DISPATCH(chunks_for(a.max_n), SW_LAUNCH_EXTRACT_LG)
+    }
+    hipLaunchKernelGGL(extract_cols_kernel, grid_cols, dim3(256), 0, stream, a.pairs, a.seqs, a.counts, a.partials, idx1);
+    GTSFM_CHECK_LAUNCH("extract_rows/cols_kernel");
+    return launch_mutual_matches(a, threshold, max0, idx0, idx1, matches, mscores, stream);
+}

@@ -78,6 +78,11 @@ SIGNATURES = {
         [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "gtsfm_sinkhorn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p]),
+    "gtsfm_sinkhorn_f32": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
     "gtsfm_lg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p]),
     "gtsfm_lg_forward": (
         C.c_int,

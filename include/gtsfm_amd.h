@@ -181,6 +181,15 @@ int gtsfm_sg_forward(const float* blob_dev, int num_layers, float bin_score, int
                      const float* descriptors_dev, int sinkhorn_iters, float match_threshold, void* workspace_dev,
                      size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* ot_dev, void* stream);
 
+/* Log-space Sinkhorn iterations on their own (parity tests, roofline measurement).        replaces SG:141-147,150-170
+ * z_dev: couplings matrices back to back, pair p is (m[p]+1) x (n[p]+1) with row stride ld = (n[p]+1 rounded up to 4); the
+ * inner m x n block holds the scores, the dustbin row / column are filled with bin_score here (SG:156-160). After `iters`
+ * iterations u_dev [npairs][max(m)+1] and v_dev [npairs][max(n)+1] hold SG:143-146's u and v (Z + u + v - norm is the
+ * log optimal-transport matrix). Builds and uploads its own batch descriptor: synchronises `stream` once. */
+size_t gtsfm_sinkhorn_workspace_bytes(int npairs, const int32_t* m_host, const int32_t* n_host);
+int gtsfm_sinkhorn_f32(float* z_dev, int npairs, const int32_t* m_host, const int32_t* n_host, float bin_score, int iters,
+                       void* workspace_dev, size_t workspace_bytes, float* u_dev, float* v_dev, void* stream);
+
 /* LightGlue(features="superpoint").forward for a batch of pairs.          replaces LG (upstream LightGlue._forward;
  * reference call site gtsfm/frontend/matcher/lightglue_matcher.py:88-110). PARITY UNPINNED: the reference does not
  * vendor LightGlue's source; this follows the published upstream algorithm (see oracle/lightglue_oracle.py).

@@ -175,6 +175,41 @@ def test_superglue_sinkhorn_iteration_counts(sg_engine, sg_sd, iters):
     np.testing.assert_allclose(res["ot"], ora["ot"][0].numpy(), rtol=0, atol=2e-4)
 
 
+@pytest.mark.parametrize("shapes,iters", [([(257, 300), (1, 5), (300, 255), (64, 1)], 20), ([(2048, 2048), (2047, 1500)], 100),
+                                           ([(700, 513)], 1), ([(2100, 2300)], 20)],
+                         ids=["ragged_small", "n2048_it100", "one_iteration", "wider_than_2048_lds_path"])
+def test_sinkhorn_standalone_vs_oracle(lib, gpu_device, shapes, iters):
+    """The sweep kernels on their own (gtsfm_sinkhorn_f32) against superglue.py:150-170 as restated by the oracle: ragged
+    batches, widths on both sides of the 256-column register chunks, the LDS-staged path beyond 2048 columns."""
+    from gtsfm_amd.runtime import lib as L
+
+    rng = np.random.default_rng(5)
+    m = np.array([s[0] for s in shapes], dtype=np.int32)
+    n = np.array([s[1] for s in shapes], dtype=np.int32)
+    scores = [(rng.standard_normal(s) * 6.0).astype(np.float32) for s in shapes]
+    flat = []
+    for (mm, nn), sc in zip(shapes, scores):
+        ld = (nn + 1 + 3) // 4 * 4
+        z = np.full((mm + 1, ld), np.nan, dtype=np.float32)  # padding and dustbins must not be read / are overwritten
+        z[:mm, :nn] = sc
+        flat.append(z.reshape(-1))
+    z_dev = T(np.concatenate(flat)).to(gpu_device)
+    ws = torch.empty(int(lib.gtsfm_sinkhorn_workspace_bytes(len(shapes), m.ctypes.data, n.ctypes.data)), dtype=torch.uint8, device=gpu_device)
+    u = torch.zeros((len(shapes), int(m.max()) + 1), device=gpu_device)
+    v = torch.zeros((len(shapes), int(n.max()) + 1), device=gpu_device)
+    L.check(lib.gtsfm_sinkhorn_f32(z_dev.data_ptr(), len(shapes), m.ctypes.data, n.ctypes.data, 1.0, iters, ws.data_ptr(), ws.numel(),
+                                   u.data_ptr(), v.data_ptr(), _stream()), "sinkhorn")
+    u, v = u.cpu().numpy(), v.cpu().numpy()
+    for p, ((mm, nn), sc) in enumerate(zip(shapes, scores)):
+        with torch.no_grad():
+            ref = sgo.log_optimal_transport(T(sc)[None], torch.tensor(1.0), iters)[0].numpy()
+        couplings = np.full((mm + 1, nn + 1), 1.0, dtype=np.float32)
+        couplings[:mm, :nn] = sc
+        norm = -np.log(np.float32(mm + nn))
+        got = couplings + u[p, : mm + 1, None] + v[p, None, : nn + 1] - norm
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4)
+
+
 def test_superglue_plugin_contract(gpu_device, sg_sd, tmp_path):
     """SuperGlueMatcher.match vs the restated reference wrapper (gtsfm/frontend/matcher/superglue_matcher.py:75-113)
     and the reference's contract tests (tests/frontend/matcher/test_matcher_base.py:51-107,

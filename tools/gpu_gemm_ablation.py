@@ -13,6 +13,6 @@ if len(sys.argv) > 1:
         v = [bench.measure_gemm_roofline(lib, dev, *shape, reps=8)['frac'] * 100 for _ in range(5)]
         print(f"debug={os.environ.get('GTSFM_GEMM_DEBUG','0'):>2} gemm {shape}: " + " ".join(f"{x:.1f}" for x in v), flush=True)
 else:
-    for d in [int(x) for x in os.environ.get("DBG_LIST", "0,1,2,3").split(",")]:
+    for d in [int(x) for x in os.environ.get("DBG_LIST", "0").split(",")]:
         env = dict(os.environ, GTSFM_GEMM_DEBUG=str(d))
         subprocess.run([sys.executable, __file__, "child"], env=env)
