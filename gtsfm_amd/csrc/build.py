@@ -30,6 +30,20 @@ def sources():
     return sorted(CSRC.glob("*.hip"))
 
 
+def _included_headers(src: Path, known: dict) -> list:
+    """Project headers `src` includes, transitively (by file name; sorted)."""
+    import re
+
+    seen, todo = {}, [src]
+    while todo:
+        f = todo.pop()
+        for name in re.findall(r'#include\s+"(?:[^"]*/)?([^"/]+)"', f.read_text()):
+            if name in known and name not in seen:
+                seen[name] = known[name]
+                todo.append(known[name])
+    return [seen[k] for k in sorted(seen)]
+
+
 def _digest() -> str:
     h = hashlib.sha256()
     for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [PKG.parent / "include" / "gtsfm_amd.h"]):
@@ -55,7 +69,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         obj = OBJ_DIR / (src.stem + ".o")
         flags = [*FLAGS, *PER_FILE_FLAGS.get(src.name, [])]
         h = hashlib.sha256(" ".join(flags).encode())
-        for f in [src, *headers]:
+        for f in [src, *_included_headers(src, {x.name: x for x in headers})]:
             h.update(f.name.encode())
             h.update(f.read_bytes())
         obj_stamp = OBJ_DIR / (src.stem + ".digest")

@@ -47,6 +47,7 @@ struct GemmParams {
 int launch_conv3x3(const ConvParams& p, hipStream_t stream);
 int launch_gemm(const GemmParams& p, hipStream_t stream);
 bool gemm_uses_dma(int K, int ldw);  // whether launch_gemm picks the LDS-DMA kernel for row-major weights of this shape
+int launch_gemm_dma(const GemmParams& p, hipStream_t stream);  // gemm_dma_kernels.hip; launch_gemm dispatches to it
 int launch_pack_rows(const float* B, int ldb, int N, const int* n_dev, int K, float* out, hipStream_t stream);
 
 size_t packed_conv3x3_floats(int cin, int cout);

@@ -229,22 +229,7 @@ __device__ __forceinline__ void gemm_step(f32x16& c00, f32x16& c01, f32x16& c10,
 }
 
 
-// Developer timeline (tools/trace_gemm.hip builds this file with -DGTSFM_TRACE; nothing of it is in the product build).
-#ifdef GTSFM_TRACE
-__device__ unsigned long long* g_gemm_trace;  // [workgroup][wave][8]
-#define GT_DECL unsigned gt_prev = (unsigned)__builtin_amdgcn_s_memtime(); const unsigned gt_begin = gt_prev; unsigned gseg[6] = {0, 0, 0, 0, 0, 0};
-#define GT_SEG(k)                                                      \
-    {                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                             \
-        const unsigned gt_now = (unsigned)__builtin_amdgcn_s_memtime(); \
-        gseg[k] += gt_now - gt_prev;                                   \
-        gt_prev = gt_now;                                              \
-        __builtin_amdgcn_sched_barrier(0);                             \
-    }
-#else
-#define GT_DECL
-#define GT_SEG(k)
-#endif
+#include "trace.h"
 
 template <bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmParams p) {
@@ -480,162 +465,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmParams p) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// GEMM with both operands staged by LDS-DMA (K % 32 == 0 and row-major weights available). See
-// tools/experimental/gemm_dma.hip for the derivation of the swizzle and the round-1 measurements; same contract as
-// gemm_mfma_kernel.
-// LDS image of one operand stage: [128 rows][32 floats]; 16-byte chunk c of row r sits at chunk position
-// c ^ ((r >> 1) & 7), which puts the 16 lanes of every ds_read_b128 service group on distinct banks; the DMA writes
-// lane-linear, so the swizzle is applied to the per-lane global source address.
-// ---------------------------------------------------------------------------------------------------------------
-#define DM_KC 32
-#define DM_A_FLOATS (128 * DM_KC)
-#define DM_W_FLOATS (128 * DM_KC)
-#define DM_STAGE_FLOATS (DM_A_FLOATS + DM_W_FLOATS)
-
-__device__ __forceinline__ int dm_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
-
-template <bool HAS_RES>
-__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A 4096 | W 4096]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware order (speed only): workgroup b runs on XCD b % 8; the column blocks of one row tile get consecutive
-    // slots of ONE XCD, so the A tile is fetched into one L2 and re-read there
-    const int ncb = (p.N + 127) / 128, mtiles = (p.M + 127) / 128;
-    const int b = blockIdx.x, kx = b >> 3;
-    const int mt = (kx / ncb) * 8 + (b & 7), cb = kx % ncb;
-    if (mt >= mtiles) return;
-    const int m0 = mt * 128, n0 = cb * 128;
-    int M = p.m_dev ? *p.m_dev : p.M;
-    const int N = p.n_dev ? *p.n_dev : p.N;
-    if (p.tile_cnt_idx) {  // ragged batch with 128-row-aligned sequences 
-        const int c = p.live_counts[p.tile_cnt_idx[mt]];
-        const int r0 = p.tile_row0[mt];
-        if (r0 >= c) return;
-        M = min(M, m0 + c - r0);
-    }
-    if (m0 >= M || n0 >= N) return;
-    const int j = lane & 31, kh = lane >> 5;
-    const int nstages = p.K / DM_KC;
-
-    // DMA: a wave moves 4 instructions x 8 rows of A and of W per stage (rows 32 wave + 8 i + lane / 8)
-    const int drow = lane >> 3, dpos = lane & 7;
-    auto stage_dma = [&](int st, int buf) {
-        float* sA = lds + buf * DM_STAGE_FLOATS;
-        float* sW = sA + DM_A_FLOATS;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // A: every wave moves 32 rows (4 instructions x 8 rows)
-            const int r = 32 * wave + 8 * i + drow;  // LDS position = r * 32 + dpos * 4 floats
-            int ga = m0 + r;
-            ga = ga < M ? ga : M - 1;  // clamp: rows beyond M are computed and never stored
-            __builtin_amdgcn_global_load_lds(p.A + (size_t)ga * p.lda + st * DM_KC + dm_swz(r, dpos) * 4, sA + (32 * wave + 8 * i) * DM_KC, 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 128 / (8 * 4); ++i) {  // W: 128 rows over all waves
-            const int rb = (128 / 4) * wave + 8 * i, r = rb + drow;
-            int gw = n0 + r;
-            gw = gw < N ? gw : N - 1;  // clamp: columns beyond N are computed and never stored
-            __builtin_amdgcn_global_load_lds(p.wraw + (size_t)gw * p.ldw + st * DM_KC + dm_swz(r, dpos) * 4, sW + rb * DM_KC, 16, 0, 0);
-        }
-    };
-    auto frag = [&](const float* base, int row, int step) {  // 16-byte fragment: floats 8 step + 4 kh .. + 3 of `row`
-        return *reinterpret_cast<const f32x4*>(base + row * DM_KC + dm_swz(row, 2 * step + kh) * 4);
-    };
-
-    f32x16 c00, c01, c10, c11;  // (row half, column half) of the wave's 64 x 64 tile; lane = row, registers = columns
-    {
-        const int colb = n0 + 64 * wn + 4 * kh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cc = colb + 8 * (r >> 2) + (r & 3);
-            const float b0 = (p.bias && cc < N) ? p.bias[cc] : 0.f, b1 = (p.bias && cc + 32 < N) ? p.bias[cc + 32] : 0.f;
-            c00[r] = c10[r] = b0;
-            c01[r] = c11[r] = b1;
-        }
-    }
-    stage_dma(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA has landed ...
-    __syncthreads();                     // ... and so has everybody else's
-    for (int st = 0; st < nstages; ++st) {
-        const float* sA = lds + (st & 1) * DM_STAGE_FLOATS;
-        const float* sW = sA + DM_A_FLOATS;
-        __builtin_amdgcn_s_setprio(3);
-        if (st + 1 < nstages) stage_dma(st + 1, (st + 1) & 1);  // the other buffer was last read one stage ago
-        __builtin_amdgcn_s_setprio(0);
-        const int ra = 64 * wm + j, rw = 64 * wn + j;
-#pragma unroll
-        for (int s = 0; s < DM_KC / 8; ++s) {
-            const f32x4 a0 = frag(sA, ra, s), a1 = frag(sA, ra + 32, s);
-            const f32x4 b0 = frag(sW, rw, s), b1 = frag(sW, rw + 32, s);
-            // weights are the MFMA's A operand, activations its B operand (a lane then owns one output row)
-#define GS(e)                                                             \
-    c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.e, a0.e, c00, 0, 0, 0); \
-    c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a0.e, c01, 0, 0, 0); \
-    c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.e, a1.e, c10, 0, 0, 0); \
-    c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a1.e, c11, 0, 0, 0);
-            GS(x) GS(y) GS(z) GS(w)
-#undef GS
-        }
-        if (st + 1 < nstages) {
-            __builtin_amdgcn_s_setprio(3);
-            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-            __syncthreads();
-        }
-    }
-    // epilogue (as gemm_mfma_kernel: scale / ReLU as whole-tile passes, plain and residual variants are separate kernels,
-    // one divergent region per row tile, 16-byte stores when everything is 16-byte aligned)
-    if (p.alpha != 1.0f) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c00[r] *= p.alpha, c01[r] *= p.alpha, c10[r] *= p.alpha, c11[r] *= p.alpha;
-    }
-    if (p.relu) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c00[r] = fmaxf(c00[r], 0.f), c01[r] = fmaxf(c01[r], 0.f), c10[r] = fmaxf(c10[r], 0.f), c11[r] = fmaxf(c11[r], 0.f);
-    }
-    const bool vec_ok = ((N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!HAS_RES || (p.ldres & 3) == 0);
-    const int colb = n0 + 64 * wn + 4 * kh;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int row = m0 + 64 * wm + j + 32 * (t >> 1);
-        const int col0 = colb + 32 * (t & 1);
-        const f32x16& ct = (t == 0) ? c00 : (t == 1) ? c01 : (t == 2) ? c10 : c11;
-        if (row < M) {
-            float* crow = p.C + (size_t)row * p.ldc + p.c_coff;
-            if (vec_ok) {
-                if (!HAS_RES) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (col0 + 8 * q < N) *reinterpret_cast<f32x4*>(crow + col0 + 8 * q) = f32x4{ct[4 * q], ct[4 * q + 1], ct[4 * q + 2], ct[4 * q + 3]};
-                } else {
-                    const float* rrow = p.res + (size_t)row * p.ldres;
-                    const int last_col = N - 4;  // clamp instead of predicating the load (always valid)
-                    f32x4 rr[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) rr[q] = *reinterpret_cast<const f32x4*>(rrow + min(col0 + 8 * q, last_col));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (col0 + 8 * q < N)
-                            *reinterpret_cast<f32x4*>(crow + col0 + 8 * q) = rr[q] + f32x4{ct[4 * q], ct[4 * q + 1], ct[4 * q + 2], ct[4 * q + 3]};
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int col = col0 + 8 * (r >> 2) + (r & 3);
-                    if (col < N) crow[col] = HAS_RES ? p.res[(size_t)row * p.ldres + col] + ct[r] : ct[r];
-                }
-            }
-        }
-    }
-}
-
-
-bool gemm_uses_dma(int K, int ldw) {
-    static const char* which = getenv("GTSFM_GEMM");  // "mfma" forces the register-staged kernel (A/B measurements)
-    return K % DM_KC == 0 && ldw % 4 == 0 && !(which && which[0] == 'm');
-}
-
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
     GTSFM_CHECK_ARG(p.K % 8 == 0 && p.K >= 8, "gemm: K must be a multiple of 8 (got %d)", p.K);
     GTSFM_CHECK_ARG(p.lda % 4 == 0, "gemm: lda must be a multiple of 4 (got %d)", p.lda);
@@ -644,16 +473,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     // >= 2 workgroups per CU
     // Both operands by LDS-DMA when the caller has row-major weights and K is a multiple of the 32-deep stage
     // (GTSFM_GEMM=mfma forces the register-staged kernel below for A/B measurements)
-    if (p.wraw && gemm_uses_dma(p.K, p.ldw)) {
-        const dim3 grid(ceil_div(ceil_div(p.M, 128), 8) * 8 * ceil_div(p.N, 128));
-        const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
-        if (p.res)
-            hipLaunchKernelGGL(gemm_dma_kernel<true>, grid, dim3(256), lds_bytes, stream, p);
-        else
-            hipLaunchKernelGGL(gemm_dma_kernel<false>, grid, dim3(256), lds_bytes, stream, p);
-        GTSFM_CHECK_LAUNCH("gemm_dma_kernel");
-        return GTSFM_OK;
-    }
+    if (p.wraw && gemm_uses_dma(p.K, p.ldw)) return launch_gemm_dma(p, stream);
     GTSFM_CHECK_ARG(p.wpack, "gemm: no packed weights for the register-staged kernel");
     GemmParams q = p;
     const int ncb_total = ceil_div(p.N, 128), mtiles = ceil_div(p.M, MT_TILE_M);

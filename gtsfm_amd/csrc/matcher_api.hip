@@ -218,7 +218,7 @@ BatchDims batch_dims(int P, const int32_t* n0, const int32_t* n1, int ext) {
 }
 
 struct SgWorkspace {
-    size_t enc_in, ka, kb, x, qkv, att, mlp, md, pack, z, part, uv_row, uv_col, max0, idx0, idx1, total;
+    size_t enc_in, ka, kb, x, qkv, mlp, md, pack, z, part, uv_row, uv_col, max0, idx0, idx1, total;
 };
 
 SgWorkspace sg_workspace_layout(const BatchDims& d) {
@@ -235,7 +235,6 @@ SgWorkspace sg_workspace_layout(const BatchDims& d) {
     w.kb = take(T * 256);
     w.x = take(T * 512);
     w.qkv = take(T * 768);
-    w.att = take(T * 256);
     w.mlp = take(T * 512);
     w.md = take(T * 256);
     w.pack = take(d.pack_floats);
@@ -283,7 +282,6 @@ extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_scor
     float* kb = (float*)(wsp + ws.kb);
     float* X = (float*)(wsp + ws.x);
     float* QKV = (float*)(wsp + ws.qkv);
-    float* ATT = (float*)(wsp + ws.att);
     float* MLP = (float*)(wsp + ws.mlp);
     float* MD = (float*)(wsp + ws.md);
     float* PACK = (float*)(wsp + ws.pack);
@@ -319,11 +317,11 @@ extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_scor
     for (int l = 0; l < num_layers; ++l) {
         TRY(gemm(X, 512, 256, 768, QKV, 768, 0, nullptr, 0, 0));
         AttnParams ap;
-        ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = ATT, ap.ldo = 256;
+        // the attention output lands in the second half of cat([x, .]); attn.merge is folded into mlp.0 at load time
+        ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = X + 256, ap.ldo = 512;
         ap.problems = (l % 2 == 0) ? self_p : cross_p, ap.counts = counts, ap.scale = 0.125f, ap.heads = 4;
         TRY(launch_attention(ap, 2 * npairs, d.max_n, stream));
-        TRY(gemm(ATT, 256, 256, 256, X, 512, 256, nullptr, 0, 0));   // merge -> message half of cat([x, message])
-        TRY(gemm(X, 512, 512, 512, MLP, 512, 0, nullptr, 0, 1));       // mlp.0 (+BN folded) + ReLU
+        TRY(gemm(X, 512, 512, 512, MLP, 512, 0, nullptr, 0, 1));       // mlp.0 (+BN, merge folded) + ReLU
         TRY(gemm(MLP, 512, 512, 256, X, 512, 0, X, 512, 0));           // mlp.3, desc += delta
     }
     TRY(gemm(X, 512, 256, 256, MD, 256, 0, nullptr, 0, 0));  // final_proj
@@ -468,7 +466,7 @@ LgDims lg_dims(int P, const int32_t* n0, const int32_t* n1) {
 }
 
 struct LgWorkspace {
-    size_t xa, xb, qkv, att, mlp, md, enca, encb, inda, indb, indf, conf, mval, z_logit, pos, pack, z, part, uv_row, uv_col, max0, idx0, idx1,
+    size_t xa, xb, qkv, mlp, md, enca, encb, inda, indb, indf, conf, mval, z_logit, pos, pack, z, part, uv_row, uv_col, max0, idx0, idx1,
         m_int, ms_int, total;
 };
 
@@ -481,7 +479,7 @@ LgWorkspace lg_workspace_layout(const LgDims& d) {
         return r;
     };
     const size_t T = d.Tp;
-    w.xa = take(T * 512), w.xb = take(T * 512), w.qkv = take(T * 768), w.att = take(T * 256), w.mlp = take(T * 512), w.md = take(T * 256);
+    w.xa = take(T * 512), w.xb = take(T * 512), w.qkv = take(T * 768), w.mlp = take(T * 512), w.md = take(T * 256);
     w.enca = take(T * 64), w.encb = take(T * 64), w.inda = take(T), w.indb = take(T), w.indf = take(T);
     w.conf = take(T), w.mval = take(T), w.z_logit = take(T), w.pos = take(T);
     w.pack = take(d.pack_floats), w.z = take(d.z_floats), w.part = take(d.part_floats);
@@ -530,7 +528,6 @@ extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* m
     float* X = (float*)(wsp + ws.xa);
     float* Xalt = (float*)(wsp + ws.xb);
     float* QKV = (float*)(wsp + ws.qkv);
-    float* ATT = (float*)(wsp + ws.att);
     float* MLP = (float*)(wsp + ws.mlp);
     float* MD = (float*)(wsp + ws.md);
     float* enc = (float*)(wsp + ws.enca);
@@ -586,16 +583,15 @@ extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* m
         TRY(gemm(X, 512, 256, 768, QKV, 768, 0, nullptr, 0, 1.0f, live));
         TRY(launch_lg_rotary(QKV, 768, 512, enc, seqs, live, nseq, d.max_n, stream));
         AttnParams ap;
-        ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = ATT, ap.ldo = 256;
+        // the attention context lands in the second half of cat([x, .]); out_proj / to_out are folded into ffn.0 at load time
+        ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = X + 256, ap.ldo = 512;
         ap.problems = self_p, ap.counts = live, ap.scale = 0.125f, ap.heads = 4;
         TRY(launch_attention(ap, nseq, d.max_n, stream));
-        TRY(gemm(ATT, 256, 256, 256, X, 512, 256, nullptr, 0, 1.0f, live));
         TRY(ffn(X));
         // cross block: shared to_qk | to_v, both directions of the bidirectional attention, to_out, ffn
         TRY(gemm(X, 512, 256, 512, QKV, 768, 0, nullptr, 0, 1.0f, live));
         ap.q = QKV, ap.k = QKV, ap.v = QKV + 256, ap.problems = cross_p;
         TRY(launch_attention(ap, nseq, d.max_n, stream));
-        TRY(gemm(ATT, 256, 256, 256, X, 512, 256, nullptr, 0, 1.0f, live));
         TRY(ffn(X));
 
         // adaptive depth / final assignment inputs

@@ -9,16 +9,18 @@ SuperGlue (``thirdparty/SuperGluePretrainedNetwork/models/superglue.py``)
   * the attention head layout ``view(b, 64, 4, N)`` (superglue.py:104: channel = d*4 + h, head is the FAST axis) is
     made head-major (channel = h*64 + d) by permuting the rows of the three projections and the columns of ``merge``
   * the q/k/v projections are fused into one 256 -> 768 matrix
-  blob entry order: kenc (32,3) (64,32) (128,64) (256,128) (256,256); per GNN layer (768,256) (256,256) (512,512)
-  (256,512); final_proj (256,256).
+  * ``attn.merge`` is folded into ``mlp.0`` (``_fold_projection``)
+  blob entry order: kenc (32,3) (64,32) (128,64) (256,128) (256,256); per GNN layer (768,256) (512,512) (256,512);
+  final_proj (256,256).
 
 LightGlue (upstream ``cvg/LightGlue`` module names)
   * ``Wqkv`` rows are regrouped from ``h*192 + d*3 + j`` to ``j*256 + h*64 + d`` (q | k | v, head-major)
   * the cross block's ``to_qk`` and ``to_v`` are fused into one 256 -> 512 matrix
-  blob entry order: posenc.Wr (raw 64); per layer: Wqkv (768,256), out_proj (256,256), self ffn.0 (512,512), self LN
-  gamma (raw 512), beta (raw 512), self ffn.3 (256,512), cross to_qk|to_v (512,256), to_out (256,256), cross ffn.0,
-  LN gamma, beta, ffn.3, log_assignment final_proj (256,256), matchability w (raw 256), [token_confidence w (raw 256)
-  for all but the last layer]; the two scalar biases per layer travel separately (host floats).
+  * ``out_proj`` / ``to_out`` are folded into the following ``ffn.0`` (``_fold_projection``)
+  blob entry order: posenc.Wr (raw 64); per layer: Wqkv (768,256), self ffn.0 (512,512), self LN gamma (raw 512), beta
+  (raw 512), self ffn.3 (256,512), cross to_qk|to_v (512,256), cross ffn.0, LN gamma, beta, ffn.3, log_assignment
+  final_proj (256,256), matchability w (raw 256), [token_confidence w (raw 256) for all but the last layer]; the two
+  scalar biases per layer travel separately (host floats).
 """
 
 from __future__ import annotations
@@ -77,6 +79,17 @@ def _fold_bn(sd, conv: str, bn: Optional[str]) -> Tuple[np.ndarray, np.ndarray]:
     return w, b
 
 
+def _fold_projection(w0: np.ndarray, b0: np.ndarray, wp: np.ndarray, bp: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """The attention output projection (SuperGlue ``attn.merge``, LightGlue ``out_proj`` / ``to_out``) feeds only the
+    second half of the following ``cat([x, message])`` linear layer (superglue.py:117-118), so it folds into that layer
+    exactly: ``W0 [x ; Wp a + bp] + b0 = [W0x | W0m Wp] [x ; a] + (b0 + W0m bp)``. One 256 x 256 GEMM per block and the
+    round trip of the message through HBM disappear; the product is formed in float64 (closer to the exact result than
+    the reference's two fp32 steps)."""
+    half = w0.shape[1] // 2
+    assert wp.shape == (half, half)
+    return np.concatenate([w0[:, :half], w0[:, half:] @ wp], 1), b0 + w0[:, half:] @ bp
+
+
 def superglue_entries(sd: Mapping[str, torch.Tensor]) -> List[Entry]:
     entries: List[Entry] = []
     for i in range(5):  # kenc.encoder: conv at 0,3,6,9,12; BN at 1,4,7,10
@@ -89,9 +102,8 @@ def superglue_entries(sd: Mapping[str, torch.Tensor]) -> List[Entry]:
             w, b = _fold_bn(sd, f"{p}.attn.proj.{j}", None)
             ws.append(w[HEAD_PERM]), bs.append(b[HEAD_PERM])
         entries.append((0, np.concatenate(ws, 0), np.concatenate(bs, 0)))
-        w, b = _fold_bn(sd, f"{p}.attn.merge", None)
-        entries.append((0, w[:, HEAD_PERM], b))
-        entries.append((0, *_fold_bn(sd, f"{p}.mlp.0", f"{p}.mlp.1")))
+        wm, bm = _fold_bn(sd, f"{p}.attn.merge", None)
+        entries.append((0, *_fold_projection(*_fold_bn(sd, f"{p}.mlp.0", f"{p}.mlp.1"), wm[:, HEAD_PERM], bm)))
         entries.append((0, *_fold_bn(sd, f"{p}.mlp.3", None)))
     entries.append((0, *_fold_bn(sd, "final_proj", None)))
     return entries
@@ -254,22 +266,21 @@ def lightglue_entries(sd: Mapping[str, torch.Tensor]) -> Tuple[List[Entry], np.n
     for l in range(n_layers):
         p = f"transformers.{l}"
         entries.append((0, _f64(sd[f"{p}.self_attn.Wqkv.weight"])[qkv_perm], _f64(sd[f"{p}.self_attn.Wqkv.bias"])[qkv_perm]))
-        entries.append((0, _f64(sd[f"{p}.self_attn.out_proj.weight"]), _f64(sd[f"{p}.self_attn.out_proj.bias"])))
 
-        def ffn(blk):
-            entries.append((0, _f64(sd[f"{p}.{blk}.ffn.0.weight"]), _f64(sd[f"{p}.{blk}.ffn.0.bias"])))
+        def ffn(blk, proj):
+            wp, bp = _f64(sd[f"{p}.{blk}.{proj}.weight"]), _f64(sd[f"{p}.{blk}.{proj}.bias"])
+            entries.append((0, *_fold_projection(_f64(sd[f"{p}.{blk}.ffn.0.weight"]), _f64(sd[f"{p}.{blk}.ffn.0.bias"]), wp, bp)))
             entries.append((1, _f64(sd[f"{p}.{blk}.ffn.1.weight"]), None))
             entries.append((1, _f64(sd[f"{p}.{blk}.ffn.1.bias"]), None))
             entries.append((0, _f64(sd[f"{p}.{blk}.ffn.3.weight"]), _f64(sd[f"{p}.{blk}.ffn.3.bias"])))
 
-        ffn("self_attn")
+        ffn("self_attn", "out_proj")
         entries.append((
             0,
             np.concatenate([_f64(sd[f"{p}.cross_attn.to_qk.weight"]), _f64(sd[f"{p}.cross_attn.to_v.weight"])], 0),
             np.concatenate([_f64(sd[f"{p}.cross_attn.to_qk.bias"]), _f64(sd[f"{p}.cross_attn.to_v.bias"])], 0),
         ))
-        entries.append((0, _f64(sd[f"{p}.cross_attn.to_out.weight"]), _f64(sd[f"{p}.cross_attn.to_out.bias"])))
-        ffn("cross_attn")
+        ffn("cross_attn", "to_out")
         a = f"log_assignment.{l}"
         entries.append((0, _f64(sd[f"{a}.final_proj.weight"]), _f64(sd[f"{a}.final_proj.bias"])))
         entries.append((1, _f64(sd[f"{a}.matchability.weight"]).reshape(-1), None))

@@ -46,19 +46,19 @@ def test_match_descriptor_block(built_library):
 
 
 def test_superglue_weight_preparation_is_equivalent(built_library):
-    """BatchNorm folding + head permutation + q/k/v fusion reproduce one propagation layer of the reference in
-    float64 (superglue.py:92-119)."""
+    """BatchNorm folding + head permutation + q/k/v fusion + the merge projection folded into mlp.0 reproduce one
+    propagation layer of the reference in float64 (superglue.py:92-119)."""
     from gtsfm_amd.runtime.matcher_engine import HEAD_PERM, superglue_entries
     from oracle import superglue_oracle as sgo
 
     sd = synthetic.synthetic_superglue_state_dict(num_layers=1)
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     entries = superglue_entries(sd)
-    assert len(entries) == 5 + 4 + 1
+    assert len(entries) == 5 + 3 + 1
     x = torch.randn((1, 256, 40), dtype=torch.float64)
     src = torch.randn((1, 256, 33), dtype=torch.float64)
     ref = sgo._propagation(sd64, "gnn.layers.0", x, src)[0].T.numpy()
-    (_, wqkv, bqkv), (_, wm, bm), (_, w0, b0), (_, w1, b1) = entries[5:9]
+    (_, wqkv, bqkv), (_, w0, b0), (_, w1, b1) = entries[5:8]
     xt, st = x[0].T.numpy(), src[0].T.numpy()
     q = xt @ wqkv[:256].T + bqkv[:256]
     k = st @ wqkv[256:512].T + bqkv[256:512]
@@ -68,8 +68,7 @@ def test_superglue_weight_preparation_is_equivalent(built_library):
         s = q[:, 64 * h : 64 * h + 64] @ k[:, 64 * h : 64 * h + 64].T / 8.0
         p = np.exp(s - s.max(1, keepdims=True))
         att[:, 64 * h : 64 * h + 64] = (p / p.sum(1, keepdims=True)) @ v[:, 64 * h : 64 * h + 64]
-    msg = att @ wm.T + bm
-    hid = np.maximum(np.concatenate([xt, msg], 1) @ w0.T + b0, 0)
+    hid = np.maximum(np.concatenate([xt, att], 1) @ w0.T + b0, 0)  # cat([x, attention output]): merge lives inside w0
     out = hid @ w1.T + b1
     np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
     assert sorted(HEAD_PERM.tolist()) == list(range(256))
@@ -80,7 +79,7 @@ def test_lightglue_weight_preparation_regroups_qkv(built_library):
 
     sd = synthetic.synthetic_lightglue_state_dict(num_layers=2)
     entries, match_bias, conf_bias = lightglue_entries(sd)
-    assert len(entries) == 1 + 2 * 14 + 1 and match_bias.shape == (2,) and conf_bias.shape == (2,)
+    assert len(entries) == 1 + 2 * 12 + 1 and match_bias.shape == (2,) and conf_bias.shape == (2,)
     w = sd["transformers.0.self_attn.Wqkv.weight"].double().numpy()
     x = np.random.default_rng(0).standard_normal((5, 256))
     qkv = (x @ w.T).reshape(5, 4, 64, 3)  # upstream unflatten(-1, (heads, head_dim, 3))
