@@ -40,6 +40,10 @@ struct GemmParams {
     const int* tile_cnt_idx;  // [M tiles] index into live_counts
     const int* tile_row0;     // [M tiles] first row of the tile within its sequence
     const int* live_counts;
+    // optional rotary epilogue (LDS-DMA kernel only): columns [0, rot_cols) are rotated pairwise with the per-row (cos, sin)
+    // pairs rot_enc[row][f][2], f = (column % 64) / 2 (LightGlue apply_cached_rotary_emb on the q and k parts of Wqkv)
+    const float* rot_enc;
+    int rot_cols;
     int nb_per_wg;  // filled by the launcher: 128-column blocks one workgroup walks
     int debug;      // developer ablation switches (GTSFM_GEMM_DEBUG): 1 = skip epilogue, 2 = skip A loads
 };

@@ -213,6 +213,226 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmParams p) {
 
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// Column-walking form (round 2). The cycle budget of the one-tile-per-workgroup kernel above at 131072 x 256 -> 768
+// (tools/trace_gemm_dma.hip, profiles/r02_gemm_dma_cycle_budget_before.txt): wave lifetime 81 k cycles per tile of which
+// the prologue (kernel arguments, bias, first DMA round trip, barrier) takes 17.7 k and the epilogue 7.5 k -- a third of
+// a wave's life without a single MFMA, so the SIMD's other wave runs alone (68 % of the matrix pipe) or both idle;
+// issuing the 8 LDS-DMA pieces of a stage costs 1.7 k cycles of 64-bit address arithmetic. Here
+//   * a workgroup walks `nb_per_wg` column blocks of its row tile with ONE continuous stage pipeline: the DMA of the next
+//     block's first stage is issued before the last MFMAs of the current block, so the prologue is paid once per
+//     workgroup and an epilogue costs only its own issue time (its stores drain under the next block's MFMAs);
+//   * DMA sources are a uniform base (SGPR pair, advanced per stage) plus 32-bit per-lane offsets computed once;
+//   * the bias joins in the epilogue (its loads fly during the block), the residual rows / rotary cos-sin pairs of a block
+//     are requested before its last stage's MFMAs and are in registers when the epilogue starts;
+//   * ROT: LightGlue's rotary embedding (apply_cached_rotary_emb) on the q and k column blocks in the epilogue -- a lane
+//     owns a row and adjacent register pairs are the (2f, 2f + 1) feature pairs, enc = [token][f][cos, sin].
+// ---------------------------------------------------------------------------------------------------------------
+template <bool HAS_RES, bool ROT>
+__global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A 4096 | W 4096]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int M = p.m_dev ? *p.m_dev : p.M;
+    const int N = p.n_dev ? *p.n_dev : p.N;
+    // XCD-aware order (speed only): workgroup b runs on XCD b % 8; the column groups of one row tile get consecutive slots of
+    // ONE XCD, so the A tile is fetched into one L2 and re-read there
+    const int ncb_total = (p.N + 127) / 128, mtiles = (p.M + 127) / 128;
+    const int groups = (ncb_total + p.nb_per_wg - 1) / p.nb_per_wg;
+    const int b = blockIdx.x, kx = b >> 3;
+    const int mt = (kx / groups) * 8 + (b & 7), cb0 = (kx % groups) * p.nb_per_wg;
+    if (mt >= mtiles) return;
+    const int m0 = mt * 128;
+    if (p.tile_cnt_idx) {  // ragged batch with 128-row-aligned sequences
+        const int c = p.live_counts[p.tile_cnt_idx[mt]];
+        const int r0 = p.tile_row0[mt];
+        if (r0 >= c) return;
+        M = min(M, m0 + c - r0);
+    }
+    if (m0 >= M) return;
+    const int nblk = min(p.nb_per_wg, (N + 127) / 128 - cb0);  // column blocks with at least one live column
+    if (nblk <= 0) return;
+    const int j = lane & 31, kh = lane >> 5;
+    const int nstages = p.K / DM_KC;
+    const int total = nblk * nstages;
+
+    // DMA: a wave moves 4 pieces x 8 rows of A and of W per stage (LDS rows 32 wave + 8 i + lane / 8); rows beyond M / N
+    // are clamped (computed, never stored)
+    const int drow = lane >> 3, dpos = lane & 7;
+    const char* baseA = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
+    const char* baseW = reinterpret_cast<const char*>(p.wraw);
+    unsigned offA[4], offW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 32 * wave + 8 * i + drow;
+        offA[i] = (unsigned)(min(r, M - 1 - m0) * p.lda + dm_swz(r, dpos) * 4) * 4u;
+    }
+    auto set_w_offsets = [&](int cbi) {
+        const int n0 = (cb0 + cbi) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 32 * wave + 8 * i + drow;
+            offW[i] = (unsigned)(min(n0 + r, N - 1) * p.ldw + dm_swz(r, dpos) * 4) * 4u;
+        }
+    };
+    int dcb = 0, dst = 0, dit = 0;  // the next stage to fetch: column block, stage within it, running index
+    auto fetch_next = [&]() {
+        if (dst == 0) set_w_offsets(dcb);
+        float* sA = lds + (dit & 1) * DM_STAGE_FLOATS;
+        float* sW = sA + DM_A_FLOATS;
+        const char* a = baseA + (size_t)dst * (DM_KC * 4);
+        const char* w = baseW + (size_t)dst * (DM_KC * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(a + offA[i]), sA + (32 * wave + 8 * i) * DM_KC, 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(w + offW[i]), sW + (32 * wave + 8 * i) * DM_KC, 16, 0, 0);
+        ++dit;
+        if (++dst == nstages) dst = 0, ++dcb;
+    };
+    auto frag = [&](const float* base, int row, int step) {  // 16-byte fragment: floats 8 step + 4 kh .. + 3 of `row`
+        return *reinterpret_cast<const f32x4*>(base + row * DM_KC + dm_swz(row, 2 * step + kh) * 4);
+    };
+
+    f32x16 c00, c01, c10, c11;  // (row half, column half) of the wave's 64 x 64 tile; lane = row, registers = columns
+    f32x4 bia[8];               // bias of the lane's 32 columns
+    f32x4 aux[16];              // residual values (HAS_RES) / rotary (cos, sin) pairs (ROT) of the block being finished
+    const bool vec_ok = ((N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!HAS_RES || (p.ldres & 3) == 0);
+    const int nbias = (p.N + 63) / 64 * 64;
+    const int row_lo = m0 + 64 * wm + j;  // the lane's rows: row_lo and row_lo + 32
+
+    GT_DECL
+    fetch_next();
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA has landed ...
+    __syncthreads();                     // ... and so has everybody else's
+    GT_SEG(0)
+    int cbi = 0, st = 0;
+#pragma unroll 1
+    for (int it = 0; it < total; ++it) {
+        const float* sA = lds + (it & 1) * DM_STAGE_FLOATS;
+        const float* sW = sA + DM_A_FLOATS;
+        const int n0 = (cb0 + cbi) * 128;
+        const int colb = n0 + 64 * wn + 4 * kh;
+        const bool last = st == nstages - 1;
+        const bool rot = ROT && n0 < p.rot_cols;
+        __builtin_amdgcn_s_setprio(3);
+        if (st == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c00[r] = c01[r] = c10[r] = c11[r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int cc = colb + 32 * (q >> 2) + 8 * (q & 3);
+                bia[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && cc < nbias) bia[q] = *reinterpret_cast<const f32x4*>(p.bias + cc);
+            }
+        }
+        if (dit < total) fetch_next();  // the other buffer was last read one stage ago
+        if (last) {
+            if (HAS_RES && vec_ok) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = row_lo + 32 * (t >> 1);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int col = colb + 32 * (t & 1) + 8 * q;
+                        aux[4 * t + q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (row < M && col < N) aux[4 * t + q] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldres + col);
+                    }
+                }
+            }
+            if (rot) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = row_lo + 32 * h;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        aux[8 * h + q] = f32x4{1.f, 0.f, 1.f, 0.f};
+                        if (row < M) aux[8 * h + q] = *reinterpret_cast<const f32x4*>(p.rot_enc + (size_t)row * 64 + 4 * kh + 8 * q);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        GT_SEG(1)
+        const int ra = 64 * wm + j, rw = 64 * wn + j;
+#pragma unroll
+        for (int s = 0; s < DM_KC / 8; ++s) {
+            const f32x4 a0 = frag(sA, ra, s), a1 = frag(sA, ra + 32, s);
+            const f32x4 b0 = frag(sW, rw, s), b1 = frag(sW, rw + 32, s);
+            // weights are the MFMA's A operand, activations its B operand (a lane then owns one output row)
+#define GS(e)                                                             \
+    c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.e, a0.e, c00, 0, 0, 0); \
+    c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a0.e, c01, 0, 0, 0); \
+    c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.e, a1.e, c10, 0, 0, 0); \
+    c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a1.e, c11, 0, 0, 0);
+            GS(x) GS(y) GS(z) GS(w)
+#undef GS
+        }
+        GT_SEG(2)
+        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): next stage's DMA, bias / residual / rotary loads; older stores are long done
+        if (it + 1 < total) __syncthreads();
+        GT_SEG(3)
+        if (last) {
+            // epilogue of column block cbi; its stores drain under the next block's MFMAs
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                c00[r] += bia[r >> 2][r & 3], c10[r] += bia[r >> 2][r & 3];
+                c01[r] += bia[4 + (r >> 2)][r & 3], c11[r] += bia[4 + (r >> 2)][r & 3];
+            }
+            if (p.alpha != 1.0f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c00[r] *= p.alpha, c01[r] *= p.alpha, c10[r] *= p.alpha, c11[r] *= p.alpha;
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    c00[r] = fmaxf(c00[r], 0.f), c01[r] = fmaxf(c01[r], 0.f), c10[r] = fmaxf(c10[r], 0.f), c11[r] = fmaxf(c11[r], 0.f);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = row_lo + 32 * (t >> 1);
+                const int col0 = colb + 32 * (t & 1);
+                const f32x16& ct = (t == 0) ? c00 : (t == 1) ? c01 : (t == 2) ? c10 : c11;
+                if (row < M) {
+                    float* crow = p.C + (size_t)row * p.ldc + p.c_coff;
+                    if (vec_ok) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v = f32x4{ct[4 * q], ct[4 * q + 1], ct[4 * q + 2], ct[4 * q + 3]};
+                            if (rot) {  // (x0, x1) -> (x0 c - x1 s, x1 c + x0 s) per feature pair, as apply_cached_rotary_emb
+                                const f32x4 e = aux[8 * (t >> 1) + 4 * (t & 1) + q];
+                                v = f32x4{(v.x * e.x) + ((-v.y) * e.y), (v.y * e.x) + (v.x * e.y), (v.z * e.z) + ((-v.w) * e.w), (v.w * e.z) + (v.z * e.w)};
+                            }
+                            if (HAS_RES) v = aux[4 * t + q] + v;
+                            if (col0 + 8 * q < N) *reinterpret_cast<f32x4*>(crow + col0 + 8 * q) = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int col = col0 + 8 * (r >> 2) + (r & 3);
+                            if (col < N) crow[col] = HAS_RES ? p.res[(size_t)row * p.ldres + col] + ct[r] : ct[r];
+                        }
+                    }
+                }
+            }
+        }
+        GT_SEG(4)
+        if (++st == nstages) st = 0, ++cbi;
+    }
+#ifdef GTSFM_TRACE
+    if (lane == 0 && g_gemm_trace) {
+        unsigned long long* o = g_gemm_trace + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int k = 0; k < 5; ++k) o[k] = gseg[k];
+        o[5] = (unsigned)__builtin_amdgcn_s_memtime() - gt_begin;
+        o[6] = nblk;
+        o[7] = nstages;
+    }
+#endif
+}
+
 bool gemm_uses_dma(int K, int ldw) {
     static const char* which = getenv("GTSFM_GEMM");  // "mfma" forces the register-staged kernel (A/B measurements)
     return K % DM_KC == 0 && ldw % 4 == 0 && !(which && which[0] == 'm');
@@ -220,12 +440,35 @@ bool gemm_uses_dma(int K, int ldw) {
 
 int launch_gemm_dma(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0) return GTSFM_OK;
-    const dim3 grid(ceil_div(ceil_div(p.M, 128), 8) * 8 * ceil_div(p.N, 128));
+    static const char* form = getenv("GTSFM_GEMM_DMA");  // "tile": the one-tile-per-workgroup kernel (A/B measurements)
+    const int ncb = ceil_div(p.N, 128), mtiles = ceil_div(p.M, 128);
+    if (form && form[0] == 't' && !p.rot_enc) {
+        const dim3 grid(ceil_div(mtiles, 8) * 8 * ncb);
+        const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
+        if (p.res)
+            hipLaunchKernelGGL(gemm_dma_kernel<true>, grid, dim3(256), lds_bytes, stream, p);
+        else
+            hipLaunchKernelGGL(gemm_dma_kernel<false>, grid, dim3(256), lds_bytes, stream, p);
+        GTSFM_CHECK_LAUNCH("gemm_dma_kernel");
+        return GTSFM_OK;
+    }
+    GTSFM_CHECK_ARG(!(p.rot_enc && p.res), "gemm: rotary epilogue and residual are exclusive");
+    GTSFM_CHECK_ARG(!p.rot_enc || (p.rot_cols % 128 == 0 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.c_coff % 4 == 0), "gemm: rotary epilogue needs 16-byte aligned rows");
+    // column blocks per workgroup: the whole row of blocks when that still leaves two full rounds of workgroups (512 slots)
+    GemmParams q = p;
+    int nbw = ncb;
+    while (nbw > 1 && (long long)mtiles * ceil_div(ncb, nbw) < 1024) nbw = (nbw + 1) / 2;
+    static const char* env = getenv("GTSFM_GEMM_NB");
+    if (env && atoi(env) > 0) nbw = atoi(env) < ncb ? atoi(env) : ncb;
+    q.nb_per_wg = nbw;
+    const dim3 grid(ceil_div(mtiles, 8) * 8 * ceil_div(ncb, nbw));
     const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
-    if (p.res)
-        hipLaunchKernelGGL(gemm_dma_kernel<true>, grid, dim3(256), lds_bytes, stream, p);
+    if (q.rot_enc)
+        hipLaunchKernelGGL((gemm_dma_walk_kernel<false, true>), grid, dim3(256), lds_bytes, stream, q);
+    else if (q.res)
+        hipLaunchKernelGGL((gemm_dma_walk_kernel<true, false>), grid, dim3(256), lds_bytes, stream, q);
     else
-        hipLaunchKernelGGL(gemm_dma_kernel<false>, grid, dim3(256), lds_bytes, stream, p);
-    GTSFM_CHECK_LAUNCH("gemm_dma_kernel");
+        hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false>), grid, dim3(256), lds_bytes, stream, q);
+    GTSFM_CHECK_LAUNCH("gemm_dma_walk_kernel");
     return GTSFM_OK;
 }

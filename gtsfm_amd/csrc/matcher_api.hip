@@ -555,7 +555,7 @@ extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* m
     BlobCursor cur = {wts, 0};
     // masked GEMM over the padded token rows; `cnt` selects which count array gates the tiles
     auto gemm = [&](const float* A, int lda, int K, int N, float* C, int ldc, int coff, const float* res, int ldres, float alpha,
-                    const int* cnt) -> int {
+                    const int* cnt, const float* rot_enc = nullptr, int rot_cols = 0) -> int {
         const float *w, *b, *raw;
         cur.linear(N, K, &w, &b, &raw);
         GemmParams g;
@@ -563,6 +563,7 @@ extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* m
         g.A = A, g.lda = lda, g.M = d.Tp, g.K = K, g.wpack = w, g.wraw = raw, g.ldw = K, g.bias = b, g.N = N;
         g.C = C, g.ldc = ldc, g.c_coff = coff, g.res = res, g.ldres = ldres, g.alpha = alpha, g.relu = 0;
         g.tile_cnt_idx = tile_idx, g.tile_row0 = tile_row0, g.live_counts = cnt;
+        g.rot_enc = rot_enc, g.rot_cols = rot_cols;
         return launch_gemm(g, stream);
     };
     auto ffn = [&](float* Xc) -> int {  // x + ffn(cat[x, message])
@@ -580,8 +581,10 @@ extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* m
 
     for (int l = 0; l < num_layers; ++l) {
         // self block: Wqkv, rotary on q and k, attention, out_proj, ffn
-        TRY(gemm(X, 512, 256, 768, QKV, 768, 0, nullptr, 0, 1.0f, live));
-        TRY(launch_lg_rotary(QKV, 768, 512, enc, seqs, live, nseq, d.max_n, stream));
+        // rotary on q and k: in the Wqkv epilogue of the LDS-DMA GEMM, a kernel of its own otherwise
+        const bool fused_rotary = gemm_uses_dma(256, 256);
+        TRY(gemm(X, 512, 256, 768, QKV, 768, 0, nullptr, 0, 1.0f, live, fused_rotary ? enc : nullptr, 512));
+        if (!fused_rotary) TRY(launch_lg_rotary(QKV, 768, 512, enc, seqs, live, nseq, d.max_n, stream));
         AttnParams ap;
         // the attention context lands in the second half of cat([x, .]); out_proj / to_out are folded into ffn.0 at load time
         ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = X + 256, ap.ldo = 512;

@@ -33,7 +33,7 @@ __global__ void sg_encode_input_kernel(const float* __restrict__ kpts, const flo
     }
 }
 
-// LightGlue: normalised keypoints (k - size/2) / (max(size)/2) -> Fourier features cos/sin(Wr k): enc[t] = [cos(32) | sin(32)]
+// LightGlue: normalised keypoints (k - size/2) / (max(size)/2) -> Fourier features cos/sin(Wr k): enc[t] = [f][cos, sin], f < 32
 __global__ void lg_posenc_kernel(const float* __restrict__ kpts, const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
                                  const float* __restrict__ Wr /*[32][2]*/, float* __restrict__ enc /*[T][64]*/) {
     const int s = blockIdx.y;
@@ -49,12 +49,14 @@ __global__ void lg_posenc_kernel(const float* __restrict__ kpts, const SeqDesc* 
         const float x = (kpts[ti * 2 + 0] - sx) / scale;
         const float y = (kpts[ti * 2 + 1] - sy) / scale;
         const float pr = x * w0 + y * w1;  // F.linear without bias: sum over 2 inputs
-        enc[t * 64 + f] = cosf(pr);
-        enc[t * 64 + 32 + f] = sinf(pr);
+        enc[t * 64 + 2 * f] = cosf(pr);  // [f][cos, sin]: one 16-byte load gives the GEMM epilogue two feature pairs' factors
+        enc[t * 64 + 2 * f + 1] = sinf(pr);
     }
 }
 
-// Rotary embedding on the q and k parts of a packed [T][ld] buffer (head-major, 4 heads x 64):
+// Rotary embedding on the q and k parts of a packed [T][ld] buffer (head-major, 4 heads x 64). Stand-alone form: the
+// LDS-DMA GEMM applies it in the Wqkv epilogue (gemm_dma_walk_kernel<false, true>); this kernel serves the register-staged
+// GEMM (GTSFM_GEMM=mfma).
 //   out[2f] = t[2f] cos_f - t[2f+1] sin_f ; out[2f+1] = t[2f+1] cos_f + t[2f] sin_f     (same freqs for every head)
 __global__ void lg_rotary_kernel(float* __restrict__ qkv, int ld, int ncols /*512: q and k*/, const float* __restrict__ enc,
                                  const SeqDesc* __restrict__ seqs, const int* __restrict__ counts) {
@@ -67,7 +69,7 @@ __global__ void lg_rotary_kernel(float* __restrict__ qkv, int ld, int ncols /*51
         const int f = pp & 31;  // frequency index within the head
         const size_t t = (size_t)sq.row_off + i;
         float* x = qkv + t * ld + pp * 2;
-        const float c = enc[t * 64 + f], sn = enc[t * 64 + 32 + f];
+        const float c = enc[t * 64 + 2 * f], sn = enc[t * 64 + 2 * f + 1];
         const float x1 = x[0], x2 = x[1];
         x[0] = (x1 * c) + ((-x2) * sn);
         x[1] = (x2 * c) + (x1 * sn);

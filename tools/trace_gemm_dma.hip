@@ -78,21 +78,22 @@ int main(int argc, char** argv) {
 #ifdef GTSFM_TRACE
     std::vector<unsigned long long> t(nrec);
     hipMemcpy(t.data(), trace, nrec * 8, hipMemcpyDeviceToHost);
-    double sum[6] = {0}; size_t waves = 0; double stages = 0;
+    double sum[6] = {0}; size_t waves = 0; double stages = 0, tiles = 0;
     for (size_t w = 0; w < nrec / 8; ++w) {
         const unsigned long long* o = &t[w * 8];
         if (!o[6]) continue;
         for (int k = 0; k < 6; ++k) sum[k] += (double)o[k];
-        stages += (double)o[7];
+        stages += (double)(o[6] * o[7]);
+        tiles += (double)o[6];
         ++waves;
     }
-    printf("%zu waves (one 128 x 128 tile per workgroup), %.0f stages of 32 each; 64 MFMAs per stage = 4096 cycles of own pipe time (8192 when shared by 2 waves)\n", waves, stages / waves);
-    printf("  prologue (bias, first DMA, barrier)   %8.0f cycles per tile\n", sum[0] / waves);
-    printf("  DMA issue                             %8.0f cycles per stage\n", sum[1] / stages);
+    printf("%zu waves, %.1f tiles of 128 x 128 per workgroup, %.0f stages of 32 per tile; 64 MFMAs per stage = 4096 cycles of own pipe time (8192 when shared by 2 waves)\n", waves, tiles / waves, stages / tiles);
+    printf("  prologue (first DMA, barrier)         %8.0f cycles per workgroup\n", sum[0] / waves);
+    printf("  DMA issue (+ init / aux loads)        %8.0f cycles per stage\n", sum[1] / stages);
     printf("  LDS reads + MFMAs                     %8.0f cycles per stage\n", sum[2] / stages);
     printf("  vmcnt(0) + barrier                    %8.0f cycles per stage\n", sum[3] / stages);
-    printf("  epilogue                              %8.0f cycles per tile\n", sum[4] / waves);
-    printf("  wave lifetime                         %8.0f cycles per tile (shares: prologue %.1f %%, dma %.1f %%, mfma %.1f %%, wait %.1f %%, epilogue %.1f %%)\n", sum[5] / waves,
+    printf("  epilogue                              %8.0f cycles per tile\n", sum[4] / tiles);
+    printf("  wave lifetime                         %8.0f cycles per tile (shares: prologue %.1f %%, dma %.1f %%, mfma %.1f %%, wait %.1f %%, epilogue %.1f %%)\n", sum[5] / tiles,
            100 * sum[0] / sum[5], 100 * sum[1] / sum[5], 100 * sum[2] / sum[5], 100 * sum[3] / sum[5], 100 * sum[4] / sum[5]);
     return 0;
 #endif
