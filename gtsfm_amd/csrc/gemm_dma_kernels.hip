@@ -276,21 +276,16 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p) {
             offW[i] = (unsigned)(min(n0 + r, N - 1) * p.ldw + dm_swz(r, dpos) * 4) * 4u;
         }
     };
-    int dcb = 0, dst = 0, dit = 0;  // the next stage to fetch: column block, stage within it, running index
-    auto fetch_next = [&]() {
-        if (dst == 0) set_w_offsets(dcb);
-        float* sA = lds + (dit & 1) * DM_STAGE_FLOATS;
-        float* sW = sA + DM_A_FLOATS;
-        const char* a = baseA + (size_t)dst * (DM_KC * 4);
-        const char* w = baseW + (size_t)dst * (DM_KC * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
+    // The 8 pieces of the NEXT stage are issued between the MFMAs of the current stage's first two k-steps (one piece per 4
+    // MFMAs): among MFMAs a piece costs ~50 cycles of the wave's issue time, hidden under the matrix pipe; issued as a burst
+    // in front of the MFMAs (first version of this kernel) the 8 pieces took 3.1 k cycles per stage during which the wave fed
+    // the pipe nothing (profiles/r02_gemm_dma_walk_cycle_budget.txt). The last two k-steps cover the DMA latency.
+    int dcb = 0, dst = 0;  // the next stage to fetch: column block, stage within it
+    auto piece = [&](int i, const char* a, const char* w, float* sA, float* sW) {
+        if (i < 4)
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(a + offA[i]), sA + (32 * wave + 8 * i) * DM_KC, 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(w + offW[i]), sW + (32 * wave + 8 * i) * DM_KC, 16, 0, 0);
-        ++dit;
-        if (++dst == nstages) dst = 0, ++dcb;
+        else
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(w + offW[i - 4]), sW + (32 * wave + 8 * (i - 4)) * DM_KC, 16, 0, 0);
     };
     auto frag = [&](const float* base, int row, int step) {  // 16-byte fragment: floats 8 step + 4 kh .. + 3 of `row`
         return *reinterpret_cast<const f32x4*>(base + row * DM_KC + dm_swz(row, 2 * step + kh) * 4);
@@ -304,7 +299,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p) {
     const int row_lo = m0 + 64 * wm + j;  // the lane's rows: row_lo and row_lo + 32
 
     GT_DECL
-    fetch_next();
+    set_w_offsets(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) piece(i, baseA, baseW, lds, lds + DM_A_FLOATS);
+    dst = 1;
+    if (dst == nstages) dst = 0, dcb = 1;
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA has landed ...
     __syncthreads();                     // ... and so has everybody else's
     GT_SEG(0)
@@ -328,7 +327,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p) {
                 if (p.bias && cc < nbias) bia[q] = *reinterpret_cast<const f32x4*>(p.bias + cc);
             }
         }
-        if (dit < total) fetch_next();  // the other buffer was last read one stage ago
+        // source of the next stage (the stage after the last one re-fetches it: nobody reads that buffer)
+        if (dcb >= nblk) dcb = nblk - 1, dst = nstages - 1;
+        if (dst == 0) set_w_offsets(dcb);
+        float* nA = lds + ((it + 1) & 1) * DM_STAGE_FLOATS;  // the other buffer was last read one stage ago
+        float* nW = nA + DM_A_FLOATS;
+        const char* na = baseA + (size_t)dst * (DM_KC * 4);
+        const char* nw = baseW + (size_t)dst * (DM_KC * 4);
+        if (++dst == nstages) dst = 0, ++dcb;
         if (last) {
             if (HAS_RES && vec_ok) {
 #pragma unroll
@@ -357,19 +363,32 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p) {
         __builtin_amdgcn_s_setprio(0);
         GT_SEG(1)
         const int ra = 64 * wm + j, rw = 64 * wn + j;
-#pragma unroll
-        for (int s = 0; s < DM_KC / 8; ++s) {
-            const f32x4 a0 = frag(sA, ra, s), a1 = frag(sA, ra + 32, s);
-            const f32x4 b0 = frag(sW, rw, s), b1 = frag(sW, rw + 32, s);
-            // weights are the MFMA's A operand, activations its B operand (a lane then owns one output row)
+        // weights are the MFMA's A operand, activations its B operand (a lane then owns one output row)
 #define GS(e)                                                             \
     c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.e, a0.e, c00, 0, 0, 0); \
     c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a0.e, c01, 0, 0, 0); \
     c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.e, a1.e, c10, 0, 0, 0); \
     c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a1.e, c11, 0, 0, 0);
-            GS(x) GS(y) GS(z) GS(w)
-#undef GS
+#pragma unroll
+        for (int s = 0; s < DM_KC / 8; ++s) {
+            const f32x4 a0 = frag(sA, ra, s), a1 = frag(sA, ra + 32, s);
+            const f32x4 b0 = frag(sW, rw, s), b1 = frag(sW, rw + 32, s);
+            if (s < 2) {
+                GS(x) piece(4 * s + 0, na, nw, nA, nW);
+                GS(y) piece(4 * s + 1, na, nw, nA, nW);
+                GS(z) piece(4 * s + 2, na, nw, nA, nW);
+                GS(w) piece(4 * s + 3, na, nw, nA, nW);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the step's 4 fragment reads
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // one LDS-DMA piece
+                }
+            } else {
+                GS(x) GS(y) GS(z) GS(w)
+            }
         }
+#undef GS
         GT_SEG(2)
         __builtin_amdgcn_s_setprio(3);
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): next stage's DMA, bias / residual / rotary loads; older stores are long done
