@@ -339,6 +339,7 @@ def parse_args(argv=None):
                          "--pairs disjoint pairs, 2 fresh detections per pair (SURVEY.md section 8d asks for both rates)")
     ap.add_argument("--pair-chunk", type=int, default=32)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the pair chunks alternate over")
+    ap.add_argument("--graphs", type=int, default=1, help="1: full pair chunks replay a captured hipGraph of the matcher's launch sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates (cap 5000; independent pairs)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help='"nccl" = RCCL; "gloo" only with --plumbing-only')
@@ -449,7 +450,8 @@ def main() -> None:
         if matcher is not None and dist is not None:
             blob = matcher.weights if rank == 0 else None
             matcher.weights = parallel.broadcast_packed_weights(blob, matcher.weights.numel(), device)
-        pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams)
+        pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams,
+                                use_graphs=bool(args.graphs))
     have_matcher = args.matcher != "none"
     mk = {"sinkhorn_iterations": args.sinkhorn} if (args.matcher == "superglue" and not plumbing) else {}
 
@@ -579,6 +581,7 @@ def main() -> None:
                 "parallelism": par,
                 "pair_chunk": args.pair_chunk,
                 "streams": args.streams,
+                "hip_graphs": bool(args.graphs),
             },
             "tflops": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2),
         }
@@ -651,7 +654,7 @@ def secondary_rates(args, detector, matcher, device, h, w, mk):
     # (1) GTSfM's cap: 21 views -> 210 exhaustive pairs, first 200; top-5000 keypoints per image
     views = torch.from_numpy(synthetic.synthetic_overlapping_views(21, h, w, 2000)).to(device)
     pairs = parallel.exhaustive_pairs(21)[:200]
-    pipe = FrontEndPipeline(detector, matcher, max_keypoints=5000, pair_chunk=8, num_streams=args.streams)
+    pipe = FrontEndPipeline(detector, matcher, max_keypoints=5000, pair_chunk=8, num_streams=args.streams, use_graphs=bool(args.graphs))
     out["exhaustive_cap5000"] = dict(timed(pipe, views, pairs, [(h, w)] * 21, 2, 1), workload=(
         f"SuperPoint+{args.matcher}: 200 exhaustive pairs of 21 synthetic {h}x{w} views, top-5000 keypoints per image (GTSfM's default cap)"))
     del pipe, views
@@ -660,7 +663,8 @@ def secondary_rates(args, detector, matcher, device, h, w, mk):
     p = 500
     images = base[(5 * torch.arange(2 * p, device=device)) % 46].contiguous()
     pairs = [(2 * q, 2 * q + 1) for q in range(p)]
-    pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams)
+    pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams,
+                            use_graphs=bool(args.graphs))
     out["independent_pairs"] = dict(timed(pipe, images, pairs, [(h, w)] * (2 * p), 1, 1), workload=(
         f"SuperPoint+{args.matcher}: {p} independent pairs = {2 * p} fresh detections of synthetic {h}x{w} views, top-{args.keypoints} keypoints per image"))
     return out

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "dense_kernels.h"
+#include "gemm_batch.h"
 #include "trace.h"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -229,13 +230,18 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmParams p) {
 //     owns a row and adjacent register pairs are the (2f, 2f + 1) feature pairs, enc = [token][f][cos, sin].
 // ---------------------------------------------------------------------------------------------------------------
 template <bool HAS_RES, bool ROT>
-__global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, GemmBatch bt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A 4096 | W 4096]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int M = p.m_dev ? *p.m_dev : p.M;
-    const int N = p.n_dev ? *p.n_dev : p.N;
+    int N = p.n_dev ? *p.n_dev : p.N;
+    if (bt.problems) {  // ragged batch of independent products (blockIdx.y = problem); p.M / p.N are the batch maxima
+        const GemmProblem pr = bt.problems[blockIdx.y];
+        p.A += (size_t)pr.a_row * p.lda, p.wraw += (size_t)pr.w_row * p.ldw, p.C += pr.c_off, p.ldc = pr.ldc;
+        M = min(bt.counts[pr.m_idx], p.M), N = min(bt.counts[pr.n_idx], p.N);
+    }
     // XCD-aware order (speed only): workgroup b runs on XCD b % 8; the column groups of one row tile get consecutive slots of
     // ONE XCD, so the A tile is fetched into one L2 and re-read there
     const int ncb_total = (p.N + 127) / 128, mtiles = (p.M + 127) / 128;
@@ -458,10 +464,16 @@ bool gemm_uses_dma(int K, int ldw) {
 }
 
 int launch_gemm_dma(const GemmParams& p, hipStream_t stream) {
-    if (p.M <= 0) return GTSFM_OK;
+    GemmBatch none = {nullptr, nullptr, 0};
+    return launch_gemm_dma_batched(p, none, stream);
+}
+
+int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_t stream) {
+    if (p.M <= 0 || (bt.problems && bt.nproblems <= 0)) return GTSFM_OK;
     static const char* form = getenv("GTSFM_GEMM_DMA");  // "tile": the one-tile-per-workgroup kernel (A/B measurements)
     const int ncb = ceil_div(p.N, 128), mtiles = ceil_div(p.M, 128);
-    if (form && form[0] == 't' && !p.rot_enc) {
+    const int nprob = bt.problems ? bt.nproblems : 1;
+    if (form && form[0] == 't' && !p.rot_enc && !bt.problems) {
         const dim3 grid(ceil_div(mtiles, 8) * 8 * ncb);
         const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
         if (p.res)
@@ -473,21 +485,22 @@ int launch_gemm_dma(const GemmParams& p, hipStream_t stream) {
     }
     GTSFM_CHECK_ARG(!(p.rot_enc && p.res), "gemm: rotary epilogue and residual are exclusive");
     GTSFM_CHECK_ARG(!p.rot_enc || (p.rot_cols % 128 == 0 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.c_coff % 4 == 0), "gemm: rotary epilogue needs 16-byte aligned rows");
+    GTSFM_CHECK_ARG(!bt.problems || (!p.m_dev && !p.n_dev && !p.tile_cnt_idx && bt.counts), "gemm: a batch takes its sizes from the problem table");
     // column blocks per workgroup: the whole row of blocks when that still leaves two full rounds of workgroups (512 slots)
     GemmParams q = p;
     int nbw = ncb;
-    while (nbw > 1 && (long long)mtiles * ceil_div(ncb, nbw) < 1024) nbw = (nbw + 1) / 2;
+    while (nbw > 1 && (long long)mtiles * ceil_div(ncb, nbw) * nprob < 1024) nbw = (nbw + 1) / 2;
     static const char* env = getenv("GTSFM_GEMM_NB");
     if (env && atoi(env) > 0) nbw = atoi(env) < ncb ? atoi(env) : ncb;
     q.nb_per_wg = nbw;
-    const dim3 grid(ceil_div(mtiles, 8) * 8 * ceil_div(ncb, nbw));
+    const dim3 grid(ceil_div(mtiles, 8) * 8 * ceil_div(ncb, nbw), nprob);
     const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
     if (q.rot_enc)
-        hipLaunchKernelGGL((gemm_dma_walk_kernel<false, true>), grid, dim3(256), lds_bytes, stream, q);
+        hipLaunchKernelGGL((gemm_dma_walk_kernel<false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
     else if (q.res)
-        hipLaunchKernelGGL((gemm_dma_walk_kernel<true, false>), grid, dim3(256), lds_bytes, stream, q);
+        hipLaunchKernelGGL((gemm_dma_walk_kernel<true, false>), grid, dim3(256), lds_bytes, stream, q, bt);
     else
-        hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false>), grid, dim3(256), lds_bytes, stream, q);
+        hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false>), grid, dim3(256), lds_bytes, stream, q, bt);
     GTSFM_CHECK_LAUNCH("gemm_dma_walk_kernel");
     return GTSFM_OK;
 }

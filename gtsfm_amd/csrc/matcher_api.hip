@@ -9,6 +9,7 @@
 #include "../../include/gtsfm_amd.h"
 #include "attention_kernels.h"
 #include "dense_kernels.h"
+#include "gemm_batch.h"
 #include "lightglue_kernels.h"
 #include "matcher_kernels.h"
 
@@ -84,11 +85,11 @@ extern "C" int gtsfm_pack_blob(int count, const int32_t* kinds, const int32_t* n
 // (LightGlue; 0 for SuperGlue):
 //   live counts [2P] | final counts [2P] | assign counts [2P] | original counts [2P] | old counts [2P] | stop layer [P]
 //   | seqs [2P][6] | pairs [P][6] | self-attention problems [2P][4] | cross-attention problems [2P][4]
-//   | tile -> count index [NT] | tile -> first row within its sequence [NT]
+//   | score-GEMM problems [P][8] | tile -> count index [NT] | tile -> first row within its sequence [NT]
 // ---------------------------------------------------------------------------------------------------------------
 
 struct DescLayout {
-    size_t live, final_cnt, assign, orig, old_cnt, stop, seqs, pairs, self_p, cross_p, tile_idx, tile_row0, total;
+    size_t live, final_cnt, assign, orig, old_cnt, stop, seqs, pairs, self_p, cross_p, score_p, tile_idx, tile_row0, total;
 };
 
 static DescLayout desc_layout(int P, int NT) {
@@ -106,6 +107,8 @@ static DescLayout desc_layout(int P, int NT) {
     L.pairs = o, o += (size_t)6 * P;
     L.self_p = o, o += (size_t)8 * P;
     L.cross_p = o, o += (size_t)8 * P;
+    o = (o + 1) / 2 * 2;
+    L.score_p = o, o += (size_t)8 * P;
     L.tile_idx = o, o += (size_t)NT;
     L.tile_row0 = o, o += (size_t)NT;
     L.total = o;
@@ -161,6 +164,8 @@ extern "C" int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* 
         PairDesc pd;
         pd.z_off = zoff, pd.part_off = poff, pd.ld = z_ld(n1[p], ext), pd.pad = 0;
         memcpy(out + L.pairs + 6 * p, &pd, sizeof(pd));
+        GemmProblem gp = {zoff, offs[0], offs[1], 2 * p, 2 * p + 1, pd.ld, 0};  // scores of pair p: rows of image 0 x rows of image 1 -> Z
+        memcpy(out + L.score_p + 8 * p, &gp, sizeof(gp));
         zoff += (long long)(n0[p] + ext) * pd.ld;
         poff += (long long)ceil_div(n0[p] + ext, R) * pd.ld * 2;
         for (int s = 0; s < 2; ++s) {
@@ -326,19 +331,24 @@ extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_scor
     }
     TRY(gemm(X, 512, 256, 256, MD, 256, 0, nullptr, 0, 0));  // final_proj
 
-    // scores = mdesc0^T mdesc1 / sqrt(256) into the (m+1) x (n+1) couplings matrix (superglue.py:257-258,156-160)
-    {
+    // scores = mdesc0^T mdesc1 / sqrt(256) into the (m+1) x (n+1) couplings matrix (superglue.py:257-258,156-160): one ragged
+    // launch for all pairs when the LDS-DMA GEMM is in use (image 1's descriptor rows are its "weights" as they are)
+    if (gemm_uses_dma(256, 256)) {
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.A = MD, g.lda = 256, g.M = d.max_n0, g.K = 256, g.wraw = MD, g.ldw = 256, g.N = d.max_n1, g.C = Z, g.alpha = 0.0625f;
+        GemmBatch bt = {(const GemmProblem*)(desc_dev + DL.score_p), counts, npairs};
+        TRY(launch_gemm_dma_batched(g, bt, stream));
+    } else {
         int row = 0;
         size_t zoff = 0;
         for (int p = 0; p < npairs; ++p) {
             const int r0 = row, r1 = row + n0[p];
             const int ld = z_ld(n1[p], 1);
-            const bool dma = gemm_uses_dma(256, 256);  // the LDS-DMA GEMM takes image 1's descriptor rows as they are
-            if (!dma) TRY(launch_pack_rows(MD + (size_t)r1 * 256, 256, n1[p], nullptr, 256, PACK, stream));
+            TRY(launch_pack_rows(MD + (size_t)r1 * 256, 256, n1[p], nullptr, 256, PACK, stream));
             GemmParams g;
             memset(&g, 0, sizeof(g));
             g.A = MD + (size_t)r0 * 256, g.lda = 256, g.M = n0[p], g.K = 256, g.wpack = PACK, g.bias = nullptr, g.N = n1[p];
-            if (dma) g.wraw = MD + (size_t)r1 * 256, g.ldw = 256;
             g.C = Z + zoff, g.ldc = ld, g.alpha = 0.0625f;
             TRY(launch_gemm(g, stream));
             zoff += (size_t)(n0[p] + 1) * ld;
@@ -625,19 +635,23 @@ extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* m
         }
     }
 
-    // sim = mdesc0 mdesc1^T per pair over the final (kept) keypoints
-    {
+    // sim = mdesc0 mdesc1^T per pair over the final (kept) keypoints: one ragged launch (LDS-DMA GEMM), sizes from final_cnt
+    if (gemm_uses_dma(256, 256)) {
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.A = MD, g.lda = 256, g.M = d.max_n0, g.K = 256, g.wraw = MD, g.ldw = 256, g.N = d.max_n1, g.C = Z, g.alpha = 1.0f;
+        GemmBatch bt = {(const GemmProblem*)(desc_dev + DL.score_p), final_cnt, npairs};
+        TRY(launch_gemm_dma_batched(g, bt, stream));
+    } else {
         size_t zoff = 0;
         int row = 0;
         for (int p = 0; p < npairs; ++p) {
             const int r0 = row, r1 = row + cap128(n0[p]);
             const int ld = z_ld(n1[p], 0);
-            const bool dma = gemm_uses_dma(256, 256);
-            if (!dma) TRY(launch_pack_rows(MD + (size_t)r1 * 256, 256, n1[p], final_cnt + 2 * p + 1, 256, PACK, stream));
+            TRY(launch_pack_rows(MD + (size_t)r1 * 256, 256, n1[p], final_cnt + 2 * p + 1, 256, PACK, stream));
             GemmParams g;
             memset(&g, 0, sizeof(g));
             g.A = MD + (size_t)r0 * 256, g.lda = 256, g.M = n0[p], g.m_dev = final_cnt + 2 * p, g.K = 256, g.wpack = PACK, g.N = n1[p];
-            if (dma) g.wraw = MD + (size_t)r1 * 256, g.ldw = 256, g.n_dev = final_cnt + 2 * p + 1;
             g.C = Z + zoff, g.ldc = ld, g.alpha = 1.0f;
             TRY(launch_gemm(g, stream));
             zoff += (size_t)n0[p] * ld;

@@ -112,7 +112,8 @@ class BatchedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
 
         pairs = [(int(i1), int(i2)) for (i1, i2) in visibility_graph]
         empty = [p for p in pairs if counts[p[0]] == 0 or counts[p[1]] == 0]  # superglue.py:233-240 early-out
-        todo = [p for p in pairs if p not in set(empty)]
+        empty_set = set(empty)
+        todo = [p for p in pairs if p not in empty_set]
         is_sg = isinstance(matcher, SuperGlueMatcher)
         dtype = np.uint32 if is_sg else np.int64
         kwargs = (

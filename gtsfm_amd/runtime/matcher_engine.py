@@ -114,6 +114,7 @@ class _MatcherBase:
         self.device = require_gpu(device)
         self._lib = _lib.load()
         self._workspace: Optional[torch.Tensor] = None
+        self._desc_cache: Dict[tuple, torch.Tensor] = {}
 
     def _get_workspace(self, nbytes: int) -> torch.Tensor:
         if self._workspace is None or self._workspace.numel() < nbytes:
@@ -122,13 +123,22 @@ class _MatcherBase:
         return self._workspace
 
     def _build_desc(self, superglue: bool, n0: np.ndarray, n1: np.ndarray, hw: np.ndarray) -> torch.Tensor:
-        p = len(n0)
-        host = np.empty(self._lib.gtsfm_match_desc_ints(int(superglue), p, n0.ctypes.data, n1.ctypes.data), dtype=np.int32)
-        _lib.check(
-            self._lib.gtsfm_match_build_desc(int(superglue), p, n0.ctypes.data, n1.ctypes.data, hw.ctypes.data, host.ctypes.data),
-            "gtsfm_match_build_desc",
-        )
-        return torch.from_numpy(host).to(self.device)
+        """A fresh device copy of the batch descriptor block (LightGlue updates its counts in place). The pristine block of
+        a batch shape is built and uploaded once and cached: chunks of a scene share shapes, so the steady state is one
+        device-to-device copy per chunk instead of a host build + H2D."""
+        key = (superglue, n0.tobytes(), n1.tobytes(), hw.tobytes())
+        pristine = self._desc_cache.get(key)
+        if pristine is None:
+            p = len(n0)
+            host = np.empty(self._lib.gtsfm_match_desc_ints(int(superglue), p, n0.ctypes.data, n1.ctypes.data), dtype=np.int32)
+            _lib.check(
+                self._lib.gtsfm_match_build_desc(int(superglue), p, n0.ctypes.data, n1.ctypes.data, hw.ctypes.data, host.ctypes.data),
+                "gtsfm_match_build_desc",
+            )
+            if len(self._desc_cache) >= 64:
+                self._desc_cache.clear()
+            pristine = self._desc_cache[key] = torch.from_numpy(host).to(self.device)
+        return pristine.clone()
 
 
     def workspace_bytes(self, n0: Sequence[int], n1: Sequence[int]) -> int:

@@ -19,8 +19,49 @@ from gtsfm_amd.runtime.matcher_engine import LightGlueEngine, SuperGlueEngine
 from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
 
 
+class _GraphedChunk:
+    """The matcher's launch sequence for one chunk shape (P pairs of exactly K keypoints per image), captured once as a
+    hipGraph and replayed per chunk: the sequence is static -- LightGlue's adaptive depth / width run on the device -- so
+    only the gather of the chunk's features into the static input buffers stays eager."""
+
+    def __init__(self, matcher, num_pairs: int, k: int, hw, matcher_kwargs: dict, stream: torch.cuda.Stream, feats, idx: torch.Tensor):
+        dev = matcher.device
+        self.matcher, self.kwargs = matcher, dict(matcher_kwargs)
+        self.is_sg = isinstance(matcher, SuperGlueEngine)
+        self.n, self.hw = [k] * num_pairs, hw
+        self.kp = torch.zeros((2 * num_pairs, k, 2), dtype=torch.float32, device=dev)
+        self.sc = torch.zeros((2 * num_pairs, k), dtype=torch.float32, device=dev)
+        self.de = torch.zeros((2 * num_pairs, k, 256), dtype=torch.float32, device=dev)
+        self.ws = torch.empty(matcher.workspace_bytes(self.n, self.n) + 256, dtype=torch.uint8, device=dev)
+        with torch.cuda.stream(stream):
+            self._gather(feats, idx)
+            self._run()  # eager warm-up on real features: descriptor cache, allocator
+        stream.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=stream):
+            self.out = self._run()
+
+    def _run(self):
+        kp, sc, de = self.kp.reshape(-1, 2), self.sc.reshape(-1), self.de.reshape(-1, 256)
+        if self.is_sg:
+            return self.matcher.match_batch(kp, sc, de, self.n, self.n, self.hw, workspace=self.ws, **self.kwargs)
+        return self.matcher.match_batch(kp, de, self.n, self.n, self.hw, workspace=self.ws, **self.kwargs)
+
+    def _gather(self, feats, idx: torch.Tensor):
+        torch.index_select(feats["xy"], 0, idx, out=self.kp)
+        torch.index_select(feats["descriptors"], 0, idx, out=self.de)
+        if self.is_sg:
+            torch.index_select(feats["scores"], 0, idx, out=self.sc)
+
+    def replay(self, feats, idx: torch.Tensor):
+        self._gather(feats, idx)
+        self.graph.replay()
+        return {k: v.clone() for k, v in self.out.items() if isinstance(v, torch.Tensor) and not k.startswith("_")}
+
+
 class FrontEndPipeline:
-    def __init__(self, detector: SuperPointEngine, matcher, max_keypoints: int = 5000, pair_chunk: int = 32, num_streams: int = 2):
+    def __init__(self, detector: SuperPointEngine, matcher, max_keypoints: int = 5000, pair_chunk: int = 32, num_streams: int = 2,
+                 use_graphs: bool = False):
         self.detector = detector
         self.matcher = matcher
         self.max_keypoints = max_keypoints
@@ -30,6 +71,9 @@ class FrontEndPipeline:
         self.num_streams = max(1, num_streams)
         self._streams: List[torch.cuda.Stream] = []
         self._stream_ws: List[Optional[torch.Tensor]] = []
+        # full chunks (every image at the keypoint cap) replay a captured hipGraph of the matcher's launch sequence
+        self.use_graphs = use_graphs
+        self._graphs: Dict[tuple, _GraphedChunk] = {}
 
     def detect(self, images: torch.Tensor, image_chunk: int = 16) -> Dict[str, torch.Tensor]:
         """images [n,H,W] (device, uint8 / float32) -> count [n], xy [n,K,2], scores [n,K], descriptors [n,K,256] with
@@ -50,32 +94,55 @@ class FrontEndPipeline:
         full = bool((counts == feats["xy"].shape[1]).all())
         device = feats["xy"].device
         nstreams = min(self.num_streams, max(1, -(-len(pairs) // self.pair_chunk)))
-        if nstreams > 1 and len(self._streams) < nstreams:
+        side_streams = nstreams > 1 or self.use_graphs  # graphs are captured on (and replayed from) pipeline-owned streams
+        if side_streams and len(self._streams) < nstreams:
             self._streams = [torch.cuda.Stream(device) for _ in range(nstreams)]
             self._stream_ws = [None] * nstreams
         main = torch.cuda.current_stream(device)
         ready = torch.cuda.Event()
         ready.record(main)
-        for ci, c0 in enumerate(range(0, len(pairs), self.pair_chunk)):
-            chunk = list(pairs[c0 : c0 + self.pair_chunk])
-            if nstreams > 1:
+        chunks = [list(pairs[c0 : c0 + self.pair_chunk]) for c0 in range(0, len(pairs), self.pair_chunk)]
+        if side_streams:
+            # size every stream's workspace for the largest chunk it will see BEFORE anything is enqueued: a workspace
+            # regrown between chunks would hand its old block back to the allocator while the side stream may still use it
+            for si in range(nstreams):
+                need = max(self.matcher.workspace_bytes([int(counts[i]) for i, _ in c], [int(counts[j]) for _, j in c]) for c in chunks[si::nstreams])
+                if self._stream_ws[si] is None or self._stream_ws[si].numel() < need:
+                    with torch.cuda.stream(self._streams[si]):
+                        self._stream_ws[si] = torch.empty(int(need * 1.1) + 256, dtype=torch.uint8, device=device)
+        k = feats["xy"].shape[1]
+        for ci, chunk in enumerate(chunks):
+            if side_streams:
                 si = ci % nstreams
                 stream = self._streams[si]
                 if ci < nstreams:
                     stream.wait_event(ready)  # features were produced on the caller's stream
-                need = self.matcher.workspace_bytes([int(counts[i]) for i, _ in chunk], [int(counts[j]) for _, j in chunk])
-                if self._stream_ws[si] is None or self._stream_ws[si].numel() < need:
-                    self._stream_ws[si] = torch.empty(int(need * 1.1) + 256, dtype=torch.uint8, device=device)
-                matcher_kwargs = dict(matcher_kwargs, workspace=self._stream_ws[si])
+                kwargs = dict(matcher_kwargs, workspace=self._stream_ws[si])
                 ctx = torch.cuda.stream(stream)
             else:
-                ctx = contextlib.nullcontext()
+                si, stream, kwargs, ctx = 0, main, matcher_kwargs, contextlib.nullcontext()
             with ctx:
-                results.append(self._match_chunk(feats, chunk, shapes, counts, full, matcher_kwargs))
-        if nstreams > 1:
+                hw0 = shapes[chunk[0][0]]
+                uniform = all(shapes[i] == hw0 and shapes[j] == hw0 for i, j in chunk)
+                if self.use_graphs and full and uniform and len(chunk) == self.pair_chunk:
+                    results.append(self._replay_chunk(feats, chunk, k, hw0, matcher_kwargs, si, stream))
+                else:
+                    results.append(self._match_chunk(feats, chunk, shapes, counts, full, kwargs))
+        if side_streams:
             for stream in self._streams[:nstreams]:
                 main.wait_stream(stream)  # the caller's stream sees every chunk's outputs
         return results
+
+    def _replay_chunk(self, feats, chunk, k, hw0, matcher_kwargs, si, stream):
+        key = (si, len(chunk), k, tuple(hw0), tuple(sorted(matcher_kwargs.items())))
+        idx = torch.tensor([i for p in chunk for i in p], dtype=torch.long, device=feats["xy"].device)
+        g = self._graphs.get(key)
+        if g is None:
+            hw = [[hw0[0], hw0[1], hw0[0], hw0[1]]] * len(chunk)
+            g = self._graphs[key] = _GraphedChunk(self.matcher, len(chunk), k, hw, matcher_kwargs, stream, feats, idx)
+        out = g.replay(feats, idx)
+        out["pairs"], out["n0"], out["n1"] = chunk, [k] * len(chunk), [k] * len(chunk)
+        return out
 
     def _match_chunk(self, feats, chunk, shapes, counts, full, matcher_kwargs):
         """One ragged multi-pair launch sequence on the current stream."""

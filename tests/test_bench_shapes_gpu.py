@@ -135,7 +135,7 @@ def test_bench_pipeline_first_pair_vs_oracle(gpu_device, views, matcher):
         eng, mk = ME.SuperGlueEngine(synthetic.synthetic_superglue_state_dict(), gpu_device), {"sinkhorn_iterations": 100}
     else:
         eng, mk = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(), gpu_device), {}
-    pipe = FrontEndPipeline(det, eng, max_keypoints=2048, pair_chunk=2, num_streams=2)
+    pipe = FrontEndPipeline(det, eng, max_keypoints=2048, pair_chunk=2, num_streams=2, use_graphs=True)  # bench.py's default path
     feats = pipe.detect(T(views[:4]).to(gpu_device))
     res = pipe.match(feats, [(0, 1), (0, 2), (1, 3), (2, 3), (0, 3)], [(1024, 1024)] * 4, **mk)
     base, ora = bench.cpu_baseline(views[:2], matcher, 2048, 100)
@@ -145,3 +145,34 @@ def test_bench_pipeline_first_pair_vs_oracle(gpu_device, views, matcher):
     assert check["max_ddescriptor"] < TOL and check["max_dscore_keypoints"] < TOL and check["max_dscore"] < TOL, check
     assert check["matches"] > 100 and check["within_tolerance"], check
     assert base["value"] > 0 and base["kind"] == "port"
+
+
+@pytest.mark.parametrize("matcher", ["lightglue", "superglue"])
+def test_graph_replay_equals_eager_launches(gpu_device, views, matcher):
+    """Full pair chunks replay a captured hipGraph of the matcher's launch sequence: same bits as the eager launches, also
+    when the feature tables are new tensors in the next step (nothing captured may point at them) and across both streams."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+    from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+
+    det = SuperPointEngine(synthetic.synthetic_superpoint_state_dict(), gpu_device)
+    if matcher == "superglue":
+        eng, mk = ME.SuperGlueEngine(synthetic.synthetic_superglue_state_dict(num_layers=4), gpu_device), {"sinkhorn_iterations": 20}
+    else:
+        eng, mk = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(num_layers=3), gpu_device), {}
+    eager = FrontEndPipeline(det, eng, max_keypoints=1024, pair_chunk=2, num_streams=2, use_graphs=False)
+    graphed = FrontEndPipeline(det, eng, max_keypoints=1024, pair_chunk=2, num_streams=2, use_graphs=True)
+    pairs = [(0, 1), (0, 2), (1, 3), (2, 3), (0, 3), (1, 2), (3, 4)]  # 3 full chunks + a tail chunk
+    for step, first in enumerate((0, 5)):  # two steps on different images: fresh feature tensors
+        feats = eager.detect(T(views[first : first + 5]).to(gpu_device))
+        a = eager.match(feats, pairs, [(1024, 1024)] * 5, **mk)
+        b = graphed.match(feats, pairs, [(1024, 1024)] * 5, **mk)
+        torch.cuda.synchronize()
+        assert len(a) == len(b) == 4
+        for ra, rb in zip(a, b):
+            assert ra["pairs"] == rb["pairs"]
+            assert torch.equal(ra["matches"], rb["matches"]) and torch.equal(ra["mscores"], rb["mscores"]), (step, ra["pairs"])
+            if matcher == "lightglue":
+                assert torch.equal(ra["stop"], rb["stop"]) and torch.equal(ra["kept"], rb["kept"])
+        assert sum(int((r["matches"] > -1).sum()) for r in a) > 100
+    assert len(graphed._graphs) == 2  # one captured graph per stream for the full-chunk shape
