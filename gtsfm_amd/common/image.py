@@ -35,10 +35,12 @@ except Exception:  # noqa: BLE001
 def rgb_to_gray_u8(value_array: np.ndarray) -> np.ndarray:
     """Grayscale conversion of ``gtsfm/utils/images.py:15-42`` (``cv.cvtColor(..., COLOR_RGB2GRAY)`` on uint8).
 
-    With OpenCV present the reference function itself is used. Without it (this container), OpenCV's 8-bit
-    fixed-point formula is restated: ``(R*4899 + G*9617 + B*1868 + 2^13) >> 14`` (coefficients 0.299/0.587/0.114 in
-    Q14). This conversion sits outside the bit-exact contract (SURVEY.md section 8c caveat 4): synthetic configs feed
-    gray images directly.
+    With OpenCV present the reference function itself is used. Without it (this container), OpenCV's 8-bit fixed-point
+    formula is restated: ``(R*9798 + G*19235 + B*3735 + 2^14) >> 15`` -- the 15-bit coefficients of
+    ``RGB2Gray<uchar>`` in the OpenCV 4.5 line the reference pins (``opencv-python>=4.5.4.60``, pyproject.toml:75; round 1
+    used the older 14-bit set 4899 / 9617 / 1868, which differs by one grey level on 0.26 % of random pixels). The same
+    arithmetic runs on the device in ``gtsfm_prep_rgb_to_gray_u8``. UNPINNED without cv2 (SURVEY.md section 8c caveat 4):
+    synthetic configs feed gray images directly.
     """
     if value_array.ndim == 2:
         return value_array
@@ -51,5 +53,5 @@ def rgb_to_gray_u8(value_array: np.ndarray) -> np.ndarray:
         return cv.cvtColor(value_array, code)
     except ImportError:
         rgb = value_array[..., :3].astype(np.uint32)
-        gray = (rgb[..., 0] * 4899 + rgb[..., 1] * 9617 + rgb[..., 2] * 1868 + (1 << 13)) >> 14
+        gray = (rgb[..., 0] * 9798 + rgb[..., 1] * 19235 + rgb[..., 2] * 3735 + (1 << 14)) >> 15
         return gray.astype(np.uint8)

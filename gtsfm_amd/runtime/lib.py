@@ -78,6 +78,12 @@ SIGNATURES = {
         [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "gtsfm_prep_rgb_to_gray_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "gtsfm_prep_cubic_taps": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "gtsfm_prep_resize_cubic_u8": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    ),
     "gtsfm_sinkhorn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p]),
     "gtsfm_sinkhorn_f32": (
         C.c_int,

@@ -167,6 +167,18 @@ int gtsfm_attention_f32(const float* q_dev, int ldq, const float* k_dev, int ldk
                         float* out_dev, int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems,
                         int max_q, int heads, float scale, void* stream);
 
+/* ---- input step in front of SuperPoint (uint8, OpenCV's 8-bit fixed-point arithmetic) ----
+ * RGB(A) -> gray.          replaces gtsfm/utils/images.py:15-42 (cv.cvtColor COLOR_RGB2GRAY / COLOR_RGBA2GRAY), called from
+ * gtsfm/frontend/detector_descriptor/superpoint.py:73. rgb_dev [H][W][channels], gray_dev [H][W]. */
+int gtsfm_prep_rgb_to_gray_u8(const uint8_t* rgb_dev, int height, int width, int channels, uint8_t* gray_dev, void* stream);
+/* INTER_CUBIC resize.      replaces gtsfm/utils/images.py:102-129 (cv.resize), called from gtsfm/loader/loader_base.py:160-200.
+ * gtsfm_prep_cubic_taps (host): per destination index the source index of the second of the four taps and the four 11-bit
+ * integer weights (float32 cubic weights, A = -0.75, rounded half to even); the caller uploads the tables of both axes.
+ * src_dev [src_h][src_w][channels] -> dst_dev [dst_h][dst_w][channels], taps clamped to the image. */
+int gtsfm_prep_cubic_taps(int dst_size, int src_size, int32_t* first_src_host, int16_t* weights_host);
+int gtsfm_prep_resize_cubic_u8(const uint8_t* src_dev, int src_h, int src_w, int channels, const int32_t* xofs_dev, const int16_t* xw_dev,
+                               const int32_t* yofs_dev, const int16_t* yw_dev, uint8_t* dst_dev, int dst_h, int dst_w, void* stream);
+
 /* SuperGlue.forward for a batch of pairs.                                                    replaces SG:228-283
  * kpts_dev [T][2] (x, y) pixels, scores_dev [T], descriptors_dev [T][256] (the wrapper's (N, 256) layout,
  * gtsfm/frontend/matcher/superglue_matcher.py:94-99 without the transposes).

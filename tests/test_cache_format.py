@@ -1,0 +1,101 @@
+"""CPU: front-end cache files and keys are interchangeable with the reference's.
+
+The reference's cacher modules cannot be imported here (they pull in gtsam / cv2 through ``gtsfm.common``, SURVEY.md
+F10), so the expected values are produced by the reference's own few lines, restated inline next to their file:line."""
+
+import hashlib
+import pickle
+from bz2 import BZ2File
+
+import numpy as np
+
+from gtsfm_amd.common.image import Image
+from gtsfm_amd.common.keypoints import Keypoints
+from gtsfm_amd.frontend.cacher import cache_format
+from gtsfm_amd.frontend.cacher.detector_descriptor_cacher import DetectorDescriptorCacher
+from gtsfm_amd.frontend.cacher.matcher_cacher import MatcherCacher
+from gtsfm_amd.frontend.detector_descriptor.detector_descriptor_base import DetectorDescriptorBase
+from gtsfm_amd.frontend.matcher.matcher_base import MatcherBase
+
+
+class FakeDetectorDescriptor(DetectorDescriptorBase):  # type(obj).__name__ is the cache namespace (the plugins carry the reference's names)
+    calls = 0
+
+    def detect_and_describe(self, image):
+        type(self).calls += 1
+        n = 7
+        kp = Keypoints(coordinates=np.arange(2 * n, dtype=np.float32).reshape(n, 2), responses=np.linspace(0.1, 0.9, n).astype(np.float32))
+        return kp, np.full((n, 256), image.value_array.mean(), dtype=np.float32)
+
+
+class FakeMatcher(MatcherBase):
+    calls = 0
+
+    def match(self, keypoints_i1, keypoints_i2, descriptors_i1, descriptors_i2, im_shape_i1, im_shape_i2):
+        type(self).calls += 1
+        return np.array([[0, 1], [2, 0]], dtype=np.uint32)
+
+
+def _image():
+    return Image(value_array=np.arange(6 * 8 * 3, dtype=np.uint8).reshape(6, 8, 3), file_name="DSC_0001.JPG")
+
+
+def test_detector_cache_key_follows_the_reference_scheme():
+    image = _image()
+    # gtsfm/utils/cache.py:14-23 and detector_descriptor_cacher.py:40,52-55
+    expected = "FakeDetectorDescriptor_" + hashlib.sha1("DSC_0001.JPG_8_6".encode()).hexdigest() + hashlib.sha1(image.value_array.tobytes()).hexdigest()
+    assert cache_format.detector_descriptor_cache_key(FakeDetectorDescriptor(), image) == expected
+
+
+def test_matcher_cache_key_follows_the_reference_scheme():
+    rng = np.random.default_rng(0)
+    kp1 = Keypoints(coordinates=rng.random((25, 2)).astype(np.float32), responses=rng.random(25).astype(np.float32))
+    kp2 = Keypoints(coordinates=rng.random((4, 2)).astype(np.float32), responses=rng.random(4).astype(np.float32), scales=rng.random(4).astype(np.float32))
+    d1, d2 = rng.random((25, 256)).astype(np.float32), rng.random((4, 256)).astype(np.float32)
+    # matcher_cacher.py:24,46-80: first 10 entries of coordinates / responses / scales / descriptors per image, then the shapes
+    parts = [kp1.coordinates[:10].flatten(), kp1.responses[:10].flatten(), d1[:10].flatten(),
+             kp2.coordinates[:10].flatten(), kp2.responses[:10].flatten(), kp2.scales[:10].flatten(), d2[:10].flatten(),
+             np.array([480, 640, 3, 400, 600, 3])]
+    expected = "FakeMatcher_" + hashlib.sha1(np.concatenate(parts).tobytes()).hexdigest()
+    assert cache_format.matcher_cache_key(FakeMatcher(), kp1, kp2, d1, d2, (480, 640, 3), (400, 600, 3)) == expected
+
+
+def test_detector_cacher_writes_reference_format_and_hits(tmp_path):
+    FakeDetectorDescriptor.calls = 0
+    plugin = FakeDetectorDescriptor(max_keypoints=123)
+    cacher = DetectorDescriptorCacher(plugin, cache_root=tmp_path)
+    assert cacher.max_keypoints == 123
+    image = _image()
+    kp, desc = cacher.detect_and_describe(image)
+    path = tmp_path / "detector_descriptor" / (cache_format.detector_descriptor_cache_key(plugin, image) + ".pbz2")
+    assert path.exists() and FakeDetectorDescriptor.calls == 1
+    # the reference's reader: pickle.load(BZ2File(file_path, "rb")) (gtsfm/utils/io.py:443) -> {"keypoints", "descriptors"}
+    raw = BZ2File(path, "rb").read()
+    assert b"gtsfm.common.keypoints" in raw and b"gtsfm_amd" not in raw, "Keypoints must unpickle inside a GTSfM installation"
+    data = pickle.loads(raw)
+    assert sorted(data) == ["descriptors", "keypoints"] and data["keypoints"] == kp and np.array_equal(data["descriptors"], desc)
+    kp2, desc2 = cacher.detect_and_describe(image)  # served from the cache
+    assert FakeDetectorDescriptor.calls == 1 and kp2 == kp and np.array_equal(desc2, desc)
+    # an entry written by "the reference" (its writer: pickle.dump(data, BZ2File(file_path, "wb")), io.py:452-455) is read back
+    other = Image(value_array=np.zeros((4, 4), dtype=np.uint8), file_name="x.png")
+    ref_path = tmp_path / "detector_descriptor" / (cache_format.detector_descriptor_cache_key(plugin, other) + ".pbz2")
+    pickle.dump({"keypoints": Keypoints(coordinates=np.ones((2, 2), dtype=np.float32)), "descriptors": np.zeros((2, 256), dtype=np.float32)}, BZ2File(ref_path, "wb"))
+    kp3, desc3 = cacher.detect_and_describe(other)
+    assert FakeDetectorDescriptor.calls == 1 and len(kp3) == 2 and desc3.shape == (2, 256)
+
+
+def test_matcher_cacher_round_trip_and_corrupted_entry(tmp_path):
+    FakeMatcher.calls = 0
+    plugin = FakeMatcher()
+    cacher = MatcherCacher(plugin, cache_root=tmp_path)
+    kp = Keypoints(coordinates=np.zeros((3, 2), dtype=np.float32), responses=np.ones(3, dtype=np.float32))
+    d = np.ones((3, 256), dtype=np.float32)
+    args = dict(keypoints_i1=kp, keypoints_i2=kp, descriptors_i1=d, descriptors_i2=d, im_shape_i1=(10, 12, 3), im_shape_i2=(10, 12, 3))
+    m = cacher.match(**args)
+    path = tmp_path / "matcher" / (cache_format.matcher_cache_key(plugin, kp, kp, d, d, (10, 12, 3), (10, 12, 3)) + ".pbz2")
+    assert path.exists() and FakeMatcher.calls == 1 and m.dtype == np.uint32
+    stored = pickle.load(BZ2File(path, "rb"))  # the (K, 2) array itself (matcher_cacher.py:126)
+    assert np.array_equal(stored, m) and stored.dtype == np.uint32
+    assert np.array_equal(cacher.match(**args), m) and FakeMatcher.calls == 1
+    path.write_bytes(b"not a bz2 stream")  # io.py:444-448: a corrupted entry is dropped and recomputed
+    assert np.array_equal(cacher.match(**args), m) and FakeMatcher.calls == 2 and path.exists()

@@ -1,0 +1,99 @@
+"""Input step in front of SuperPoint: loader downsize (cv.INTER_CUBIC) + RGB -> gray.
+
+PARITY UNPINNED: the reference does this with OpenCV, which is absent here and on the GPU box; the oracle
+(``oracle/imageprep_oracle.py``) restates OpenCV's 8-bit fixed-point algorithms. CPU tests: the oracle's properties, the
+host-side tap tables of the C ABI against the oracle's, the host gray formula. GPU tests: the two HIP kernels bit-exact
+against the oracle (integer arithmetic on both sides)."""
+
+import numpy as np
+import pytest
+import torch
+
+from gtsfm_amd.common.image import rgb_to_gray_u8
+from gtsfm_amd.utils import synthetic
+from oracle import imageprep_oracle as ipo
+
+T = torch.from_numpy
+
+
+def _synthetic_rgb(h, w, seed):
+    return np.stack([synthetic.synthetic_gray_image(h, w, seed + c, blur=1 + c) for c in range(3)], -1)
+
+
+def test_oracle_gray_formula_and_host_fallback_agree():
+    rgb = np.random.default_rng(0).integers(0, 256, size=(37, 41, 3), dtype=np.uint8)
+    gray = ipo.rgb_to_gray_u8(rgb)
+    assert gray.dtype == np.uint8 and gray.shape == (37, 41)
+    assert np.abs(gray.astype(int) - np.rint(0.299 * rgb[..., 0] + 0.587 * rgb[..., 1] + 0.114 * rgb[..., 2]).astype(int)).max() <= 1
+    np.testing.assert_array_equal(rgb_to_gray_u8(rgb), gray)  # the plugin's host path uses the same 15-bit coefficients
+    np.testing.assert_array_equal(ipo.rgb_to_gray_u8(np.concatenate([rgb, rgb[..., :1]], -1)), gray)  # alpha ignored
+    grey_in = np.full((4, 4, 3), 200, dtype=np.uint8)
+    assert (ipo.rgb_to_gray_u8(grey_in) == 200).all()  # the coefficients sum to 2^15
+
+
+def test_oracle_resize_properties():
+    img = _synthetic_rgb(120, 90, 3)
+    np.testing.assert_array_equal(ipo.resize_inter_cubic_u8(img, 120, 90), img)  # identity
+    const = np.full((50, 70), 137, dtype=np.uint8)
+    assert (ipo.resize_inter_cubic_u8(const, 31, 44) == 137).all()  # weights sum to 2^11 per axis
+    small = ipo.resize_inter_cubic_u8(img, 60, 45)
+    assert small.shape == (60, 45, 3) and small.dtype == np.uint8
+    np.testing.assert_array_equal(ipo.resize_inter_cubic_u8(img[..., 1], 60, 45), small[..., 1])  # channels are independent
+    assert ipo.downsampled_size(1936, 1296, 760) == (1135, 760)  # Lund door at the olsson loader's default
+    assert ipo.downsampled_size(1296, 1936, 760) == (760, 1135)
+    assert ipo.downsampled_size(480, 640, 760) == (480, 640)
+
+
+@pytest.mark.parametrize("dst,src", [(760, 1296), (1135, 1936), (44, 70), (90, 90), (200, 77)])
+def test_abi_tap_tables_match_the_oracle(built_library, dst, src):
+    """gtsfm_prep_cubic_taps (host C, float32) vs the oracle's numpy float32 restatement: identical integers."""
+    from gtsfm_amd.runtime import lib as L
+
+    lib = L.load()
+    first = np.empty(dst, dtype=np.int32)
+    weights = np.empty((dst, 4), dtype=np.int16)
+    L.check(lib.gtsfm_prep_cubic_taps(dst, src, first.ctypes.data, weights.ctypes.data), "taps")
+    s, w = ipo._cubic_taps(dst, src)
+    np.testing.assert_array_equal(first, s)
+    np.testing.assert_array_equal(weights, w)
+    assert (weights.astype(int).sum(1) == 2048).all() or abs(int(weights.astype(int).sum(1).min()) - 2048) <= 2
+
+
+def test_target_size_helper_matches_the_oracle():
+    from gtsfm_amd.runtime.image_prep import downsampled_size
+
+    for h, w, r in [(1936, 1296, 760), (1296, 1936, 760), (480, 640, 760), (1080, 1920, 760), (3000, 4000, 1000), (761, 900, 760)]:
+        assert downsampled_size(h, w, r) == ipo.downsampled_size(h, w, r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,nh,nw,channels", [(1936, 1296, 1135, 760, 3), (300, 200, 120, 80, 3), (97, 131, 64, 64, 1), (64, 64, 200, 150, 3)])
+def test_device_resize_bit_exact_vs_oracle(gpu_device, h, w, nh, nw, channels):
+    from gtsfm_amd.runtime.image_prep import ImagePrep
+
+    img = _synthetic_rgb(h, w, 11)
+    img = img if channels == 3 else np.ascontiguousarray(img[..., 0])
+    out = ImagePrep(gpu_device).resize_cubic(T(img).to(gpu_device), nh, nw).cpu().numpy()
+    np.testing.assert_array_equal(out, ipo.resize_inter_cubic_u8(img, nh, nw))
+
+
+@pytest.mark.gpu
+def test_device_gray_and_prepare_bit_exact_vs_oracle(gpu_device):
+    from gtsfm_amd.runtime.image_prep import ImagePrep
+
+    prep = ImagePrep(gpu_device)
+    rgb = _synthetic_rgb(333, 517, 5)
+    np.testing.assert_array_equal(prep.rgb_to_gray(T(rgb).to(gpu_device)).cpu().numpy(), ipo.rgb_to_gray_u8(rgb))
+    rgba = np.concatenate([rgb, rgb[..., :1]], -1)
+    np.testing.assert_array_equal(prep.rgb_to_gray(T(np.ascontiguousarray(rgba)).to(gpu_device)).cpu().numpy(), ipo.rgb_to_gray_u8(rgb))
+    batch = np.stack([rgb, rgb[::-1].copy()])
+    np.testing.assert_array_equal(prep.rgb_to_gray(T(batch).to(gpu_device)).cpu().numpy(), np.stack([ipo.rgb_to_gray_u8(b) for b in batch]))
+    # the loader + wrapper sequence on a Lund-door-sized image: downsize to a short side of 760, then gray
+    big = _synthetic_rgb(1936, 1296, 9)
+    nh, nw = ipo.downsampled_size(1936, 1296, 760)
+    ref = ipo.rgb_to_gray_u8(ipo.resize_inter_cubic_u8(big, nh, nw))
+    got = prep.prepare(big, max_resolution=760)
+    assert got.shape == (1135, 760) and got.dtype == torch.uint8
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    gray = synthetic.synthetic_gray_image(100, 120, 1)
+    np.testing.assert_array_equal(prep.prepare(gray).cpu().numpy(), gray)  # gray input passes through

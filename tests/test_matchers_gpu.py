@@ -446,6 +446,62 @@ def test_batched_correspondence_generator(gpu_device, sg_sd, tmp_path):
             assert corr[(i, j)].dtype == ref.dtype
 
 
+@pytest.mark.parametrize("which", ["superglue", "lightglue"])
+def test_batched_correspondence_generator_vs_oracle(gpu_device, sg_sd, tmp_path, which):
+    """The resident generator (device top-k, ragged gathers, pair chunks alternating over two HIP streams) against the
+    ORACLE directly -- detection + wrapper selection + matcher restated on the CPU -- on a small scene of overlapping views
+    with ragged keypoint counts (the other generator tests compare the HIP pipeline with the HIP plugins)."""
+    from gtsfm_amd.common.image import Image
+    from gtsfm_amd.frontend.correspondence_generator.batched_det_desc_correspondence_generator import (
+        BatchedDetDescCorrespondenceGenerator,
+    )
+    from gtsfm_amd.frontend.detector_descriptor.superpoint import SuperPointDetectorDescriptor
+    from gtsfm_amd.frontend.matcher.lightglue_matcher import LightGlueMatcher
+    from gtsfm_amd.frontend.matcher.superglue_matcher import SuperGlueMatcher
+    from oracle import superpoint_oracle as spo
+
+    sp_sd = synthetic.synthetic_superpoint_state_dict()
+    lg_sd = synthetic.synthetic_lightglue_state_dict()
+    torch.save(sp_sd, str(tmp_path / "sp.pth"))
+    torch.save(sg_sd, str(tmp_path / "sg.pth"))
+    torch.save(lg_sd, str(tmp_path / "lg.pth"))
+    views = synthetic.synthetic_overlapping_views(4, 200, 264, seed=91)
+    grays = [views[0], views[1], views[2][:168, :232], views[3]]  # one smaller image: fewer keypoints than the cap
+    images = [Image(value_array=g) for g in grays]
+    graph = [(0, 1), (0, 2), (1, 3), (2, 3), (0, 3)]
+    cap = 300
+    det = SuperPointDetectorDescriptor(max_keypoints=cap, weights_path=tmp_path / "sp.pth")
+    matcher = SuperGlueMatcher(weights_path=tmp_path / "sg.pth") if which == "superglue" else LightGlueMatcher("superpoint", weights_path=tmp_path / "lg.pth")
+    gen = BatchedDetDescCorrespondenceGenerator(matcher, det, image_batch=2, pair_batch=2)
+    kps, corr = gen.generate_correspondences(None, images, graph)
+    feats = []
+    for g in grays:
+        c, sc, d = spo.detect_and_describe(sp_sd, g, max_keypoints=1 << 30)
+        sel = synthetic.topk_detection_order(sc, cap)
+        feats.append((c[sel], sc[sel], d[sel]))
+    assert len({len(f[0]) for f in feats}) > 1, "the scene should have ragged keypoint counts"
+    for i in range(4):
+        np.testing.assert_array_equal(kps[i].coordinates, feats[i][0])
+        np.testing.assert_allclose(kps[i].responses, feats[i][1], rtol=0, atol=SCORE_TOL)
+    total = 0
+    for i, j in graph:
+        (c0, s0, d0), (c1, s1, d1) = feats[i], feats[j]
+        shp0, shp1 = grays[i].shape, grays[j].shape
+        with torch.no_grad():
+            if which == "superglue":
+                ora = sgo.superglue_forward(sg_sd, T(c0)[None], T(c1)[None], T(s0)[None], T(s1)[None], T(d0).T[None].contiguous(),
+                                            T(d1).T[None].contiguous(), shp0, shp1, sinkhorn_iterations=20)
+            else:
+                ora = lgo.lightglue_forward(lg_sd, T(c0)[None], T(c1)[None], T(d0)[None], T(d1)[None], shp0, shp1)
+        m0 = ora["matches0"][0].numpy()
+        valid = m0 > -1
+        ref = np.stack([np.flatnonzero(valid), m0[valid]], -1)
+        np.testing.assert_array_equal(corr[(i, j)], ref.astype(corr[(i, j)].dtype))
+        assert corr[(i, j)].dtype == (np.uint32 if which == "superglue" else np.int64)
+        total += len(ref)
+    assert total > 100
+
+
 def test_real_images_lund_door_pair(gpu_device, sg_engine):
     """Real-image pair end to end on the device (SuperPoint -> top-1024 -> SuperGlue, 20 iterations) vs the reference's
     outputs for the same two Lund-door frames."""
