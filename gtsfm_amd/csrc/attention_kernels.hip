@@ -347,9 +347,9 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
 
-#ifndef AT_INTERLEAVE
-    // ---- variant validated on the GPU at the end of round 1 (the compiler keeps the S MFMAs and the softmax in separate
-    // basic blocks here: the uniform branches between them stop its scheduler from interleaving the two)
+    // (A variant with the S MFMAs and the softmax VALU arranged in shared straight-line blocks -- rebase branches moved
+    // between two halves of the S phase -- was measured in round 2: 256 registers, 495 vs 499 image-pairs/s in the
+    // workload, not kept.)
     for (int t = 0; t < ntiles; ++t) {
         const int k0 = t * AT_KT;
         const bool more = t + 1 < ntiles;
@@ -433,121 +433,6 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
             sc0 = sn0, sc1 = sn1;
         }
     }
-#else
-    // ---- NOT YET RUN: the same pipeline arranged so that MFMAs and softmax VALU share straight-line blocks. All tiles but
-    // the last take the `true` path (never masked: only the last tile can be partial); the rare rebase / shift branches
-    // sit BETWEEN the two halves of the S phase: block A = accumulator start + 32 MFMAs (u = 0..3) + row maximum,
-    // block B = 32 MFMAs (u = 4..7) + 32 exp2 + row sum.
-    auto pv_phase = [&]() {
-#pragma unroll
-        for (int T = 0; T < 2; ++T) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int key = 32 * T + 8 * gq + 4 * kh;
-                f32x4 a0, a1, bb;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a0[e] = velem(key + e, j);
-                    a1[e] = velem(key + e, 32 + j);
-                    bb[e] = T ? sc1[4 * gq + e] : sc0[4 * gq + e];
-                }
-                mfma8(o0, o1, a0, a1, bb);
-            }
-        }
-    };
-    auto rebase_by = [&](float d, bool scale_o) {  // rare path: shift the current scores, rescale O and l
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sc0[r] -= d;
-            sc1[r] -= d;
-        }
-        if (scale_o) {
-            const float alpha = __builtin_amdgcn_exp2f(-d);
-            l *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o0[r] *= alpha;
-                o1[r] *= alpha;
-            }
-        }
-        m += d;
-    };
-    for (int t = 0; t + 1 < ntiles; ++t) {
-        const int k0 = t * AT_KT;
-        // block A
-        const float neg_m = -m;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sn0[r] = sn1[r] = neg_m;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) mfma8(sn0, sn1, kfrag(j, u), kfrag(32 + j, u), qreg[u]);
-        float mloc = fmaxf(sc0[0], sc1[0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(sc0[r], sc1[r]));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const bool rebase = (t == 0) || (mloc > AT_REBASE);
-        float d = 0.f;
-        if (__any(rebase)) {
-            d = rebase ? mloc : 0.f;
-            rebase_by(d, t > 0);
-        }
-        // block B
-#pragma unroll
-        for (int u = 4; u < 8; ++u) mfma8(sn0, sn1, kfrag(j, u), kfrag(32 + j, u), qreg[u]);
-        float lsum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sc0[r] = __builtin_amdgcn_exp2f(sc0[r]);
-            sc1[r] = __builtin_amdgcn_exp2f(sc1[r]);
-            lsum += sc0[r] + sc1[r];
-        }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l += lsum;
-        if (__any(d != 0.f)) {  // the next tile was accumulated relative to the reference before this rebase
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sn0[r] -= d;
-                sn1[r] -= d;
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // own V(t) DMA landed
-        __syncthreads();                     // B1: K buffer free, V(t) visible
-        if (t + 2 < ntiles) tile_dma(kbase, p.ldk, k0 + 2 * AT_KT, Ks);
-        pv_phase();
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // own K(t+2) DMA landed
-        __syncthreads();                     // B2: V buffer free, K(t+2) visible
-        tile_dma(vbase, p.ldv, k0 + AT_KT, Vs);
-        sc0 = sn0, sc1 = sn1;
-    }
-    {  // last tile: mask, softmax, P V
-        const int t = ntiles - 1, k0 = t * AT_KT;
-        if (k0 + AT_KT > nk) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (key >= nk) sc0[r] = -__builtin_inff();
-                if (key + 32 >= nk) sc1[r] = -__builtin_inff();
-            }
-        }
-        float mloc = fmaxf(sc0[0], sc1[0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(sc0[r], sc1[r]));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const bool rebase = (t == 0) || (mloc > AT_REBASE);
-        if (__any(rebase)) rebase_by(rebase ? mloc : 0.f, t > 0);
-        float lsum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sc0[r] = __builtin_amdgcn_exp2f(sc0[r]);
-            sc1[r] = __builtin_amdgcn_exp2f(sc1[r]);
-            lsum += sc0[r] + sc1[r];
-        }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l += lsum;
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();  // V(t) visible
-        pv_phase();
-    }
-#endif
     if (!qvalid) return;
     const float inv = (l > 0.f) ? 1.0f / l : 0.f;
     float* op = p.out + (size_t)(pr.q_off + qrow) * p.ldo + h * 64 + kh * 4;

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
     f32x4 aux[16];              // residual values (HAS_RES) / rotary (cos, sin) pairs (ROT) of the block being finished
     const bool vec_ok = ((N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!HAS_RES || (p.ldres & 3) == 0);
     const int nbias = (p.N + 63) / 64 * 64;
-    const int row_lo = m0 + 64 * wm + j;  // the lane's rows: row_lo and row_lo + 32
+    const int row_lo = m0 + 64 * wm + j;  // the lane's rows in the MFMA layout: row_lo and row_lo + 32
+    const int tr = lane >> 3, tc = lane & 7;  // transposed epilogue: lane -> (row tr + 8 i, 16-byte chunk tc) of a 32 x 32 tile
 
     GT_DECL
     set_w_offsets(0);
@@ -341,27 +342,22 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
         const char* na = baseA + (size_t)dst * (DM_KC * 4);
         const char* nw = baseW + (size_t)dst * (DM_KC * 4);
         if (++dst == nstages) dst = 0, ++dcb;
-        if (last) {
-            if (HAS_RES && vec_ok) {
+        if (last && vec_ok) {
+            // residual values / rotary (cos, sin) pairs of this block, in the epilogue's transposed lane mapping (see below):
+            // requested now, in registers when the last MFMAs are done
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int row = row_lo + 32 * (t >> 1);
+            for (int t = 0; t < 4; ++t) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int col = colb + 32 * (t & 1) + 8 * q;
-                        aux[4 * t + q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (row < M && col < N) aux[4 * t + q] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldres + col);
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + 64 * wm + 32 * (t >> 1) + tr + 8 * i;
+                    const int col = n0 + 64 * wn + 32 * (t & 1) + 4 * tc;
+                    if (HAS_RES) {
+                        aux[4 * t + i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (row < M && col < N) aux[4 * t + i] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldres + col);
                     }
-                }
-            }
-            if (rot) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = row_lo + 32 * h;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        aux[8 * h + q] = f32x4{1.f, 0.f, 1.f, 0.f};
-                        if (row < M) aux[8 * h + q] = *reinterpret_cast<const f32x4*>(p.rot_enc + (size_t)row * 64 + 4 * kh + 8 * q);
+                    if (rot) {  // pairs f = (col % 64) / 2 and f + 1 of the row's [f][cos, sin] table
+                        aux[4 * t + i] = f32x4{1.f, 0.f, 1.f, 0.f};
+                        if (row < M) aux[4 * t + i] = *reinterpret_cast<const f32x4*>(p.rot_enc + (size_t)row * 64 + 32 * (t & 1) + 4 * tc);
                     }
                 }
             }
@@ -398,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
         GT_SEG(2)
         __builtin_amdgcn_s_setprio(3);
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): next stage's DMA, bias / residual / rotary loads; older stores are long done
-        if (it + 1 < total) __syncthreads();
+        __syncthreads();  // (also after the last stage: the epilogue below re-uses the consumed buffer as scratch)
         GT_SEG(3)
         if (last) {
             // epilogue of column block cbi; its stores drain under the next block's MFMAs
@@ -416,25 +412,41 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
                 for (int r = 0; r < 16; ++r)
                     c00[r] = fmaxf(c00[r], 0.f), c01[r] = fmaxf(c01[r], 0.f), c10[r] = fmaxf(c10[r], 0.f), c11[r] = fmaxf(c11[r], 0.f);
             }
+            if (vec_ok) {
+                // Transposed through LDS, one 32 x 32 accumulator tile at a time: in the MFMA layout a lane owns a ROW, so a
+                // 16-byte store instruction touches 32 rows x 32 B (64 cache lines per wave-instruction; the epilogue was
+                // store-issue-bound: 6.0 k cycles per tile). After the transpose 8 lanes cover 128 contiguous bytes of a row:
+                // 8 full lines per instruction, and the residual / rotary operands arrive the same way. Scratch = this wave's
+                // OWN 4 KiB slice of the A stage all waves have just finished reading (only this wave's later DMA writes it).
+                float* scr = const_cast<float*>(sA) + 32 * wave * DM_KC;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int row = row_lo + 32 * (t >> 1);
-                const int col0 = colb + 32 * (t & 1);
-                const f32x16& ct = (t == 0) ? c00 : (t == 1) ? c01 : (t == 2) ? c10 : c11;
-                if (row < M) {
-                    float* crow = p.C + (size_t)row * p.ldc + p.c_coff;
-                    if (vec_ok) {
+                for (int t = 0; t < 4; ++t) {
+                    const f32x16& ct = (t == 0) ? c00 : (t == 1) ? c01 : (t == 2) ? c10 : c11;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            f32x4 v = f32x4{ct[4 * q], ct[4 * q + 1], ct[4 * q + 2], ct[4 * q + 3]};
-                            if (rot) {  // (x0, x1) -> (x0 c - x1 s, x1 c + x0 s) per feature pair, as apply_cached_rotary_emb
-                                const f32x4 e = aux[8 * (t >> 1) + 4 * (t & 1) + q];
-                                v = f32x4{(v.x * e.x) + ((-v.y) * e.y), (v.y * e.x) + (v.x * e.y), (v.z * e.z) + ((-v.w) * e.w), (v.w * e.z) + (v.z * e.w)};
-                            }
-                            if (HAS_RES) v = aux[4 * t + q] + v;
-                            if (col0 + 8 * q < N) *reinterpret_cast<f32x4*>(crow + col0 + 8 * q) = v;
+                    for (int q = 0; q < 4; ++q)  // row j, 16-byte chunk 2 q + kh, XOR-swizzled by the row (conflict-free writes)
+                        *reinterpret_cast<f32x4*>(scr + j * 32 + (((2 * q + kh) ^ (j & 7)) << 2)) = f32x4{ct[4 * q], ct[4 * q + 1], ct[4 * q + 2], ct[4 * q + 3]};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int rr = tr + 8 * i;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(scr + rr * 32 + ((tc ^ (rr & 7)) << 2));
+                        const int row = m0 + 64 * wm + 32 * (t >> 1) + rr;
+                        const int col = n0 + 64 * wn + 32 * (t & 1) + 4 * tc;
+                        if (rot) {  // (x0, x1) -> (x0 c - x1 s, x1 c + x0 s) per feature pair, as apply_cached_rotary_emb
+                            const f32x4 e = aux[4 * t + i];
+                            v = f32x4{(v.x * e.x) + ((-v.y) * e.y), (v.y * e.x) + (v.x * e.y), (v.z * e.z) + ((-v.w) * e.w), (v.w * e.z) + (v.z * e.w)};
                         }
-                    } else {
+                        if (HAS_RES) v = aux[4 * t + i] + v;
+                        if (row < M && col < N) *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + p.c_coff + col) = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = row_lo + 32 * (t >> 1);
+                    const int col0 = colb + 32 * (t & 1);
+                    const f32x16& ct = (t == 0) ? c00 : (t == 1) ? c01 : (t == 2) ? c10 : c11;
+                    if (row < M) {
+                        float* crow = p.C + (size_t)row * p.ldc + p.c_coff;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int col = col0 + 8 * (r >> 2) + (r & 3);

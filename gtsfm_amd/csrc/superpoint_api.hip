@@ -211,8 +211,10 @@ SpWorkspace sp_workspace_layout(int B, int H, int W) {
     ws.mask = take(pix8);
     ws.supp = take(pix8);
     ws.rows = take(((size_t)B * Hc * 8 * 2 + B) * 4);
-    // scratch for the top-k path: an NMS radius >= 1 leaves at most one keypoint per 2x2 block (ties aside)
-    ws.full_capacity = (int)(Hc * 8 * Wc * 8 / 4 + 64);
+    // scratch for the top-k path: one slot per pixel, so that no image can overflow it -- NMS leaves far fewer keypoints
+    // on natural images, but a flat or saturated image ties everywhere and keeps every pixel above the threshold; a smaller
+    // scratch would drop the bottom rows silently before the top-k. 12 bytes per pixel and image.
+    ws.full_capacity = (int)(Hc * 8 * Wc * 8);
     ws.xy_full = take((size_t)B * ws.full_capacity * 2 * 4);
     ws.sc_full = take((size_t)B * ws.full_capacity * 4);
     ws.cnt_full = take((size_t)B * 4);
@@ -306,8 +308,8 @@ extern "C" int gtsfm_sp_forward(const float* wts, const void* image_dev, int ima
 
     int32_t* count_raw = kp_count_raw_dev ? kp_count_raw_dev : rows + (size_t)2 * B * H8;  // tail of the rows scratch
     if (Hc == 0 || Wc == 0) {  // image smaller than one 8x8 cell: no keypoints
-        hipMemsetAsync(kp_count_dev, 0, sizeof(int32_t) * B, stream);
-        if (kp_count_raw_dev) hipMemsetAsync(kp_count_raw_dev, 0, sizeof(int32_t) * B, stream);
+        if (hipMemsetAsync(kp_count_dev, 0, sizeof(int32_t) * B, stream) != hipSuccess) return GTSFM_ERR_HIP;
+        if (kp_count_raw_dev && hipMemsetAsync(kp_count_raw_dev, 0, sizeof(int32_t) * B, stream) != hipSuccess) return GTSFM_ERR_HIP;
         return GTSFM_OK;
     }
 

@@ -258,8 +258,8 @@ int launch_extract_keypoints(const float* nms, int B, int H, int W, float thr, i
                              int* count, int* count_raw, float* kp_xy, float* kp_score, hipStream_t stream) {
     if (B == 0) return GTSFM_OK;
     if (H * W == 0) {
-        hipMemsetAsync(count, 0, sizeof(int) * B, stream);
-        hipMemsetAsync(count_raw, 0, sizeof(int) * B, stream);
+        if (hipMemsetAsync(count, 0, sizeof(int) * B, stream) != hipSuccess || hipMemsetAsync(count_raw, 0, sizeof(int) * B, stream) != hipSuccess)
+            return GTSFM_ERR_HIP;
         return GTSFM_OK;
     }
     hipLaunchKernelGGL(kp_count_rows_kernel, dim3(H, B), dim3(64), 0, stream, nms, H, W, thr, border, rowcnt);

@@ -14,8 +14,11 @@ import threading
 from pathlib import Path
 from typing import Optional
 
+import os
+
 _PKG = Path(__file__).resolve().parent.parent
-LIB_PATH = _PKG / "libgtsfm_amd.so"
+# GTSFM_LIB: developer switch -- load a differently built copy of the library (kernel variants for A/B measurements)
+LIB_PATH = Path(os.environ["GTSFM_LIB"]) if os.environ.get("GTSFM_LIB") else _PKG / "libgtsfm_amd.so"
 
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU call 6: LDS-DMA pieces interleaved with the MFMAs
 set -u
-OUT=gpurun_out/r2c6
+OUT=gpurun_out/r2c11
 mkdir -p $OUT
 for shape in "131072 256 768" "131072 512 512" "131072 512 256 1" "131072 256 512" "131072 256 256" "32768 256 768" "5000 256 4800"; do
   timeout 60 tools/bin/gemm_dma_walk $shape | tr '\n' ' ' | sed "s/^/walk2: /"; echo
