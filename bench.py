@@ -154,7 +154,7 @@ def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5):
     achieved = flops / (ms * 1e-3) / 1e12
     t = pmc_traffic("attention_mfma_kernel") if (n, nseq) == (2048, 64) else None
     return {
-        "bound": "mfma", "kernel": "attention_mfma_kernel", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "bound": "mfma", "kernel": "attention_dma_kernel", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
         "traffic": None if t is None else t["fetch_bytes"] + t["write_bytes"],
         "traffic_note": None if t is None else f"HBM bytes per launch, rocprofv3 PMC, {t['source']}",
@@ -177,7 +177,7 @@ def measure_gemm_roofline(lib, device, rows: int, k: int, n: int, reps: int = 5)
     achieved = 2.0 * rows * k * n / (ms * 1e-3) / 1e12
     t = pmc_traffic(f"gemm_dma_kernel_{k}x{n}") if rows == 131072 else None
     return {
-        "bound": "mfma", "kernel": "gemm_dma_kernel", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "bound": "mfma", "kernel": "gemm_dma_walk_kernel", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 4), "launch_shape": f"{rows} x {k} -> {n}",
         "algorithmic_bytes": 4 * (rows * k + n * k + rows * n),
         "traffic": None if t is None else t["fetch_bytes"] + t["write_bytes"],
