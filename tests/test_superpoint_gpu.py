@@ -174,6 +174,36 @@ def test_linear_rowmajor_matches_aten(lib, gpu_device, m, k, n, relu, res, m_liv
     assert float((got[:m_live, 2 : n_live + 2] - ref[:m_live, :n_live]).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("m,k,n,relu,res,m_live,n_live", [(300, 256, 68, 0, 0, 300, 68), (1000, 512, 512, 1, 1, 1000, 512), (260, 256, 300, 0, 1, 200, 296),
+                                                          (4097, 32, 128, 1, 0, 4097, 128), (131, 256, 768, 0, 0, 131, 768), (640, 512, 256, 0, 1, 640, 132)])
+def test_linear_rowmajor_aligned_layout(lib, gpu_device, m, k, n, relu, res, m_live, n_live):
+    """Same kernel with 16-byte aligned rows (ldc % 4 == 0, live column count % 4 == 0): the epilogue that transposes each
+    accumulator tile through LDS and writes full 128-byte lines, incl. partial row / column tiles, several column blocks per
+    workgroup, a single 32-deep stage, bias + scale + ReLU + residual."""
+    gen = torch.Generator().manual_seed(m * 3 + k + n)
+    a = torch.randn((m, k), generator=gen)
+    w = torch.randn((n, k), generator=gen) / k**0.5
+    b = torch.randn((n,), generator=gen)
+    r = torch.randn((m, n + 4), generator=gen)
+    ref = F.linear(a, w, b) * 0.5
+    if relu:
+        ref = F.relu(ref)
+    if res:
+        ref = r[:, :n] + ref
+    ad, wd, rd = a.to(gpu_device), w.to(gpu_device), r.to(gpu_device)
+    out = torch.full((m, n + 8), -5.0, device=gpu_device)  # ldc = n + 8, c_coff = 4
+    bp = _pad64(b, gpu_device)
+    md = torch.tensor([m_live], dtype=torch.int32, device=gpu_device)
+    nd = torch.tensor([n_live], dtype=torch.int32, device=gpu_device)
+    _check(lib, lib.gtsfm_linear_rowmajor_f32(ad.data_ptr(), k, m, md.data_ptr() if m_live < m else None, k, wd.data_ptr(), k, bp.data_ptr(), n,
+                                              nd.data_ptr() if n_live < n else None, out.data_ptr(), n + 8, 4, rd.data_ptr() if res else None, n + 4,
+                                              0.5, relu, _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert torch.all(got[:, :4] == -5.0) and torch.all(got[:, n_live + 4 :] == -5.0) and torch.all(got[m_live:] == -5.0)
+    assert float((got[:m_live, 4 : n_live + 4] - ref[:m_live, :n_live]).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_linear_with_packed_activation_operand(lib, gpu_device):
     """A B^T of two activation matrices through pack_rows (score GEMM, superglue.py:257-258)."""
     a, b = torch.randn((150, 256)), torch.randn((90, 256))
