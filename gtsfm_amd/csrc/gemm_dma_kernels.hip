@@ -498,10 +498,15 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     GTSFM_CHECK_ARG(!(p.rot_enc && p.res), "gemm: rotary epilogue and residual are exclusive");
     GTSFM_CHECK_ARG(!p.rot_enc || (p.rot_cols % 128 == 0 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.c_coff % 4 == 0), "gemm: rotary epilogue needs 16-byte aligned rows");
     GTSFM_CHECK_ARG(!bt.problems || (!p.m_dev && !p.n_dev && !p.tile_cnt_idx && bt.counts), "gemm: a batch takes its sizes from the problem table");
-    // column blocks per workgroup: the whole row of blocks when that still leaves two full rounds of workgroups (512 slots)
+    // Column blocks per workgroup: ONE. The kernel can walk several blocks of a row tile with one stage pipeline, which paid
+    // while the prologue and a burst of DMA pieces per stage were expensive (76 vs 73 % at 256 -> 768). With the pieces issued
+    // between the MFMAs and the transposed epilogue, one block per workgroup is as fast (79.5 / 84.2 / 77.2 % at 256->768 /
+    // 512->512 / 512->256+res against 77.7 / 82.5 / 76.0 walking all blocks; 500 vs 501 image-pairs/s in the workload) and the
+    // workgroups of one row tile then run side by side on ONE XCD (block order below), so its A rows are fetched once and
+    // re-read from that L2: 179 MB fetched per 131072 x 256 -> 768 launch instead of 829 MB (A itself: 134 MB).
+    // GTSFM_GEMM_NB = n walks n blocks (experiments).
     GemmParams q = p;
-    int nbw = ncb;
-    while (nbw > 1 && (long long)mtiles * ceil_div(ncb, nbw) * nprob < 1024) nbw = (nbw + 1) / 2;
+    int nbw = 1;
     static const char* env = getenv("GTSFM_GEMM_NB");
     if (env && atoi(env) > 0) nbw = atoi(env) < ncb ? atoi(env) : ncb;
     q.nb_per_wg = nbw;

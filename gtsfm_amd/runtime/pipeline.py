@@ -91,7 +91,8 @@ class FrontEndPipeline:
         if counts is None:
             counts = feats["count"].cpu().numpy()
         results = []
-        full = bool((counts == feats["xy"].shape[1]).all())
+        used = np.unique(np.asarray(pairs, dtype=np.int64).reshape(-1)) if len(pairs) else np.zeros(0, dtype=np.int64)
+        full = bool((np.asarray(counts)[used] == feats["xy"].shape[1]).all())  # only the images the pairs touch (a gathered table may hold empty slots)
         device = feats["xy"].device
         nstreams = min(self.num_streams, max(1, -(-len(pairs) // self.pair_chunk)))
         side_streams = nstreams > 1 or self.use_graphs  # graphs are captured on (and replayed from) pipeline-owned streams
