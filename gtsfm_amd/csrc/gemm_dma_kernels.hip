@@ -23,211 +23,26 @@
 
 __device__ __forceinline__ int dm_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-template <bool HAS_RES>
-__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A 4096 | W 4096]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware order (speed only): workgroup b runs on XCD b % 8; the column blocks of one row tile get consecutive
-    // slots of ONE XCD, so the A tile is fetched into one L2 and re-read there
-    const int ncb = (p.N + 127) / 128, mtiles = (p.M + 127) / 128;
-    const int b = blockIdx.x, kx = b >> 3;
-    const int mt = (kx / ncb) * 8 + (b & 7), cb = kx % ncb;
-    if (mt >= mtiles) return;
-    const int m0 = mt * 128, n0 = cb * 128;
-    int M = p.m_dev ? *p.m_dev : p.M;
-    const int N = p.n_dev ? *p.n_dev : p.N;
-    if (p.tile_cnt_idx) {  // ragged batch with 128-row-aligned sequences 
-        const int c = p.live_counts[p.tile_cnt_idx[mt]];
-        const int r0 = p.tile_row0[mt];
-        if (r0 >= c) return;
-        M = min(M, m0 + c - r0);
-    }
-    if (m0 >= M || n0 >= N) return;
-    const int j = lane & 31, kh = lane >> 5;
-    const int nstages = p.K / DM_KC;
-
-    // DMA: a wave moves 4 instructions x 8 rows of A and of W per stage (rows 32 wave + 8 i + lane / 8)
-    const int drow = lane >> 3, dpos = lane & 7;
-    auto stage_dma = [&](int st, int buf) {
-        float* sA = lds + buf * DM_STAGE_FLOATS;
-        float* sW = sA + DM_A_FLOATS;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // A: every wave moves 32 rows (4 instructions x 8 rows)
-            const int r = 32 * wave + 8 * i + drow;  // LDS position = r * 32 + dpos * 4 floats
-            int ga = m0 + r;
-            ga = ga < M ? ga : M - 1;  // clamp: rows beyond M are computed and never stored
-            __builtin_amdgcn_global_load_lds(p.A + (size_t)ga * p.lda + st * DM_KC + dm_swz(r, dpos) * 4, sA + (32 * wave + 8 * i) * DM_KC, 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 128 / (8 * 4); ++i) {  // W: 128 rows over all waves
-            const int rb = (128 / 4) * wave + 8 * i, r = rb + drow;
-            int gw = n0 + r;
-            gw = gw < N ? gw : N - 1;  // clamp: columns beyond N are computed and never stored
-            __builtin_amdgcn_global_load_lds(p.wraw + (size_t)gw * p.ldw + st * DM_KC + dm_swz(r, dpos) * 4, sW + rb * DM_KC, 16, 0, 0);
-        }
-    };
-    auto frag = [&](const float* base, int row, int step) {  // 16-byte fragment: floats 8 step + 4 kh .. + 3 of `row`
-        return *reinterpret_cast<const f32x4*>(base + row * DM_KC + dm_swz(row, 2 * step + kh) * 4);
-    };
-
-    GT_DECL
-    f32x16 c00, c01, c10, c11;  // (row half, column half) of the wave's 64 x 64 tile; lane = row, registers = columns
-#ifdef DM_BIAS_LATE
-    // the bias joins in the epilogue: its loads are in flight during the whole tile instead of 32 dependent L2 round trips
-    // ahead of the first MFMA
-    f32x4 bia[8];
-    {
-        const int colb = n0 + 64 * wn + 4 * kh, nb = (p.N + 63) / 64 * 64;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int cc = colb + 32 * (q >> 2) + 8 * (q & 3);
-            bia[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bias && cc < nb) bia[q] = *reinterpret_cast<const f32x4*>(p.bias + cc);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c00[r] = c01[r] = c10[r] = c11[r] = 0.f;
-    }
-#else
-    {
-        const int colb = n0 + 64 * wn + 4 * kh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cc = colb + 8 * (r >> 2) + (r & 3);
-            const float b0 = (p.bias && cc < N) ? p.bias[cc] : 0.f, b1 = (p.bias && cc + 32 < N) ? p.bias[cc + 32] : 0.f;
-            c00[r] = c10[r] = b0;
-            c01[r] = c11[r] = b1;
-        }
-    }
-#endif
-    stage_dma(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's DMA has landed ...
-    __syncthreads();                     // ... and so has everybody else's
-    GT_SEG(0)
-    for (int st = 0; st < nstages; ++st) {
-        const float* sA = lds + (st & 1) * DM_STAGE_FLOATS;
-        const float* sW = sA + DM_A_FLOATS;
-        __builtin_amdgcn_s_setprio(3);
-        if (st + 1 < nstages) stage_dma(st + 1, (st + 1) & 1);  // the other buffer was last read one stage ago
-        __builtin_amdgcn_s_setprio(0);
-        GT_SEG(1)
-        const int ra = 64 * wm + j, rw = 64 * wn + j;
-#define GS(e)                                                             \
-    c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.e, a0.e, c00, 0, 0, 0); \
-    c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a0.e, c01, 0, 0, 0); \
-    c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.e, a1.e, c10, 0, 0, 0); \
-    c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a1.e, c11, 0, 0, 0);
-#ifdef DM_PREFETCH
-        // fragments run one k-step ahead of the MFMAs that consume them (issue order pinned: the 4 LDS reads of step s + 1
-        // go out in front of the 16 MFMAs of step s)
-        f32x4 a0 = frag(sA, ra, 0), a1 = frag(sA, ra + 32, 0), b0 = frag(sW, rw, 0), b1 = frag(sW, rw + 32, 0);
-#pragma unroll
-        for (int s = 0; s < DM_KC / 8; ++s) {
-            f32x4 a0n = a0, a1n = a1, b0n = b0, b1n = b1;
-            if (s + 1 < DM_KC / 8) a0n = frag(sA, ra, s + 1), a1n = frag(sA, ra + 32, s + 1), b0n = frag(sW, rw, s + 1), b1n = frag(sW, rw + 32, s + 1);
-            GS(x) GS(y) GS(z) GS(w)
-            a0 = a0n, a1 = a1n, b0 = b0n, b1 = b1n;
-            if (s + 1 < DM_KC / 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-        }
-#else
-#pragma unroll
-        for (int s = 0; s < DM_KC / 8; ++s) {
-            const f32x4 a0 = frag(sA, ra, s), a1 = frag(sA, ra + 32, s);
-            const f32x4 b0 = frag(sW, rw, s), b1 = frag(sW, rw + 32, s);
-            // weights are the MFMA's A operand, activations its B operand (a lane then owns one output row)
-            GS(x) GS(y) GS(z) GS(w)
-        }
-#endif
-#undef GS
-        GT_SEG(2)
-        if (st + 1 < nstages) {
-            __builtin_amdgcn_s_setprio(3);
-            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-            __syncthreads();
-        }
-        GT_SEG(3)
-    }
-    // epilogue (as gemm_mfma_kernel: scale / ReLU as whole-tile passes, plain and residual variants are separate kernels,
-    // one divergent region per row tile, 16-byte stores when everything is 16-byte aligned)
-#ifdef DM_BIAS_LATE
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        c00[r] += bia[r >> 2][r & 3], c10[r] += bia[r >> 2][r & 3];
-        c01[r] += bia[4 + (r >> 2)][r & 3], c11[r] += bia[4 + (r >> 2)][r & 3];
-    }
-#endif
-    if (p.alpha != 1.0f) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c00[r] *= p.alpha, c01[r] *= p.alpha, c10[r] *= p.alpha, c11[r] *= p.alpha;
-    }
-    if (p.relu) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c00[r] = fmaxf(c00[r], 0.f), c01[r] = fmaxf(c01[r], 0.f), c10[r] = fmaxf(c10[r], 0.f), c11[r] = fmaxf(c11[r], 0.f);
-    }
-    const bool vec_ok = ((N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!HAS_RES || (p.ldres & 3) == 0);
-    const int colb = n0 + 64 * wn + 4 * kh;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int row = m0 + 64 * wm + j + 32 * (t >> 1);
-        const int col0 = colb + 32 * (t & 1);
-        const f32x16& ct = (t == 0) ? c00 : (t == 1) ? c01 : (t == 2) ? c10 : c11;
-        if (row < M) {
-            float* crow = p.C + (size_t)row * p.ldc + p.c_coff;
-            if (vec_ok) {
-                if (!HAS_RES) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (col0 + 8 * q < N) *reinterpret_cast<f32x4*>(crow + col0 + 8 * q) = f32x4{ct[4 * q], ct[4 * q + 1], ct[4 * q + 2], ct[4 * q + 3]};
-                } else {
-                    const float* rrow = p.res + (size_t)row * p.ldres;
-                    const int last_col = N - 4;  // clamp instead of predicating the load (always valid)
-                    f32x4 rr[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) rr[q] = *reinterpret_cast<const f32x4*>(rrow + min(col0 + 8 * q, last_col));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (col0 + 8 * q < N)
-                            *reinterpret_cast<f32x4*>(crow + col0 + 8 * q) = rr[q] + f32x4{ct[4 * q], ct[4 * q + 1], ct[4 * q + 2], ct[4 * q + 3]};
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int col = col0 + 8 * (r >> 2) + (r & 3);
-                    if (col < N) crow[col] = HAS_RES ? p.res[(size_t)row * p.ldres + col] + ct[r] : ct[r];
-                }
-            }
-        }
-    }
-    GT_SEG(4)
-#ifdef GTSFM_TRACE
-    if (lane == 0 && g_gemm_trace) {
-        unsigned long long* o = g_gemm_trace + ((size_t)blockIdx.x * 4 + wave) * 8;
-        for (int k = 0; k < 5; ++k) o[k] = gseg[k];
-        o[5] = (unsigned)__builtin_amdgcn_s_memtime() - gt_begin;
-        o[6] = 1;
-        o[7] = nstages;
-    }
-#endif
-}
-
-
-
 // ---------------------------------------------------------------------------------------------------------------
-// Column-walking form (round 2). The cycle budget of the one-tile-per-workgroup kernel above at 131072 x 256 -> 768
+// The kernel. History (round 2): the first LDS-DMA kernel computed one tile per workgroup with every wave issuing its 8 pieces
+// of a stage as a burst in front of the MFMAs and a row-per-lane epilogue. Its cycle budget at 131072 x 256 -> 768
 // (tools/trace_gemm_dma.hip, profiles/r02_gemm_dma_cycle_budget_before.txt): wave lifetime 81 k cycles per tile of which
 // the prologue (kernel arguments, bias, first DMA round trip, barrier) takes 17.7 k and the epilogue 7.5 k -- a third of
 // a wave's life without a single MFMA, so the SIMD's other wave runs alone (68 % of the matrix pipe) or both idle;
 // issuing the 8 LDS-DMA pieces of a stage costs 1.7 k cycles of 64-bit address arithmetic. Here
-//   * a workgroup walks `nb_per_wg` column blocks of its row tile with ONE continuous stage pipeline: the DMA of the next
-//     block's first stage is issued before the last MFMAs of the current block, so the prologue is paid once per
-//     workgroup and an epilogue costs only its own issue time (its stores drain under the next block's MFMAs);
+//   * a workgroup can walk `nb_per_wg` column blocks of its row tile with ONE continuous stage pipeline (the DMA of the next
+//     block's first stage is issued before the last MFMAs of the current block: prologue once per workgroup; 73 -> 76 %);
+//     since the two steps below the default is nb_per_wg = 1 again -- as fast, and A is read once (see launch_gemm_dma_batched);
+//   * the 8 pieces of the next stage are issued BETWEEN the MFMAs of the current stage's first two k-steps (77 %);
+//   * the epilogue is transposed through LDS so that stores and residual / rotary loads cover full 128-byte lines (79-80 %);
 //   * DMA sources are a uniform base (SGPR pair, advanced per stage) plus 32-bit per-lane offsets computed once;
 //   * the bias joins in the epilogue (its loads fly during the block), the residual rows / rotary cos-sin pairs of a block
 //     are requested before its last stage's MFMAs and are in registers when the epilogue starts;
-//   * ROT: LightGlue's rotary embedding (apply_cached_rotary_emb) on the q and k column blocks in the epilogue -- a lane
-//     owns a row and adjacent register pairs are the (2f, 2f + 1) feature pairs, enc = [token][f][cos, sin].
+//   * ROT: LightGlue's rotary embedding (apply_cached_rotary_emb) on the q and k column blocks in the epilogue,
+//     enc = [token][f][cos, sin];
+//   * ragged batches: per-tile live counts (LightGlue's 128-row-aligned sequences) or a problem table (GemmBatch).
+// Measured and dropped: a fifth loader wave per workgroup issuing all 32 pieces of a stage (62 %: one stage of slack with two
+// buffers); all 8 pieces inside the first k-step (+-0); bias preloaded into the accumulators / fragments one k-step ahead (+-0).
 // ---------------------------------------------------------------------------------------------------------------
 template <bool HAS_RES, bool ROT>
 __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, GemmBatch bt) {
@@ -482,19 +297,8 @@ int launch_gemm_dma(const GemmParams& p, hipStream_t stream) {
 
 int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_t stream) {
     if (p.M <= 0 || (bt.problems && bt.nproblems <= 0)) return GTSFM_OK;
-    static const char* form = getenv("GTSFM_GEMM_DMA");  // "tile": the one-tile-per-workgroup kernel (A/B measurements)
     const int ncb = ceil_div(p.N, 128), mtiles = ceil_div(p.M, 128);
     const int nprob = bt.problems ? bt.nproblems : 1;
-    if (form && form[0] == 't' && !p.rot_enc && !bt.problems) {
-        const dim3 grid(ceil_div(mtiles, 8) * 8 * ncb);
-        const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
-        if (p.res)
-            hipLaunchKernelGGL(gemm_dma_kernel<true>, grid, dim3(256), lds_bytes, stream, p);
-        else
-            hipLaunchKernelGGL(gemm_dma_kernel<false>, grid, dim3(256), lds_bytes, stream, p);
-        GTSFM_CHECK_LAUNCH("gemm_dma_kernel");
-        return GTSFM_OK;
-    }
     GTSFM_CHECK_ARG(!(p.rot_enc && p.res), "gemm: rotary epilogue and residual are exclusive");
     GTSFM_CHECK_ARG(!p.rot_enc || (p.rot_cols % 128 == 0 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.c_coff % 4 == 0), "gemm: rotary epilogue needs 16-byte aligned rows");
     GTSFM_CHECK_ARG(!bt.problems || (!p.m_dev && !p.n_dev && !p.tile_cnt_idx && bt.counts), "gemm: a batch takes its sizes from the problem table");
