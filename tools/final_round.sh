@@ -1,11 +1,17 @@
 #!/bin/bash
-# Round-end GPU pass: parity tests, the bench lines that go to profiles/, kernel stats + PMC passes (tools/prof.sh).
+# Round-end GPU pass: parity tests, smoke, every bench line kept under profiles/, GEMM shapes + cycle budget, kernel stats +
+# PMC passes (tools/prof_r02.sh).   gpurun --timeout 2400 -- 'bash tools/final_round.sh'
 set -u
-mkdir -p gpurun_out/final
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee gpurun_out/final/pytest_gpu.txt
-timeout 400 python bench.py > gpurun_out/final/bench_lightglue.json 2> gpurun_out/final/bench_lightglue.err; tail -c 600 gpurun_out/final/bench_lightglue.json
-timeout 300 python bench.py --matcher superglue --sinkhorn 100 --no-cpu-baseline > gpurun_out/final/bench_superglue_sinkhorn100.json 2>/dev/null; cut -c1-150 gpurun_out/final/bench_superglue_sinkhorn100.json
-timeout 300 python bench.py --matcher superglue --sinkhorn 20 --no-cpu-baseline > gpurun_out/final/bench_superglue_sinkhorn20.json 2>/dev/null; cut -c1-150 gpurun_out/final/bench_superglue_sinkhorn20.json
-timeout 300 python bench.py --matcher none --images 64 --no-cpu-baseline > gpurun_out/final/bench_superpoint_only.json 2>/dev/null; cut -c1-150 gpurun_out/final/bench_superpoint_only.json
-timeout 300 python bench.py --matcher none --height 480 --width 640 --images 256 --no-cpu-baseline > gpurun_out/final/bench_config2.json 2>/dev/null; cut -c1-150 gpurun_out/final/bench_config2.json
-timeout 300 python bench.py --pair-definition independent --pairs 500 --steps 2 --no-cpu-baseline > gpurun_out/final/bench_independent.json 2>/dev/null; cut -c1-150 gpurun_out/final/bench_independent.json
+OUT=gpurun_out/final
+mkdir -p $OUT
+( time timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider ) > $OUT/pytest_gpu.txt 2>&1; tail -4 $OUT/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $OUT/smoke.txt
+( time timeout 900 python bench.py --steps 5 --warmup 2 ) > $OUT/bench_lightglue.json 2> $OUT/bench_lightglue.err; head -c 250 $OUT/bench_lightglue.json; echo; tail -3 $OUT/bench_lightglue.err
+timeout 600 python bench.py --matcher superglue --sinkhorn 100 --steps 3 --warmup 1 --no-secondary > $OUT/bench_superglue_sinkhorn100.json 2>/dev/null; head -c 200 $OUT/bench_superglue_sinkhorn100.json; echo
+timeout 600 python bench.py --matcher superglue --sinkhorn 20 --steps 3 --warmup 1 --no-secondary --no-cpu-baseline > $OUT/bench_superglue_sinkhorn20.json 2>/dev/null; head -c 200 $OUT/bench_superglue_sinkhorn20.json; echo
+timeout 900 python bench.py --mode scene --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_scene_config4.json 2>/dev/null; head -c 200 $OUT/bench_scene_config4.json; echo
+timeout 300 python bench.py --matcher none --height 480 --width 640 --images 256 --steps 3 --warmup 1 > $OUT/bench_config2.json 2>/dev/null; head -c 200 $OUT/bench_config2.json; echo
+timeout 300 python bench.py --matcher none --images 64 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_superpoint_only.json 2>/dev/null; head -c 200 $OUT/bench_superpoint_only.json; echo
+for shape in "131072 256 768" "131072 512 512" "131072 512 256 1" "131072 256 512" "131072 256 256" "32768 256 768" "5000 256 4800"; do timeout 60 tools/bin/gemm_dma_walk $shape | tail -1; done | tee $OUT/gemm_shapes.txt
+for shape in "131072 256 768" "131072 512 512"; do timeout 60 tools/bin/gemm_dma_walk_trace $shape; done > $OUT/gemm_cycle_budget.txt 2>&1
+bash tools/prof_r02.sh 2>&1 | tail -50
