@@ -40,11 +40,12 @@ __device__ __forceinline__ int dm_swz(int row, int chunk) { return chunk ^ ((row
 //     are requested before its last stage's MFMAs and are in registers when the epilogue starts;
 //   * ROT: LightGlue's rotary embedding (apply_cached_rotary_emb) on the q and k column blocks in the epilogue,
 //     enc = [token][f][cos, sin];
-//   * ragged batches: per-tile live counts (LightGlue's 128-row-aligned sequences) or a problem table (GemmBatch).
+//   * ragged batches: per-tile live counts (LightGlue's 128-row-aligned sequences) or a problem table (GemmBatch);
+//   * LNG: LayerNorm + GELU of the workgroup's own rows after its last column block (LightGlue's FFN).
 // Measured and dropped: a fifth loader wave per workgroup issuing all 32 pieces of a stage (62 %: one stage of slack with two
 // buffers); all 8 pieces inside the first k-step (+-0); bias preloaded into the accumulators / fragments one k-step ahead (+-0).
 // ---------------------------------------------------------------------------------------------------------------
-template <bool HAS_RES, bool ROT>
+template <bool HAS_RES, bool ROT, bool LNG = false>
 __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, GemmBatch bt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A 4096 | W 4096]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -274,6 +275,53 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
         GT_SEG(4)
         if (++st == nstages) st = 0, ++cbi;
     }
+    if (LNG) {
+        // y = GELU(LayerNorm(x)) over this workgroup's rows, 512 columns, in place (eps 1e-5, affine; two-pass statistics as
+        // torch.nn.functional.layer_norm -- the same arithmetic as layernorm_gelu_kernel). The stores above are this
+        // workgroup's own: visible to its waves after the barrier.
+        __syncthreads();
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(bt.ln_gamma + lane * 8), g1 = *reinterpret_cast<const f32x4*>(bt.ln_gamma + lane * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bt.ln_beta + lane * 8), b1 = *reinterpret_cast<const f32x4*>(bt.ln_beta + lane * 8 + 4);
+        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll 1
+        for (int r0 = 0; r0 < 32; r0 += 4) {
+            const int row0 = m0 + 32 * wave + r0;
+            if (row0 >= M) break;
+            f32x4 xa[4], xb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* src = p.C + (size_t)min(row0 + r, M - 1) * p.ldc + p.c_coff + lane * 8;
+                xa[r] = *reinterpret_cast<const f32x4*>(src);
+                xb[r] = *reinterpret_cast<const f32x4*>(src + 4);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (row0 + r >= M) break;
+                float v[8] = {xa[r].x, xa[r].y, xa[r].z, xa[r].w, xb[r].x, xb[r].y, xb[r].z, xb[r].w};
+                float sum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += v[e];
+                const float mean = wave_sum(sum) / 512.0f;
+                float ssq = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[e] - mean;
+                    ssq += d * d;
+                }
+                const float var = wave_sum(ssq) / 512.0f;
+                const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float y = (v[e] - mean) * rstd * gm[e] + be[e];
+                    v[e] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+                }
+                float* dst = p.C + (size_t)(row0 + r) * p.ldc + p.c_coff + lane * 8;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+        }
+    }
 #ifdef GTSFM_TRACE
     if (lane == 0 && g_gemm_trace) {
         unsigned long long* o = g_gemm_trace + ((size_t)blockIdx.x * 4 + wave) * 8;
@@ -291,7 +339,7 @@ bool gemm_uses_dma(int K, int ldw) {
 }
 
 int launch_gemm_dma(const GemmParams& p, hipStream_t stream) {
-    GemmBatch none = {nullptr, nullptr, 0};
+    GemmBatch none = {nullptr, nullptr, 0, nullptr, nullptr};
     return launch_gemm_dma_batched(p, none, stream);
 }
 
@@ -313,10 +361,17 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     int nbw = 1;
     static const char* env = getenv("GTSFM_GEMM_NB");
     if (env && atoi(env) > 0) nbw = atoi(env) < ncb ? atoi(env) : ncb;
+    if (bt.ln_gamma) {  // the fused LayerNorm needs every column of a row in one workgroup
+        GTSFM_CHECK_ARG(bt.ln_beta && p.N == 512 && !p.n_dev && !p.res && !p.rot_enc && !bt.problems && p.ldc % 4 == 0 && p.c_coff % 4 == 0 && !p.relu,
+                        "gemm: the LayerNorm + GELU epilogue serves plain 512-column products with 16-byte aligned rows");
+        nbw = ncb;
+    }
     q.nb_per_wg = nbw;
     const dim3 grid(ceil_div(mtiles, 8) * 8 * ceil_div(ncb, nbw), nprob);
     const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
-    if (q.rot_enc)
+    if (bt.ln_gamma)
+        hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
+    else if (q.rot_enc)
         hipLaunchKernelGGL((gemm_dma_walk_kernel<false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
     else if (q.res)
         hipLaunchKernelGGL((gemm_dma_walk_kernel<true, false>), grid, dim3(256), lds_bytes, stream, q, bt);
