@@ -5,7 +5,7 @@
 // pack buffer, with the host's n0 / n1 arrays in the loop.
 #pragma once
 
-#include "dense_kernels.h"
+#include "gemm_kernels.h"
 
 struct GemmProblem {
     long long c_off;  // floats

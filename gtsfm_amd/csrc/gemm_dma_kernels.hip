@@ -4,7 +4,7 @@
 
 #include <stdlib.h>
 
-#include "dense_kernels.h"
+#include "gemm_kernels.h"
 #include "gemm_batch.h"
 #include "trace.h"
 

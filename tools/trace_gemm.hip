@@ -3,7 +3,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <vector>
-#include "../gtsfm_amd/csrc/dense_kernels.hip"
+#include "../gtsfm_amd/csrc/gemm_mfma_kernels.hip"
 
 void gtsfm_set_error(const char* fmt, ...) {
     va_list ap;
