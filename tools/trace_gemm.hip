@@ -5,6 +5,11 @@
 #include <vector>
 #include "../gtsfm_amd/csrc/gemm_mfma_kernels.hip"
 
+// the register-staged kernel alone: no LDS-DMA dispatch, packer restated
+bool gemm_uses_dma(int, int) { return false; }
+int launch_gemm_dma(const GemmParams&, hipStream_t) { return GTSFM_ERR_INVALID; }
+size_t packed_linear_floats(int k, int n) { return (size_t)ceil_div(n, 64) * (k / 8) * MT_PACK_STEP_FLOATS; }
+
 void gtsfm_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
