@@ -62,7 +62,10 @@ class BatchedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
     ) -> Tuple[List[Keypoints], Dict[Tuple[int, int], np.ndarray]]:
         import torch
 
+        from gtsfm_amd.runtime.image_prep import ImagePrep
         from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+
+        prep = None
 
         imgs = self._resolve(client, images)
         det, matcher = self._detector_descriptor, self._matcher
@@ -95,10 +98,18 @@ class BatchedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         for (h, w), idxs in by_shape.items():
             for b0 in range(0, len(idxs), self._image_batch):
                 sel = idxs[b0 : b0 + self._image_batch]
-                gray = np.stack([np.ascontiguousarray(rgb_to_gray_u8(imgs[i].value_array)) for i in sel])
-                if gray.dtype != np.uint8:
-                    gray = gray.astype(np.float32) / 255.0
-                out = det._model.forward(torch.from_numpy(gray).to(device), top_k=k)
+                arrays = [imgs[i].value_array for i in sel]
+                if all(a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == arrays[0].shape[2] for a in arrays):
+                    # RGB(A) uint8: one upload of the batch, gray conversion on the device (same 15-bit fixed-point formula)
+                    if prep is None:
+                        prep = ImagePrep(device)
+                    batch = prep.rgb_to_gray(torch.from_numpy(np.ascontiguousarray(np.stack(arrays))).to(device))
+                else:
+                    gray = np.stack([np.ascontiguousarray(rgb_to_gray_u8(a)) for a in arrays])
+                    if gray.dtype != np.uint8:
+                        gray = gray.astype(np.float32) / 255.0
+                    batch = torch.from_numpy(gray).to(device)
+                out = det._model.forward(batch, top_k=k)
                 ii = torch.tensor(sel, dtype=torch.long, device=device)
                 xy[ii], sc[ii], de[ii] = out["xy"], out["scores"], out["descriptors"]
                 counts[sel] = out["count"].cpu().numpy()

@@ -176,3 +176,25 @@ def test_graph_replay_equals_eager_launches(gpu_device, views, matcher):
                 assert torch.equal(ra["stop"], rb["stop"]) and torch.equal(ra["kept"], rb["kept"])
         assert sum(int((r["matches"] > -1).sum()) for r in a) > 100
     assert len(graphed._graphs) == 2  # one captured graph per stream for the full-chunk shape
+
+
+def test_config1_resolution_input_step_and_superpoint_vs_oracle(gpu_device, sp_engine, sp_sd):
+    """BASELINE config 1's shapes on synthetic pixels: a 1936 x 1296 RGB frame (the Lund-door images' size) goes through the
+    device input step (INTER_CUBIC downsize to the olsson loader's short side of 760 -> 1135 x 760, RGB -> gray) and SuperPoint
+    (neither side a multiple of 8), against the oracle chain; keypoints identical, descriptors within 1e-4."""
+    from gtsfm_amd.runtime.image_prep import ImagePrep
+    from oracle import imageprep_oracle as ipo
+
+    rgb = np.stack([synthetic.synthetic_gray_image(1936, 1296, 61 + c, blur=4 + c) for c in range(3)], -1)
+    gray_dev = ImagePrep(gpu_device).prepare(rgb, max_resolution=760)
+    gray_ref = ipo.rgb_to_gray_u8(ipo.resize_inter_cubic_u8(rgb, *ipo.downsampled_size(1936, 1296, 760)))
+    assert gray_ref.shape == (1135, 760)
+    np.testing.assert_array_equal(gray_dev.cpu().numpy(), gray_ref)
+    out = sp_engine.forward(gray_dev[None].contiguous())
+    k = int(out["count"][0])
+    with torch.no_grad():
+        ora = spo.superpoint_forward(sp_sd, spo.gray_u8_to_tensor(gray_ref))
+    assert k == ora["keypoints"].shape[0] and k > 1000
+    np.testing.assert_array_equal(out["xy"][0, :k].cpu().numpy(), ora["keypoints"].numpy())
+    np.testing.assert_allclose(out["scores"][0, :k].cpu().numpy(), ora["scores"].numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(out["descriptors"][0, :k].cpu().numpy(), ora["descriptors"].numpy().T, rtol=0, atol=TOL)

@@ -488,8 +488,11 @@ def test_batched_correspondence_generator_vs_oracle(gpu_device, sg_sd, tmp_path,
     torch.save(sg_sd, str(tmp_path / "sg.pth"))
     torch.save(lg_sd, str(tmp_path / "lg.pth"))
     views = synthetic.synthetic_overlapping_views(4, 200, 264, seed=91)
-    grays = [views[0], views[1], views[2][:168, :232], views[3]]  # one smaller image: fewer keypoints than the cap
-    images = [Image(value_array=g) for g in grays]
+    from oracle import imageprep_oracle as ipo
+
+    rgb1 = np.stack([views[1], views[1][::-1, ::-1], 255 - views[1]], -1)  # an RGB image: gray conversion on the device
+    grays = [views[0], ipo.rgb_to_gray_u8(rgb1), views[2][:168, :232], views[3]]  # one smaller image: fewer keypoints than the cap
+    images = [Image(value_array=grays[0]), Image(value_array=rgb1), Image(value_array=grays[2]), Image(value_array=grays[3])]
     graph = [(0, 1), (0, 2), (1, 3), (2, 3), (0, 3)]
     cap = 300
     det = SuperPointDetectorDescriptor(max_keypoints=cap, weights_path=tmp_path / "sp.pth")
