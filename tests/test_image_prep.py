@@ -44,6 +44,20 @@ def test_oracle_resize_properties():
     assert ipo.downsampled_size(480, 640, 760) == (480, 640)
 
 
+@pytest.mark.parametrize("h,w,nh,nw", [(300, 200, 120, 80), (484, 324, 283, 190), (97, 131, 64, 64), (64, 64, 200, 150)])
+def test_oracle_resize_agrees_with_an_independent_float_bicubic(h, w, nh, nw):
+    """Independent anchor for the unpinned restatement: ATen's float64 bicubic (same half-pixel mapping, same A = -0.75
+    kernel, replicated borders) rounded to uint8 must agree with the 11-bit fixed-point restatement to one grey level, and
+    on all but a few per cent of the pixels exactly (measured: 0 - 5 %)."""
+    import torch.nn.functional as F
+
+    for img in (synthetic.synthetic_gray_image(h, w, 5, blur=1), np.random.default_rng(1).integers(0, 256, size=(h, w), dtype=np.uint8)):
+        ours = ipo.resize_inter_cubic_u8(img, nh, nw).astype(int)
+        ref = F.interpolate(T(img)[None, None].double(), size=(nh, nw), mode="bicubic", align_corners=False)[0, 0]
+        diff = np.abs(ours - ref.round().clamp(0, 255).numpy().astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 0.08
+
+
 @pytest.mark.parametrize("dst,src", [(760, 1296), (1135, 1936), (44, 70), (90, 90), (200, 77)])
 def test_abi_tap_tables_match_the_oracle(built_library, dst, src):
     """gtsfm_prep_cubic_taps (host C, float32) vs the oracle's numpy float32 restatement: identical integers."""
