@@ -1,0 +1,611 @@
+// Verifier stage on the device: what OpencvVerifierBase.verify does per image pair with
+// use_intrinsics_in_verification=True (gtsfm/frontend/verifier/opencv_verifier_base.py:47-111, ransac.py:52-84, called from
+// gtsfm/two_view_estimator.py:391-397) -- normalise the matched keypoints, RANSAC over five-point essential-matrix
+// hypotheses with the squared Sampson error (gtsfm/utils/verification.py:172-220), cv.recoverPose's cheirality choice --
+// for a whole batch of pairs in two launches, keypoints and matches never leaving HBM.
+//
+// PARITY UNPINNED: cv2.findEssentialMat / cv.recoverPose are OpenCV (absent; its USAC sampler is not reproducible). The
+// published mathematics is restated (Nister's five-point solver, PAMI 2004) with a counter-based sampler; every double
+// operation below follows oracle/verifier_oracle.py in the same order (this file is compiled with -ffp-contract=off and
+// honours NaNs: a degenerate sample turns into NaN models that count zero inliers), so inlier masks are compared bit for bit.
+//
+// Mapping: one workgroup of 256 threads per pair; a round = 256 hypotheses, one per thread (sample, solve, score the <= 10
+// real solutions against all matches of the pair, MSAC cost); rounds stop by the (1 - w^5)^n <= 1 - p rule, at most 4. The solver's
+// 10x20 elimination matrix lives in per-thread scratch: the stage is latency-bound double-precision scalar work, a few
+// hundred microseconds per round, against ~2 ms of matcher time per pair -- no MFMA, no LDS tiling worth having.
+
+#include <math.h>
+
+#include "../../include/gtsfm_amd.h"
+#include "common.h"
+
+#define VF_ROUND 256
+#define VF_MAX_ROUNDS 4
+#define VF_ROOT_RANGE_CAP 1.0e8
+#define VF_BISECT_ITERS 128
+#define VF_JACOBI_SWEEPS 8
+#define VF_DEPTH_LIMIT 50.0
+#define VF_SUCCESS_PROB 0.999999
+
+__constant__ int VF_LIN_LIN[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+__constant__ int VF_QUAD_LIN[10][4] = {{0, 2, 4, 5},     {2, 3, 8, 9},     {4, 8, 10, 11},   {5, 9, 11, 12},   {3, 1, 6, 7},
+                                        {8, 6, 13, 14},   {9, 7, 14, 15},   {10, 13, 16, 17}, {11, 14, 17, 18}, {12, 15, 18, 19}};
+
+__device__ __forceinline__ unsigned long long vf_splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// Five distinct match indices of hypothesis `hyp` (oracle: sample_indices).
+__device__ void vf_sample(unsigned long long seed, unsigned long long hyp, int m, int out[5]) {
+    unsigned long long attempt = 0;
+    for (int k = 0; k < 5; ++k) {
+        for (;;) {
+            const bool exhausted = attempt >= 64;
+            int draw = (int)(vf_splitmix64(seed ^ vf_splitmix64((hyp << 8) | attempt)) % (unsigned long long)m);
+            bool clash = false;
+            for (int j = 0; j < k; ++j) clash |= out[j] == draw;
+            if (exhausted) {
+                for (draw = 0;; ++draw) {
+                    bool used = false;
+                    for (int j = 0; j < k; ++j) used |= out[j] == draw;
+                    if (!used) break;
+                }
+                clash = false;
+            } else {
+                ++attempt;
+            }
+            if (!clash) {
+                out[k] = draw;
+                break;
+            }
+        }
+    }
+}
+
+// Null space of the 5x9 epipolar system: Gauss-Jordan with complete pivoting (oracle: _null_space).
+__device__ void vf_null_space(double a[5][9], double basis[4][9]) {
+    int perm[9];
+    for (int j = 0; j < 9; ++j) perm[j] = j;
+    for (int r = 0; r < 5; ++r) {
+        double best = -1.0;
+        int pr = r, pc = r;
+        for (int i = r; i < 5; ++i)
+            for (int j = r; j < 9; ++j) {
+                const double v = fabs(a[i][j]);
+                if (v > best) {
+                    best = v;
+                    pr = i;
+                    pc = j;
+                }
+            }
+        for (int j = 0; j < 9; ++j) {
+            const double t = a[r][j];
+            a[r][j] = a[pr][j];
+            a[pr][j] = t;
+        }
+        for (int i = 0; i < 5; ++i) {
+            const double t = a[i][r];
+            a[i][r] = a[i][pc];
+            a[i][pc] = t;
+        }
+        {
+            const int t = perm[r];
+            perm[r] = perm[pc];
+            perm[pc] = t;
+        }
+        const double piv = a[r][r];
+        for (int j = r; j < 9; ++j) a[r][j] = a[r][j] / piv;
+        for (int i = 0; i < 5; ++i) {
+            if (i == r) continue;
+            const double f = a[i][r];
+            for (int j = r + 1; j < 9; ++j) a[i][j] = a[i][j] - f * a[r][j];
+            a[i][r] = 0.0;
+        }
+    }
+    for (int k = 0; k < 4; ++k) {
+        for (int j = 0; j < 9; ++j) basis[k][j] = 0.0;
+        basis[k][perm[5 + k]] = 1.0;
+        for (int i = 0; i < 5; ++i) basis[k][perm[i]] = -a[i][5 + k];
+    }
+}
+
+__device__ __forceinline__ void vf_mul_lin_lin(const double* p, const double* q, double* out) {
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            const int k = VF_LIN_LIN[a][b];
+            out[k] = out[k] + p[a] * q[b];
+        }
+}
+
+__device__ __forceinline__ void vf_mul_quad_lin(const double* p, const double* q, double* out) {
+    for (int a = 0; a < 10; ++a)
+        for (int b = 0; b < 4; ++b) {
+            const int k = VF_QUAD_LIN[a][b];
+            out[k] = out[k] + p[a] * q[b];
+        }
+}
+
+// The ten cubic constraints on E = x X + y Y + z Z + W (oracle: _constraints): rows 0..8 (E E^T - tr(E E^T)/2 I) E, row 9 det E.
+__device__ void vf_constraints(const double basis[4][9], double m[10][20]) {
+    double e[3][3][4];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int c = 0; c < 4; ++c) e[i][j][c] = basis[c][3 * i + j];
+    double eet[6][10];  // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+    const int slot[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 3; ++j) {
+            double* acc = eet[slot[i][j]];
+            for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+            for (int k = 0; k < 3; ++k) vf_mul_lin_lin(e[i][k], e[j][k], acc);
+        }
+    double lam_diag[3][10];
+    for (int k = 0; k < 10; ++k) {
+        const double half_trace = ((eet[0][k] + eet[3][k]) + eet[5][k]) * 0.5;
+        lam_diag[0][k] = eet[0][k] - half_trace;
+        lam_diag[1][k] = eet[3][k] - half_trace;
+        lam_diag[2][k] = eet[5][k] - half_trace;
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double* acc = m[3 * i + j];
+            for (int k = 0; k < 20; ++k) acc[k] = 0.0;
+            for (int k = 0; k < 3; ++k) vf_mul_quad_lin(i == k ? lam_diag[i] : eet[slot[i][k]], e[k][j], acc);
+        }
+    double c[3][10];
+    const int ma[3][4][2] = {{{1, 1}, {2, 2}, {1, 2}, {2, 1}}, {{1, 2}, {2, 0}, {1, 0}, {2, 2}}, {{1, 0}, {2, 1}, {1, 1}, {2, 0}}};
+    for (int n = 0; n < 3; ++n) {
+        double p[10], q[10];
+        for (int k = 0; k < 10; ++k) p[k] = q[k] = 0.0;
+        vf_mul_lin_lin(e[ma[n][0][0]][ma[n][0][1]], e[ma[n][1][0]][ma[n][1][1]], p);
+        vf_mul_lin_lin(e[ma[n][2][0]][ma[n][2][1]], e[ma[n][3][0]][ma[n][3][1]], q);
+        for (int k = 0; k < 10; ++k) c[n][k] = p[k] - q[k];
+    }
+    double* acc = m[9];
+    for (int k = 0; k < 20; ++k) acc[k] = 0.0;
+    vf_mul_quad_lin(c[0], e[0][0], acc);
+    vf_mul_quad_lin(c[1], e[0][1], acc);
+    vf_mul_quad_lin(c[2], e[0][2], acc);
+}
+
+// Reduced row echelon form on the ten leading columns, row pivoting (oracle: _gauss_jordan_10x20).
+__device__ void vf_gauss_jordan(double a[10][20]) {
+    for (int c = 0; c < 10; ++c) {
+        double best = -1.0;
+        int pr = c;
+        for (int i = c; i < 10; ++i) {
+            const double v = fabs(a[i][c]);
+            if (v > best) {
+                best = v;
+                pr = i;
+            }
+        }
+        for (int j = 0; j < 20; ++j) {
+            const double t = a[c][j];
+            a[c][j] = a[pr][j];
+            a[pr][j] = t;
+        }
+        const double piv = a[c][c];
+        for (int j = c; j < 20; ++j) a[c][j] = a[c][j] / piv;
+        for (int i = 0; i < 10; ++i) {
+            if (i == c) continue;
+            const double f = a[i][c];
+            for (int j = c + 1; j < 20; ++j) a[i][j] = a[i][j] - f * a[c][j];
+            a[i][c] = 0.0;
+        }
+    }
+}
+
+__device__ __forceinline__ void vf_poly_mul(const double* a, int na, const double* b, int nb, double* out) {
+    for (int k = 0; k < na + nb - 1; ++k) out[k] = 0.0;
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) out[i + j] = out[i + j] + a[i] * b[j];
+}
+
+__device__ __forceinline__ double vf_horner(const double* c, int deg, double x) {
+    double v = c[deg];
+    for (int k = deg - 1; k >= 0; --k) v = v * x + c[k];
+    return v;
+}
+
+// Rows k, l, m of Nister's B(z) from the eliminated tail, then (p1, p2, p3) = row k x row l and det (oracle: _hidden_variable).
+__device__ void vf_hidden_variable(const double a[10][20], double p1[8], double p2[8], double p3[7], double det[11]) {
+    double rx[3][4], ry[3][4], rc[3][5];
+    for (int n = 0; n < 3; ++n) {
+        const double* bp = &a[4 + 2 * n][10];
+        const double* bq = &a[5 + 2 * n][10];
+        rx[n][0] = bp[2], rx[n][1] = bp[1] - bq[2], rx[n][2] = bp[0] - bq[1], rx[n][3] = -bq[0];
+        ry[n][0] = bp[5], ry[n][1] = bp[4] - bq[5], ry[n][2] = bp[3] - bq[4], ry[n][3] = -bq[3];
+        rc[n][0] = bp[9], rc[n][1] = bp[8] - bq[9], rc[n][2] = bp[7] - bq[8], rc[n][3] = bp[6] - bq[7], rc[n][4] = -bq[6];
+    }
+    double u[11], v[11], w[11];
+    vf_poly_mul(ry[0], 4, rc[1], 5, u);
+    vf_poly_mul(rc[0], 5, ry[1], 4, v);
+    for (int k = 0; k < 8; ++k) p1[k] = u[k] - v[k];
+    vf_poly_mul(rc[0], 5, rx[1], 4, u);
+    vf_poly_mul(rx[0], 4, rc[1], 5, v);
+    for (int k = 0; k < 8; ++k) p2[k] = u[k] - v[k];
+    vf_poly_mul(rx[0], 4, ry[1], 4, u);
+    vf_poly_mul(ry[0], 4, rx[1], 4, v);
+    for (int k = 0; k < 7; ++k) p3[k] = u[k] - v[k];
+    vf_poly_mul(p1, 8, rx[2], 4, u);
+    vf_poly_mul(p2, 8, ry[2], 4, v);
+    vf_poly_mul(p3, 7, rc[2], 5, w);
+    for (int k = 0; k < 11; ++k) det[k] = (u[k] + v[k]) + w[k];
+}
+
+// Real roots of a tenth-degree polynomial in [-R, R] through the chain of its derivatives (oracle: real_roots_deg10).
+__device__ int vf_real_roots(const double p[11], double roots[10]) {
+    double big = 0.0;
+    for (int k = 0; k < 10; ++k) {
+        const double v = fabs(p[k] / p[10]);
+        if (v > big) big = v;
+    }
+    double rng = 1.0 + big;
+    if (rng > VF_ROOT_RANGE_CAP) rng = VF_ROOT_RANGE_CAP;
+    double prev[10], cur[10], d[11];
+    int nprev = 0;
+    for (int deg = 1; deg <= 10; ++deg) {
+        const int s = 10 - deg;
+        for (int k = 0; k <= deg; ++k) {
+            double factor = 1.0;
+            for (int i = 1; i <= s; ++i) factor *= (double)(k + i);
+            d[k] = p[k + s] * factor;
+        }
+        int ncur = 0;
+        for (int j = 0; j <= nprev; ++j) {
+            double lo = j == 0 ? -rng : prev[j - 1];
+            double hi = j == nprev ? rng : prev[j];
+            const double flo = vf_horner(d, deg, lo), fhi = vf_horner(d, deg, hi);
+            if ((flo < 0) == (fhi < 0)) continue;
+            const bool neg_lo = flo < 0;
+            for (int it = 0; it < VF_BISECT_ITERS; ++it) {
+                const double mid = 0.5 * (lo + hi);
+                if (!(mid > lo && mid < hi)) break;
+                const double fm = vf_horner(d, deg, mid);
+                if ((fm < 0) == neg_lo)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            cur[ncur++] = 0.5 * (lo + hi);
+        }
+        for (int j = 0; j < ncur; ++j) prev[j] = cur[j];
+        nprev = ncur;
+    }
+    for (int j = 0; j < nprev; ++j) roots[j] = prev[j];
+    return nprev;
+}
+
+// Squared Sampson error of one correspondence (gtsfm/utils/verification.py:172-220; oracle: sampson_sq).
+__device__ __forceinline__ double vf_sampson_sq(const double* e, double a, double b, double c, double d) {
+    const double l2x = (e[0] * a + e[1] * b) + e[2];
+    const double l2y = (e[3] * a + e[4] * b) + e[5];
+    const double l2z = (e[6] * a + e[7] * b) + e[8];
+    const double l1x = (e[0] * c + e[3] * d) + e[6];
+    const double l1y = (e[1] * c + e[4] * d) + e[7];
+    const double r = (c * l2x + d * l2y) + l2z;
+    const double den = ((l2x * l2x + l2y * l2y) + l1x * l1x) + l1y * l1y;
+    return (r * r) / den;
+}
+
+__global__ __launch_bounds__(256) void verify_gather_kernel(const float* __restrict__ kp_xy, const long long* __restrict__ kp_off1,
+                                                            const long long* __restrict__ kp_off2, const int* __restrict__ match_idx,
+                                                            const long long* __restrict__ match_off, const double* __restrict__ intrinsics,
+                                                            double* __restrict__ pts) {
+    const int pair = blockIdx.y;
+    const long long begin = match_off[pair], m = match_off[pair + 1] - begin;
+    const double* K = intrinsics + 8 * (size_t)pair;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
+        const int* mi = match_idx + 2 * (begin + i);
+        const float* a = kp_xy + 2 * (kp_off1[pair] + mi[0]);
+        const float* b = kp_xy + 2 * (kp_off2[pair] + mi[1]);
+        double* o = pts + 4 * (begin + i);
+        o[0] = ((double)a[0] - K[2]) / K[0];
+        o[1] = ((double)a[1] - K[3]) / K[1];
+        o[2] = ((double)b[0] - K[6]) / K[4];
+        o[3] = ((double)b[1] - K[7]) / K[5];
+    }
+}
+
+struct VfShared {
+    double cost[256];
+    int index[256];
+    double best_e[9];
+    double best_cost;
+    int best_count, best_index, stop, inliers;
+    double pose[2][9];
+    double t[3];
+    int good[4];
+};
+
+// Cyclic Jacobi eigen-decomposition of a symmetric 3x3 (oracle: _jacobi_eigen_sym3).
+__device__ void vf_jacobi3(double a[3][3], double v[3][3]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) v[i][j] = i == j ? 1.0 : 0.0;
+    const int pq[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int sweep = 0; sweep < VF_JACOBI_SWEEPS; ++sweep)
+        for (int n = 0; n < 3; ++n) {
+            const int p = pq[n][0], q = pq[n][1];
+            if (a[p][q] == 0.0) continue;
+            const double tau = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+            const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            const double c = 1.0 / sqrt(1.0 + t * t);
+            const double sn = t * c;
+            const double app = a[p][p], aqq = a[q][q], apq = a[p][q];
+            a[p][p] = app - t * apq;
+            a[q][q] = aqq + t * apq;
+            a[p][q] = a[q][p] = 0.0;
+            const int r = 3 - p - q;
+            const double arp = a[r][p], arq = a[r][q];
+            a[r][p] = a[p][r] = c * arp - sn * arq;
+            a[r][q] = a[q][r] = sn * arp + c * arq;
+            for (int k = 0; k < 3; ++k) {
+                const double vkp = v[k][p], vkq = v[k][q];
+                v[k][p] = c * vkp - sn * vkq;
+                v[k][q] = sn * vkp + c * vkq;
+            }
+        }
+}
+
+__device__ __forceinline__ void vf_mat3(const double a[3][3], const double b[3][3], double out[3][3]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) out[i][j] = (a[i][0] * b[0][j] + a[i][1] * b[1][j]) + a[i][2] * b[2][j];
+}
+
+// E -> R1, R2 (row-major) and t as cv.decomposeEssentialMat (oracle: decompose_essential).
+__device__ void vf_decompose(const double* ev, double r1[9], double r2[9], double t[3]) {
+    double e[3][3], s[3][3], v[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) e[i][j] = ev[3 * i + j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) s[i][j] = (e[0][i] * e[0][j] + e[1][i] * e[1][j]) + e[2][i] * e[2][j];
+    vf_jacobi3(s, v);
+    const double lam[3] = {s[0][0], s[1][1], s[2][2]};
+    int order[3] = {0, 1, 2};  // descending eigenvalue, ties by index (insertion sort, stable)
+    for (int i = 1; i < 3; ++i)
+        for (int j = i; j > 0 && lam[order[j]] > lam[order[j - 1]]; --j) {
+            const int tmp = order[j];
+            order[j] = order[j - 1];
+            order[j - 1] = tmp;
+        }
+    double v0[3], v1[3], u0[3], u1[3], u2[3], v2[3];
+    for (int k = 0; k < 3; ++k) v0[k] = v[k][order[0]], v1[k] = v[k][order[1]];
+    for (int i = 0; i < 3; ++i) u0[i] = (e[i][0] * v0[0] + e[i][1] * v0[1]) + e[i][2] * v0[2];
+    double n = sqrt((u0[0] * u0[0] + u0[1] * u0[1]) + u0[2] * u0[2]);
+    for (int i = 0; i < 3; ++i) u0[i] = u0[i] / n;
+    for (int i = 0; i < 3; ++i) u1[i] = (e[i][0] * v1[0] + e[i][1] * v1[1]) + e[i][2] * v1[2];
+    const double dot = (u0[0] * u1[0] + u0[1] * u1[1]) + u0[2] * u1[2];
+    for (int i = 0; i < 3; ++i) u1[i] = u1[i] - dot * u0[i];
+    n = sqrt((u1[0] * u1[0] + u1[1] * u1[1]) + u1[2] * u1[2]);
+    for (int i = 0; i < 3; ++i) u1[i] = u1[i] / n;
+    u2[0] = u0[1] * u1[2] - u0[2] * u1[1], u2[1] = u0[2] * u1[0] - u0[0] * u1[2], u2[2] = u0[0] * u1[1] - u0[1] * u1[0];
+    v2[0] = v0[1] * v1[2] - v0[2] * v1[1], v2[1] = v0[2] * v1[0] - v0[0] * v1[2], v2[2] = v0[0] * v1[1] - v0[1] * v1[0];
+    double um[3][3], vt[3][3], uw[3][3], out[3][3];
+    for (int i = 0; i < 3; ++i) um[i][0] = u0[i], um[i][1] = u1[i], um[i][2] = u2[i];
+    for (int j = 0; j < 3; ++j) vt[0][j] = v0[j], vt[1][j] = v1[j], vt[2][j] = v2[j];
+    const double w[3][3] = {{0.0, -1.0, 0.0}, {1.0, 0.0, 0.0}, {0.0, 0.0, 1.0}};
+    const double wt[3][3] = {{0.0, 1.0, 0.0}, {-1.0, 0.0, 0.0}, {0.0, 0.0, 1.0}};
+    vf_mat3(um, w, uw);
+    vf_mat3(uw, vt, out);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r1[3 * i + j] = out[i][j];
+    vf_mat3(um, wt, uw);
+    vf_mat3(uw, vt, out);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r2[3 * i + j] = out[i][j];
+    for (int i = 0; i < 3; ++i) t[i] = u2[i];
+}
+
+// Both depths of l1 R x1 + t = l2 x2 in (0, VF_DEPTH_LIMIT)? (oracle: cheirality_count)
+__device__ __forceinline__ bool vf_in_front(const double* r, double t0, double t1, double t2, double x, double y, double bx, double by) {
+    const double ax = (r[0] * x + r[1] * y) + r[2];
+    const double ay = (r[3] * x + r[4] * y) + r[5];
+    const double az = (r[6] * x + r[7] * y) + r[8];
+    const double aa = (ax * ax + ay * ay) + az * az;
+    const double bb = (bx * bx + by * by) + 1.0;
+    const double ab = (ax * bx + ay * by) + az;
+    const double at = (ax * t0 + ay * t1) + az * t2;
+    const double bt = (bx * t0 + by * t1) + t2;
+    const double det = aa * bb - ab * ab;
+    const double l1 = (ab * bt - at * bb) / det;
+    const double l2 = (aa * bt - ab * at) / det;
+    return l1 > 0 && l2 > 0 && l1 < VF_DEPTH_LIMIT && l2 < VF_DEPTH_LIMIT;
+}
+
+__global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __restrict__ pts, const long long* __restrict__ match_off,
+                                                            const double* __restrict__ intrinsics, const unsigned long long* __restrict__ seeds,
+                                                            double threshold_px, double* __restrict__ out_e, double* __restrict__ out_r,
+                                                            double* __restrict__ out_t, unsigned char* __restrict__ out_mask,
+                                                            int* __restrict__ out_stats) {
+    __shared__ VfShared sh;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const long long begin = match_off[pair];
+    const int m = (int)(match_off[pair + 1] - begin);
+    const double* P = pts + 4 * begin;
+    unsigned char* mask = out_mask + begin;
+    int* stats = out_stats + 8 * (size_t)pair;
+    if (m < 6) {  // NUM_MATCHES_REQ_E_MATRIX and the "< 6" guard of opencv_verifier_base.py:79
+        for (int i = tid; i < m; i += 256) mask[i] = 0;
+        if (tid < 8) stats[tid] = tid >= 2 && tid < 4 ? -1 : 0;
+        if (tid < 9) out_e[9 * (size_t)pair + tid] = out_r[9 * (size_t)pair + tid] = NAN;
+        if (tid < 3) out_t[3 * (size_t)pair + tid] = NAN;
+        return;
+    }
+    const double fx = intrinsics[8 * (size_t)pair] > intrinsics[8 * (size_t)pair + 4] ? intrinsics[8 * (size_t)pair] : intrinsics[8 * (size_t)pair + 4];
+    const double thr = threshold_px / fx, thr2 = thr * thr;
+    const unsigned long long seed = seeds[pair];
+    if (tid == 0) sh.best_cost = INFINITY, sh.best_count = 0, sh.best_index = -1, sh.stop = 0;
+    __syncthreads();
+
+    int rounds = 0;
+    for (int rnd = 0; rnd < VF_MAX_ROUNDS; ++rnd) {
+        const int hyp = rnd * VF_ROUND + tid;
+        int idx[5];
+        vf_sample(seed, (unsigned long long)hyp, m, idx);
+        double basis[4][9];
+        double my_e[9];
+        double my_cost = INFINITY;
+        int my_count = 0, my_root = 0;
+        {
+            double q[5][9];
+            for (int k = 0; k < 5; ++k) {
+                const double a = P[4 * idx[k]], b = P[4 * idx[k] + 1], c = P[4 * idx[k] + 2], d = P[4 * idx[k] + 3];
+                q[k][0] = c * a, q[k][1] = c * b, q[k][2] = c, q[k][3] = d * a, q[k][4] = d * b, q[k][5] = d, q[k][6] = a, q[k][7] = b, q[k][8] = 1.0;
+            }
+            vf_null_space(q, basis);
+        }
+        double p1[8], p2[8], p3[7], det[11], roots[10];
+        {
+            double mat[10][20];
+            vf_constraints(basis, mat);
+            vf_gauss_jordan(mat);
+            vf_hidden_variable(mat, p1, p2, p3, det);
+        }
+        const int nroots = vf_real_roots(det, roots);
+        for (int r = 0; r < nroots; ++r) {
+            const double z = roots[r];
+            const double x = vf_horner(p1, 7, z) / vf_horner(p3, 6, z);
+            const double y = vf_horner(p2, 7, z) / vf_horner(p3, 6, z);
+            double e[9];
+            for (int k = 0; k < 9; ++k) e[k] = ((x * basis[0][k] + y * basis[1][k]) + z * basis[2][k]) + basis[3][k];
+            // MSAC cost (USAC's default score): sum of min(error, thr^2), added in match order; NaN errors are outliers
+            double cost = 0.0;
+            int count = 0;
+            for (int i = 0; i < m; ++i) {
+                const double err = vf_sampson_sq(e, P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]);
+                const bool in = err < thr2;
+                cost = cost + (in ? err : thr2);
+                count += in ? 1 : 0;
+            }
+            if (cost < my_cost) {
+                my_cost = cost, my_count = count, my_root = r;
+                for (int k = 0; k < 9; ++k) my_e[k] = e[k];
+            }
+        }
+        // round winner: lowest cost, then the smallest (hypothesis, root)
+        sh.cost[tid] = my_cost;
+        sh.index[tid] = hyp * 16 + my_root;
+        __syncthreads();
+        for (int step = 128; step > 0; step >>= 1) {
+            if (tid < step) {
+                const double c0 = sh.cost[tid], c1 = sh.cost[tid + step];
+                if (c1 < c0 || (c1 == c0 && sh.index[tid + step] < sh.index[tid])) sh.cost[tid] = c1, sh.index[tid] = sh.index[tid + step];
+            }
+            __syncthreads();
+        }
+        const double win_cost = sh.cost[0];
+        const int win_index = sh.index[0];
+        const bool improves = win_cost < sh.best_cost;
+        __syncthreads();
+        if (improves && hyp * 16 + my_root == win_index) {
+            for (int k = 0; k < 9; ++k) sh.best_e[k] = my_e[k];
+            sh.best_cost = win_cost;
+            sh.best_count = my_count;
+            sh.best_index = win_index;
+        }
+        __syncthreads();
+        rounds = rnd + 1;
+        if (tid == 0 && sh.best_count > 0) {  // (1 - w^5)^(256 rounds) <= 1 - p, exact multiplication chain (oracle: _stop_after)
+            const double w = (double)sh.best_count / (double)m;
+            const double q = 1.0 - w * w * w * w * w;
+            double p256 = q;
+            for (int k = 0; k < 8; ++k) p256 = p256 * p256;
+            double acc = p256;
+            for (int k = 0; k < rounds - 1; ++k) acc = acc * p256;
+            sh.stop = acc <= 1.0 - VF_SUCCESS_PROB ? 1 : 0;
+        }
+        __syncthreads();
+        if (sh.stop) break;
+    }
+
+    if (sh.best_index < 0) {  // no sample produced a model
+        for (int i = tid; i < m; i += 256) mask[i] = 0;
+        if (tid < 8) stats[tid] = tid == 1 ? rounds * VF_ROUND : (tid >= 2 && tid < 4 ? -1 : 0);
+        if (tid < 9) out_e[9 * (size_t)pair + tid] = out_r[9 * (size_t)pair + tid] = NAN;
+        if (tid < 3) out_t[3 * (size_t)pair + tid] = NAN;
+        return;
+    }
+    double e[9];
+    for (int k = 0; k < 9; ++k) e[k] = sh.best_e[k];
+    if (tid == 0) {
+        sh.inliers = 0;
+        for (int k = 0; k < 4; ++k) sh.good[k] = 0;
+        double r1[9], r2[9], t[3];
+        vf_decompose(e, r1, r2, t);
+        for (int k = 0; k < 9; ++k) sh.pose[0][k] = r1[k], sh.pose[1][k] = r2[k];
+        for (int k = 0; k < 3; ++k) sh.t[k] = t[k];
+    }
+    __syncthreads();
+    int inl = 0, good[4] = {0, 0, 0, 0};
+    const double t0 = sh.t[0], t1 = sh.t[1], t2 = sh.t[2];
+    for (int i = tid; i < m; i += 256) {
+        const double a = P[4 * i], b = P[4 * i + 1], c = P[4 * i + 2], d = P[4 * i + 3];
+        const bool in = vf_sampson_sq(e, a, b, c, d) < thr2;
+        mask[i] = in ? 1 : 0;
+        if (in) {
+            ++inl;
+            good[0] += vf_in_front(sh.pose[0], t0, t1, t2, a, b, c, d) ? 1 : 0;
+            good[1] += vf_in_front(sh.pose[1], t0, t1, t2, a, b, c, d) ? 1 : 0;
+            good[2] += vf_in_front(sh.pose[0], -t0, -t1, -t2, a, b, c, d) ? 1 : 0;
+            good[3] += vf_in_front(sh.pose[1], -t0, -t1, -t2, a, b, c, d) ? 1 : 0;
+        }
+    }
+    atomicAdd(&sh.inliers, inl);
+    for (int k = 0; k < 4; ++k) atomicAdd(&sh.good[k], good[k]);
+    __syncthreads();
+    if (tid == 0) {
+        int pick = 3;
+        for (int k = 0; k < 4; ++k) {
+            bool top = true;
+            for (int j = 0; j < 4; ++j) top &= sh.good[k] >= sh.good[j];
+            if (top) {
+                pick = k;
+                break;
+            }
+        }
+        const double sign = pick >= 2 ? -1.0 : 1.0;
+        for (int k = 0; k < 9; ++k) {
+            out_e[9 * (size_t)pair + k] = e[k];
+            out_r[9 * (size_t)pair + k] = sh.pose[pick & 1][k];
+        }
+        for (int k = 0; k < 3; ++k) out_t[3 * (size_t)pair + k] = sign < 0 ? -sh.t[k] : sh.t[k];
+        stats[0] = sh.inliers, stats[1] = rounds * VF_ROUND, stats[2] = sh.best_index >> 4, stats[3] = sh.best_index & 15;
+        for (int k = 0; k < 4; ++k) stats[4 + k] = sh.good[k];
+    }
+}
+
+extern "C" size_t gtsfm_verify_workspace_bytes(long long total_matches) {
+    return align_up((size_t)(total_matches > 0 ? total_matches : 0) * 4 * sizeof(double), 256) + 256;
+}
+
+extern "C" int gtsfm_verify_essential_f64(const float* kp_xy_dev, const long long* kp_off1_dev, const long long* kp_off2_dev,
+                                          const int32_t* match_idx_dev, const long long* match_off_dev, long long total_matches,
+                                          const double* intrinsics_dev, const unsigned long long* seeds_dev, double threshold_px,
+                                          int num_pairs, void* workspace_dev, size_t workspace_bytes, double* essential_dev,
+                                          double* rotation_dev, double* translation_dev, uint8_t* inlier_mask_dev, int32_t* stats_dev,
+                                          void* stream) {
+    GTSFM_CHECK_ARG(num_pairs >= 0 && total_matches >= 0 && threshold_px > 0, "verify_essential: bad sizes or threshold");
+    if (num_pairs == 0) return GTSFM_OK;
+    GTSFM_CHECK_ARG(kp_xy_dev && kp_off1_dev && kp_off2_dev && match_off_dev && intrinsics_dev && seeds_dev, "verify_essential: null input");
+    GTSFM_CHECK_ARG(essential_dev && rotation_dev && translation_dev && stats_dev, "verify_essential: null output");
+    GTSFM_CHECK_ARG(total_matches == 0 || (match_idx_dev && inlier_mask_dev), "verify_essential: null match arrays");
+    GTSFM_CHECK_ARG(num_pairs <= 65535, "verify_essential: at most 65535 pairs per call");
+    if (workspace_bytes < gtsfm_verify_workspace_bytes(total_matches) || !workspace_dev) {
+        gtsfm_set_error("verify_essential: workspace too small (%zu < %zu)", workspace_bytes, gtsfm_verify_workspace_bytes(total_matches));
+        return GTSFM_ERR_WORKSPACE;
+    }
+    double* pts = (double*)align_up((size_t)workspace_dev, 256);
+    if (total_matches > 0) {
+        hipLaunchKernelGGL(verify_gather_kernel, dim3(4, num_pairs), dim3(256), 0, (hipStream_t)stream, kp_xy_dev, kp_off1_dev, kp_off2_dev,
+                           match_idx_dev, match_off_dev, intrinsics_dev, pts);
+        GTSFM_CHECK_LAUNCH("verify_gather_kernel");
+    }
+    hipLaunchKernelGGL(verify_ransac_kernel, dim3(num_pairs), dim3(256), 0, (hipStream_t)stream, pts, match_off_dev, intrinsics_dev, seeds_dev,
+                       threshold_px, essential_dev, rotation_dev, translation_dev, inlier_mask_dev, stats_dev);
+    GTSFM_CHECK_LAUNCH("verify_ransac_kernel");
+    return GTSFM_OK;
+}

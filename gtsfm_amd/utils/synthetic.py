@@ -309,3 +309,47 @@ def synthetic_pair_features(
         s1[dst] = np.clip(s0[src] * rng.uniform(0.8, 1.2, m), 0.0051, 1.0).astype(np.float32)
         gt[src] = dst
     return k0, s0, d0, k1, s1, d1, gt
+
+
+def _rotation_about(axis: np.ndarray, angle: float) -> np.ndarray:
+    axis = np.asarray(axis, dtype=np.float64) / np.linalg.norm(axis)
+    k = np.array([[0.0, -axis[2], axis[1]], [axis[2], 0.0, -axis[0]], [-axis[1], axis[0], 0.0]])
+    return np.eye(3) + np.sin(angle) * k + (1.0 - np.cos(angle)) * (k @ k)
+
+
+def synthetic_two_view_matches(
+    num_matches: int, outlier_ratio: float = 0.0, noise_px: float = 0.0, seed: int = 0, fx: float = 800.0, width: int = 1024, height: int = 1024,
+    num_extra_keypoints: int = 0,
+) -> Dict[str, np.ndarray]:
+    """A two-view scene for the verifier stage: 3-D points in a slab 6-14 units in front of camera 1, a second camera
+    rotated by 0.25 rad about a seeded axis and displaced by a unit vector, pinhole projection with (fx, fx, w/2, h/2),
+    Gaussian pixel noise, and the first ``outlier_ratio`` share of the matches re-pointed at random pixels of image 2.
+    Keypoint tables are shuffled (and padded with unmatched keypoints) so match indices are not the identity.
+
+    Returns coordinates_i1/2 float32 (N1|N2, 2), match_indices int32 (M, 2), is_inlier bool (M), i2Ri1 (3,3), i2Ui1 (3,),
+    intrinsics (fx, fy, cx, cy)."""
+    rng = np.random.default_rng(seed)
+    cx, cy = width / 2.0, height / 2.0
+    pts = np.stack([rng.uniform(-4, 4, num_matches), rng.uniform(-3, 3, num_matches), rng.uniform(6, 14, num_matches)], 1)
+    rot = _rotation_about(rng.normal(size=3), 0.25)
+    trans = rng.normal(size=3)
+    trans /= np.linalg.norm(trans)
+    p2 = pts @ rot.T + trans
+    uv1 = pts[:, :2] / pts[:, 2:] * fx + [cx, cy] + noise_px * rng.normal(size=(num_matches, 2))
+    uv2 = p2[:, :2] / p2[:, 2:] * fx + [cx, cy] + noise_px * rng.normal(size=(num_matches, 2))
+    num_out = int(round(outlier_ratio * num_matches))
+    uv2[:num_out] = rng.uniform([0, 0], [width, height], size=(num_out, 2))
+    is_inlier = np.arange(num_matches) >= num_out
+    extra1 = rng.uniform([0, 0], [width, height], size=(num_extra_keypoints, 2))
+    extra2 = rng.uniform([0, 0], [width, height], size=(num_extra_keypoints, 2))
+    perm1 = rng.permutation(num_matches + num_extra_keypoints)
+    perm2 = rng.permutation(num_matches + num_extra_keypoints)
+    c1 = np.concatenate([uv1, extra1], 0)[perm1].astype(np.float32)
+    c2 = np.concatenate([uv2, extra2], 0)[perm2].astype(np.float32)
+    inv1, inv2 = np.argsort(perm1), np.argsort(perm2)
+    order = rng.permutation(num_matches)
+    match_indices = np.stack([inv1[:num_matches], inv2[:num_matches]], 1)[order].astype(np.int32)
+    return {
+        "coordinates_i1": c1, "coordinates_i2": c2, "match_indices": match_indices, "is_inlier": is_inlier[order], "i2Ri1": rot,
+        "i2Ui1": trans, "intrinsics": (fx, fx, cx, cy),
+    }

@@ -219,6 +219,30 @@ int gtsfm_lg_forward(const float* blob_dev, int num_layers, const float* match_b
                      float width_confidence, float filter_threshold, int pruning_threshold, void* workspace_dev,
                      size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev, void* stream);
 
+/* ---- verifier stage behind the matcher (float64) ----
+ * OpencvVerifierBase.verify with use_intrinsics_in_verification=True for a batch of pairs.
+ *                                  replaces gtsfm/frontend/verifier/opencv_verifier_base.py:47-111 + ransac.py:52-84
+ *                                  (cv2.findEssentialMat) + gtsfm/utils/verification.py:54-96 (cv.recoverPose),
+ *                                  called from gtsfm/two_view_estimator.py:391-397.
+ * PARITY UNPINNED (OpenCV absent, its sampler not reproducible): Nister's five-point solver, squared Sampson error
+ * (gtsfm/utils/verification.py:172-220), RANSAC with a counter-based sampler (splitmix64 of seed / hypothesis / attempt),
+ * 256 hypotheses per round, at most 4 rounds, stop when (1 - w^5)^n <= 1e-6; see oracle/verifier_oracle.py.
+ * kp_xy_dev [*][2] float32 pixel coordinates of all keypoint tables; pair p uses the tables starting at rows kp_off1_dev[p]
+ * (image i1) and kp_off2_dev[p] (image i2). match_idx_dev [total_matches][2] int32 (row in i1's table, row in i2's table),
+ * pair p owning rows match_off_dev[p] .. match_off_dev[p+1]. intrinsics_dev [num_pairs][8] = fx, fy, cx, cy of i1 then i2
+ * (pinhole; lens distortion is the caller's to remove). threshold_px is divided by max(fx1, fx2) as the reference does.
+ * Outputs per pair: essential_dev [9] i2Ei1 (unnormalised), rotation_dev [9] i2Ri1 row-major, translation_dev [3] unit i2Ui1,
+ * inlier_mask_dev [total_matches] (1 = verified), stats_dev [8] int32 = inliers, hypotheses drawn, winning hypothesis,
+ * winning root, cheirality counts of (R1,t) (R2,t) (R1,-t) (R2,-t). Pairs with fewer than 6 matches or no model: inliers = 0,
+ * NaN matrices (the reference's failure tuple is built by the caller). */
+size_t gtsfm_verify_workspace_bytes(long long total_matches);
+int gtsfm_verify_essential_f64(const float* kp_xy_dev, const long long* kp_off1_dev, const long long* kp_off2_dev,
+                               const int32_t* match_idx_dev, const long long* match_off_dev, long long total_matches,
+                               const double* intrinsics_dev, const unsigned long long* seeds_dev, double threshold_px,
+                               int num_pairs, void* workspace_dev, size_t workspace_bytes, double* essential_dev,
+                               double* rotation_dev, double* translation_dev, uint8_t* inlier_mask_dev, int32_t* stats_dev,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,142 @@
+"""Verifier-stage oracle (``oracle/verifier_oracle.py``) and host logic, CPU only.
+
+PARITY UNPINNED towards OpenCV (see the oracle's header). What can be checked without it: the restated mathematics against
+independent numpy implementations (LAPACK SVD / eigenvalues / roots), the geometric definition of the solver's output, and
+the reference's own verifier contract suite (``tests/frontend/verifier/test_verifier_base.py``) run on the oracle."""
+
+import pickle
+
+import numpy as np
+import pytest
+
+from gtsfm_amd.utils import synthetic
+from oracle import verifier_oracle as vo
+
+
+def _angle(r_a, r_b):
+    return np.degrees(np.arccos(np.clip((np.trace(r_a.T @ r_b) - 1) / 2, -1, 1)))
+
+
+def _normalised_scene(m, outliers=0.0, noise=0.0, seed=0):
+    s = synthetic.synthetic_two_view_matches(m, outliers, noise, seed=seed)
+    n1 = vo.normalize_pinhole(s["coordinates_i1"], *s["intrinsics"])[s["match_indices"][:, 0]]
+    n2 = vo.normalize_pinhole(s["coordinates_i2"], *s["intrinsics"])[s["match_indices"][:, 1]]
+    return s, n1, n2
+
+
+def test_sampler_is_distinct_deterministic_and_covers_tiny_sets():
+    idx = vo.sample_indices(7, np.arange(512), 50)
+    assert idx.shape == (512, 5) and all(len(set(r)) == 5 for r in idx.tolist())
+    np.testing.assert_array_equal(idx, vo.sample_indices(7, np.arange(512), 50))
+    assert (idx != vo.sample_indices(8, np.arange(512), 50)).any()
+    tiny = vo.sample_indices(0, np.arange(256), 5)  # five of five: every draw must terminate
+    assert all(sorted(r) == [0, 1, 2, 3, 4] for r in tiny.tolist())
+    assert np.bincount(idx.reshape(-1), minlength=50).min() > 20  # roughly uniform
+
+
+def test_root_finder_against_companion_matrix_eigenvalues():
+    rng = np.random.default_rng(0)
+    polys = rng.normal(size=(64, 11))
+    polys[:8, 10] *= 1e-3  # large roots
+    roots, count = vo.real_roots_deg10(polys)
+    for k in range(64):
+        ref = np.roots(polys[k][::-1])
+        ref = np.sort(ref[np.abs(ref.imag) < 1e-7 * np.maximum(1, np.abs(ref.real))].real)
+        assert count[k] == len(ref)
+        np.testing.assert_allclose(roots[k, : count[k]], ref, rtol=1e-8, atol=1e-10)
+
+
+def test_five_point_solutions_satisfy_their_definition_and_contain_the_truth():
+    s, n1, n2 = _normalised_scene(200, seed=3)
+    idx = vo.sample_indices(0, np.arange(64), 200)
+    models, count = vo.five_point_models(n1[idx], n2[idx])
+    t = s["i2Ui1"]
+    e_true = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ s["i2Ri1"]
+    e_true /= np.linalg.norm(e_true)
+    assert count.min() >= 1 and count.max() <= 10
+    for h in range(64):
+        closest = np.inf
+        for r in range(count[h]):
+            e = models[h, r] / np.linalg.norm(models[h, r])
+            for k in idx[h]:  # epipolar constraint on the sample
+                assert abs(np.array([*n2[k], 1.0]) @ e @ np.array([*n1[k], 1.0])) < 1e-9
+            assert abs(np.linalg.det(e)) < 1e-6 and np.abs(2 * e @ e.T @ e - np.trace(e @ e.T) * e).max() < 1e-6
+            closest = min(closest, np.abs(e - e_true).max(), np.abs(e + e_true).max())
+        assert closest < 1e-4  # float32 pixel coordinates: projections rounded to ~3e-5 px, amplified by the minimal sample's conditioning
+        assert np.isnan(models[h, count[h] :]).all()
+
+
+def test_sampson_error_against_its_textbook_form():
+    rng = np.random.default_rng(1)
+    f = rng.normal(size=(3, 3))
+    x1, x2 = rng.normal(size=(20, 2)), rng.normal(size=(20, 2))
+    h1, h2 = np.c_[x1, np.ones(20)], np.c_[x2, np.ones(20)]
+    l2, l1 = h1 @ f.T, h2 @ f  # verification.py:213-220
+    ref = np.square(np.sum(h1 * l1, 1)) / (np.sum(np.square(l1[:, :2]), 1) + np.sum(np.square(l2[:, :2]), 1))
+    np.testing.assert_allclose(vo.sampson_sq(f, x1, x2), ref, rtol=1e-12)
+
+
+def test_decomposition_against_lapack_svd():
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        rot = synthetic._rotation_about(rng.normal(size=3), rng.uniform(0.05, 1.0))
+        t = rng.normal(size=3)
+        t /= np.linalg.norm(t)
+        e = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ rot * rng.uniform(0.1, 10)
+        r1, r2, tt = vo.decompose_essential(e)
+        u, sv, vt = np.linalg.svd(e)
+        assert abs(sv[0] - sv[1]) < 1e-9 * sv[0] and sv[2] < 1e-9 * sv[0]
+        for r in (r1, r2):
+            assert abs(np.linalg.det(r) - 1) < 1e-12 and np.abs(r @ r.T - np.eye(3)).max() < 1e-12
+        assert min(np.abs(r1 - rot).max(), np.abs(r2 - rot).max()) < 1e-9
+        assert min(np.abs(tt - t).max(), np.abs(tt + t).max()) < 1e-9
+
+
+@pytest.mark.parametrize("m,outliers,noise,thr", [(60, 0.0, 0.0, 0.5), (300, 0.4, 0.5, 2.0), (300, 0.65, 0.5, 4.0)])
+def test_ransac_recovers_planted_geometry(m, outliers, noise, thr):
+    s = synthetic.synthetic_two_view_matches(m, outliers, noise, seed=5, num_extra_keypoints=40)
+    res = vo.verify(s["coordinates_i1"], s["coordinates_i2"], s["match_indices"], s["intrinsics"], s["intrinsics"], thr, seed=9)
+    assert (res["mask"] & s["is_inlier"]).sum() >= 0.9 * s["is_inlier"].sum()
+    assert (res["mask"] & ~s["is_inlier"]).sum() <= 0.05 * m
+    assert _angle(res["R"], s["i2Ri1"]) < 2.0 and abs(np.linalg.det(res["R"]) - 1) < 1e-9
+    assert res["hypotheses"] in (256, 512, 768, 1024)
+    if outliers == 0.0:
+        assert res["hypotheses"] == 256 and res["mask"].all()  # (1 - 1)^256 <= 1e-6 after the first round
+    np.testing.assert_array_equal(res["v_corr_idxs"], s["match_indices"][res["mask"]])
+    assert res["inlier_ratio"] == res["mask"].mean()
+
+
+def test_reference_contract_suite_on_the_oracle():
+    """two-plane scene: pose within 2 degrees and every match verified (test_verifier_base.py:80-99); fewer than six
+    matches / empty input: the failure tuple (:117-135, opencv_verifier_base.py:71-80)."""
+    from tests.test_verifier_gpu import _two_planes_scene
+
+    uv1, uv2, rot, direction = _two_planes_scene(4, 4)
+    matches = np.stack([np.arange(8), np.arange(8)], 1)
+    res = vo.verify(uv1, uv2, matches, (1, 1, 0, 0), (1, 1, 0, 0), 0.5)
+    assert _angle(res["R"], rot) < 2 and np.degrees(np.arccos(np.clip(res["t"] @ direction, -1, 1))) < 2
+    np.testing.assert_array_equal(res["v_corr_idxs"], matches)
+    for bad in (np.zeros((0, 2), dtype=np.int32), np.array([], dtype=np.int32), matches[:5]):
+        fail = vo.verify(uv1, uv2, bad, (1, 1, 0, 0), (1, 1, 0, 0), 0.5)
+        assert fail["R"] is None and fail["t"] is None and fail["v_corr_idxs"].size == 0 and fail["inlier_ratio"] == 0.0
+
+
+def test_plugin_constructs_pickles_and_refuses_what_it_does_not_do():
+    from gtsfm_amd.common.calibration import PinholeIntrinsics, pinhole_parameters
+    from gtsfm_amd.frontend.verifier.ransac import Ransac
+
+    v = pickle.loads(pickle.dumps(Ransac(use_intrinsics_in_verification=True, estimation_threshold_px=4)))
+    assert repr(v) == "Ransac__use_intrinsicsTrue_4px"  # verifier_base.py:37-41: the cache / report key of the reference
+    with pytest.raises(ValueError):
+        Ransac(use_intrinsics_in_verification=False, estimation_threshold_px=4)
+    assert pinhole_parameters(PinholeIntrinsics(500.0, 320.0, 240.0)) == (500.0, 500.0, 320.0, 240.0, True)
+
+    class Distorted(PinholeIntrinsics):
+        def k1(self):
+            return 0.1
+
+    assert pinhole_parameters(Distorted(500.0, 320.0, 240.0))[4] is False
+    from gtsfm_amd.common.keypoints import Keypoints
+
+    few = v.verify(Keypoints(np.zeros((9, 2), np.float32)), Keypoints(np.zeros((9, 2), np.float32)), np.zeros((3, 2), np.int64), PinholeIntrinsics(), PinholeIntrinsics())
+    assert few[0] is None and few[1] is None and few[2].size == 0 and few[3] == 0.0  # no GPU needed for the early-outs
