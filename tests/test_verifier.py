@@ -47,11 +47,16 @@ def test_root_finder_against_companion_matrix_eigenvalues():
 
 
 def test_five_point_solutions_satisfy_their_definition_and_contain_the_truth():
-    s, n1, n2 = _normalised_scene(200, seed=3)
+    rng = np.random.default_rng(3)  # exact double-precision projections (the float32 pixel tables of the scenes round them)
+    pts = np.stack([rng.uniform(-4, 4, 200), rng.uniform(-3, 3, 200), rng.uniform(6, 14, 200)], 1)
+    rot = synthetic._rotation_about(rng.normal(size=3), 0.25)
+    t = rng.normal(size=3)
+    t /= np.linalg.norm(t)
+    p2 = pts @ rot.T + t
+    n1, n2 = pts[:, :2] / pts[:, 2:], p2[:, :2] / p2[:, 2:]
     idx = vo.sample_indices(0, np.arange(64), 200)
     models, count = vo.five_point_models(n1[idx], n2[idx])
-    t = s["i2Ui1"]
-    e_true = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ s["i2Ri1"]
+    e_true = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ rot
     e_true /= np.linalg.norm(e_true)
     assert count.min() >= 1 and count.max() <= 10
     for h in range(64):
@@ -60,9 +65,9 @@ def test_five_point_solutions_satisfy_their_definition_and_contain_the_truth():
             e = models[h, r] / np.linalg.norm(models[h, r])
             for k in idx[h]:  # epipolar constraint on the sample
                 assert abs(np.array([*n2[k], 1.0]) @ e @ np.array([*n1[k], 1.0])) < 1e-9
-            assert abs(np.linalg.det(e)) < 1e-6 and np.abs(2 * e @ e.T @ e - np.trace(e @ e.T) * e).max() < 1e-6
+            assert abs(np.linalg.det(e)) < 1e-5 and np.abs(2 * e @ e.T @ e - np.trace(e @ e.T) * e).max() < 1e-5  # ill-conditioned samples
             closest = min(closest, np.abs(e - e_true).max(), np.abs(e + e_true).max())
-        assert closest < 1e-4  # float32 pixel coordinates: projections rounded to ~3e-5 px, amplified by the minimal sample's conditioning
+        assert closest < 1e-6
         assert np.isnan(models[h, count[h] :]).all()
 
 
