@@ -294,10 +294,10 @@ __device__ __forceinline__ double vf_sampson_sq(const double* e, double a, doubl
 
 __global__ __launch_bounds__(256) void verify_gather_kernel(const float* __restrict__ kp_xy, const long long* __restrict__ kp_off1,
                                                             const long long* __restrict__ kp_off2, const int* __restrict__ match_idx,
-                                                            const long long* __restrict__ match_off, const double* __restrict__ intrinsics,
-                                                            double* __restrict__ pts) {
+                                                            const long long* __restrict__ match_off, const int* __restrict__ match_count,
+                                                            const double* __restrict__ intrinsics, double* __restrict__ pts) {
     const int pair = blockIdx.y;
-    const long long begin = match_off[pair], m = match_off[pair + 1] - begin;
+    const long long begin = match_off[pair], m = match_count ? (long long)match_count[pair] : match_off[pair + 1] - begin;
     const double* K = intrinsics + 8 * (size_t)pair;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
         const int* mi = match_idx + 2 * (begin + i);
@@ -417,17 +417,18 @@ __device__ __forceinline__ bool vf_in_front(const double* r, double t0, double t
 }
 
 __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __restrict__ pts, const long long* __restrict__ match_off,
-                                                            const double* __restrict__ intrinsics, const unsigned long long* __restrict__ seeds,
+                                                            const int* __restrict__ match_count, const double* __restrict__ intrinsics, const unsigned long long* __restrict__ seeds,
                                                             double threshold_px, double* __restrict__ out_e, double* __restrict__ out_r,
                                                             double* __restrict__ out_t, unsigned char* __restrict__ out_mask,
                                                             int* __restrict__ out_stats) {
     __shared__ VfShared sh;
     const int pair = blockIdx.x, tid = threadIdx.x;
     const long long begin = match_off[pair];
-    const int m = (int)(match_off[pair + 1] - begin);
+    const int m = match_count ? match_count[pair] : (int)(match_off[pair + 1] - begin);
     const double* P = pts + 4 * begin;
     unsigned char* mask = out_mask + begin;
     int* stats = out_stats + 8 * (size_t)pair;
+    for (long long i = m + tid; i < match_off[pair + 1] - begin; i += 256) mask[i] = 0;  // unused capacity behind the list
     if (m < 6) {  // NUM_MATCHES_REQ_E_MATRIX and the "< 6" guard of opencv_verifier_base.py:79
         for (int i = tid; i < m; i += 256) mask[i] = 0;
         if (tid < 8) stats[tid] = tid >= 2 && tid < 4 ? -1 : 0;
@@ -578,13 +579,59 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
     }
 }
 
+// Matcher output -> ragged match lists without a host round trip: pair p's matches0 block (n0 rows of `matches`, -1 =
+// unmatched) becomes the (row, matches0[row]) pairs in row order (the plugins' (K, 2) format, superglue_matcher.py:100-102)
+// at match_off[p], their number in match_count[p]. One workgroup per pair, ordered by a ballot prefix per 256 rows.
+__global__ __launch_bounds__(256) void verify_compact_matches_kernel(const int* __restrict__ matches, const long long* __restrict__ row_off,
+                                                                     const int* __restrict__ n0, const long long* __restrict__ match_off,
+                                                                     int* __restrict__ match_idx, int* __restrict__ match_count) {
+    __shared__ int wave_total[4];
+    __shared__ int running;
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int* src = matches + row_off[pair];
+    int* dst = match_idx + 2 * match_off[pair];
+    const int rows = n0[pair];
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (int base = 0; base < rows; base += 256) {
+        const int row = base + tid;
+        const int v = row < rows ? src[row] : -1;
+        const unsigned long long ballot = __ballot(v > -1);
+        const int before = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_total[wave] = __popcll(ballot);
+        __syncthreads();
+        int offset = running;
+        for (int w = 0; w < wave; ++w) offset += wave_total[w];
+        if (v > -1) {
+            dst[2 * (offset + before)] = row;
+            dst[2 * (offset + before) + 1] = v;
+        }
+        __syncthreads();
+        if (tid == 0) running += wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+        __syncthreads();
+    }
+    if (tid == 0) match_count[pair] = running;
+}
+
+extern "C" int gtsfm_verify_compact_matches(const int32_t* matches_dev, const long long* row_off_dev, const int32_t* n0_dev,
+                                            const long long* match_off_dev, int num_pairs, int32_t* match_idx_dev,
+                                            int32_t* match_count_dev, void* stream) {
+    GTSFM_CHECK_ARG(num_pairs >= 0, "verify_compact_matches: negative pair count");
+    if (num_pairs == 0) return GTSFM_OK;
+    GTSFM_CHECK_ARG(matches_dev && row_off_dev && n0_dev && match_off_dev && match_idx_dev && match_count_dev, "verify_compact_matches: null pointer");
+    hipLaunchKernelGGL(verify_compact_matches_kernel, dim3(num_pairs), dim3(256), 0, (hipStream_t)stream, matches_dev, row_off_dev, n0_dev,
+                       match_off_dev, match_idx_dev, match_count_dev);
+    GTSFM_CHECK_LAUNCH("verify_compact_matches_kernel");
+    return GTSFM_OK;
+}
+
 extern "C" size_t gtsfm_verify_workspace_bytes(long long total_matches) {
     return align_up((size_t)(total_matches > 0 ? total_matches : 0) * 4 * sizeof(double), 256) + 256;
 }
 
 extern "C" int gtsfm_verify_essential_f64(const float* kp_xy_dev, const long long* kp_off1_dev, const long long* kp_off2_dev,
-                                          const int32_t* match_idx_dev, const long long* match_off_dev, long long total_matches,
-                                          const double* intrinsics_dev, const unsigned long long* seeds_dev, double threshold_px,
+                                          const int32_t* match_idx_dev, const long long* match_off_dev, const int32_t* match_count_dev,
+                                          long long total_matches, const double* intrinsics_dev, const unsigned long long* seeds_dev, double threshold_px,
                                           int num_pairs, void* workspace_dev, size_t workspace_bytes, double* essential_dev,
                                           double* rotation_dev, double* translation_dev, uint8_t* inlier_mask_dev, int32_t* stats_dev,
                                           void* stream) {
@@ -601,10 +648,10 @@ extern "C" int gtsfm_verify_essential_f64(const float* kp_xy_dev, const long lon
     double* pts = (double*)align_up((size_t)workspace_dev, 256);
     if (total_matches > 0) {
         hipLaunchKernelGGL(verify_gather_kernel, dim3(4, num_pairs), dim3(256), 0, (hipStream_t)stream, kp_xy_dev, kp_off1_dev, kp_off2_dev,
-                           match_idx_dev, match_off_dev, intrinsics_dev, pts);
+                           match_idx_dev, match_off_dev, match_count_dev, intrinsics_dev, pts);
         GTSFM_CHECK_LAUNCH("verify_gather_kernel");
     }
-    hipLaunchKernelGGL(verify_ransac_kernel, dim3(num_pairs), dim3(256), 0, (hipStream_t)stream, pts, match_off_dev, intrinsics_dev, seeds_dev,
+    hipLaunchKernelGGL(verify_ransac_kernel, dim3(num_pairs), dim3(256), 0, (hipStream_t)stream, pts, match_off_dev, match_count_dev, intrinsics_dev, seeds_dev,
                        threshold_px, essential_dev, rotation_dev, translation_dev, inlier_mask_dev, stats_dev);
     GTSFM_CHECK_LAUNCH("verify_ransac_kernel");
     return GTSFM_OK;

@@ -95,9 +95,10 @@ SIGNATURES = {
     "gtsfm_verify_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "gtsfm_verify_essential_f64": (
         C.c_int,
-        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
          C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "gtsfm_verify_compact_matches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gtsfm_lg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p]),
     "gtsfm_lg_forward": (
         C.c_int,

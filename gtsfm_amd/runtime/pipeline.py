@@ -166,6 +166,49 @@ class FrontEndPipeline:
         out["pairs"], out["n0"], out["n1"] = chunk, n0, n1
         return out
 
+    def verify(self, feats: Dict[str, torch.Tensor], results: List[Dict[str, torch.Tensor]], intrinsics: np.ndarray, threshold_px: float,
+               engine=None) -> List[Dict[str, torch.Tensor]]:
+        """The verifier stage on the matcher's device output (``two_view_estimator.py:391-397`` per pair in the reference):
+        per chunk of ``match()`` one compaction launch and one RANSAC launch, nothing copied to the host. ``intrinsics``
+        [num_images, 4] = (fx, fy, cx, cy) per row of the feature table. Pair (i, j) draws its minimal samples from the seed
+        ``i << 32 | j``, so a pair's result does not depend on how the pair list was chunked or sharded. Returns per chunk
+        E / R / t / mask / stats plus match_idx, match_off (host), match_count and the chunk's pair list."""
+        if engine is None:
+            if getattr(self, "_verifier", None) is None:
+                from gtsfm_amd.runtime.verifier_engine import VerifierEngine
+
+                self._verifier = VerifierEngine(feats["xy"].device)
+            engine = self._verifier
+        k = feats["xy"].shape[1]
+        table = feats["xy"].reshape(-1, 2)
+        intrinsics = np.asarray(intrinsics, dtype=np.float64)
+        out = []
+        for res in results:
+            pairs, n0, n1 = res["pairs"], res["n0"], res["n1"]
+            rows = np.concatenate([[0], np.cumsum([a + b for a, b in zip(n0, n1)])])[:-1]
+            idx, match_off, count = engine.compact_matches(res["matches"], rows.tolist(), n0)
+            intr = np.concatenate([intrinsics[[i for i, _ in pairs]], intrinsics[[j for _, j in pairs]]], axis=1)
+            ver = engine.verify_batch(table, [i * k for i, _ in pairs], [j * k for _, j in pairs], idx, match_off, intr, threshold_px,
+                                      seeds=[(i << 32) | j for i, j in pairs], match_count=count)
+            ver.update(match_idx=idx, match_off=match_off, match_count=count, pairs=pairs)
+            out.append(ver)
+        return out
+
+    @staticmethod
+    def verified_to_numpy(verified: List[Dict[str, torch.Tensor]]) -> Dict[Tuple[int, int], Dict[str, np.ndarray]]:
+        """Per pair the verifier plugins' return values: R, t (None without a model), v_corr_idxs (N,2), inlier_ratio."""
+        out: Dict[Tuple[int, int], Dict[str, np.ndarray]] = {}
+        for ver in verified:
+            idx, mask, count = ver["match_idx"].cpu().numpy(), ver["mask"].cpu().numpy().astype(bool), ver["match_count"].cpu().numpy()
+            rot, trans, stats = ver["R"].cpu().numpy(), ver["t"].cpu().numpy(), ver["stats"].cpu().numpy()
+            for p, pair in enumerate(ver["pairs"]):
+                lo = ver["match_off"][p]
+                m, keep = idx[lo : lo + count[p]], mask[lo : lo + count[p]]
+                ok = stats[p, 0] > 0
+                out[pair] = {"R": rot[p] if ok else None, "t": trans[p] if ok else None, "v_corr_idxs": m[keep].astype(np.int64),
+                             "inlier_ratio": float(keep.mean()) if ok else 0.0, "putative": m.astype(np.int64), "hypotheses": int(stats[p, 1])}
+        return out
+
     @staticmethod
     def matches_to_numpy(results: List[Dict[str, torch.Tensor]], dtype=np.int64) -> Dict[Tuple[int, int], np.ndarray]:
         """(K,2) index arrays per pair, image-i1 keypoint order (the plugins' output format)."""

@@ -46,15 +46,18 @@ class VerifierEngine:
         intrinsics: np.ndarray,
         threshold_px: float,
         seeds: Optional[Sequence[int]] = None,
+        match_count: Optional[torch.Tensor] = None,
     ) -> Dict[str, torch.Tensor]:
         """kp_xy [*,2] float32 pixel coordinates (device); pair p reads image i1's rows from kp_off1[p] and image i2's from
         kp_off2[p]; match_idx [M,2] int32 (device) rows relative to those offsets, pair p owning match_off[p]:match_off[p+1];
-        intrinsics [P,8] = (fx, fy, cx, cy) of i1 then i2. Returns device tensors: E [P,3,3], R [P,3,3], t [P,3] (NaN when a
+        intrinsics [P,8] = (fx, fy, cx, cy) of i1 then i2; match_count [P] int32 (device, optional): only the first
+        match_count[p] rows of pair p's slice are matches (capacity layout of ``compact_matches``). Returns device tensors: E [P,3,3], R [P,3,3], t [P,3] (NaN when a
         pair has no model), mask [M] uint8, stats [P,8] int32 (``STATS_FIELDS``). Enqueued on the current stream."""
         num_pairs = len(kp_off1)
         assert len(kp_off2) == num_pairs and len(match_off) == num_pairs + 1
         assert kp_xy.is_cuda and kp_xy.dtype == torch.float32 and kp_xy.is_contiguous()
         total = int(match_off[-1])
+        assert match_count is None or (match_count.dtype == torch.int32 and match_count.is_cuda and match_count.numel() == num_pairs)
         assert match_idx.dtype == torch.int32 and match_idx.is_contiguous() and match_idx.numel() == 2 * total
         dev = self.device
         off1, off2 = self._dev(kp_off1, torch.int64), self._dev(kp_off2, torch.int64)
@@ -74,7 +77,8 @@ class VerifierEngine:
         ws = self._workspace(total)
         _lib.check(
             self._lib.gtsfm_verify_essential_f64(
-                kp_xy.data_ptr(), off1.data_ptr(), off2.data_ptr(), match_idx.data_ptr() if total else None, moff.data_ptr(), total,
+                kp_xy.data_ptr(), off1.data_ptr(), off2.data_ptr(), match_idx.data_ptr() if total else None, moff.data_ptr(),
+                match_count.data_ptr() if match_count is not None else None, total,
                 intr.data_ptr(), seeds_dev.data_ptr(), float(threshold_px), num_pairs, ws.data_ptr(), ws.numel(), out["E"].data_ptr(),
                 out["R"].data_ptr(), out["t"].data_ptr(), out["mask"].data_ptr() if total else None, out["stats"].data_ptr(),
                 torch.cuda.current_stream(dev).cuda_stream,
@@ -82,3 +86,22 @@ class VerifierEngine:
             "gtsfm_verify_essential_f64",
         )
         return out
+
+    def compact_matches(self, matches: torch.Tensor, row_off: Sequence[int], n0: Sequence[int]):
+        """Matcher output [T] int32 (per pair: matches0 then matches1) -> (match_idx [sum(n0),2] int32, match_off host list
+        [P+1] = capacity prefix of n0, match_count [P] int32 device): the (K, 2) arrays of the plugins, left on the device."""
+        num_pairs = len(n0)
+        assert matches.dtype == torch.int32 and matches.is_cuda and matches.is_contiguous() and len(row_off) == num_pairs
+        match_off = np.concatenate([[0], np.cumsum(np.asarray(n0, dtype=np.int64))]).astype(np.int64)
+        idx = torch.empty((int(match_off[-1]), 2), dtype=torch.int32, device=self.device)
+        count = torch.zeros(num_pairs, dtype=torch.int32, device=self.device)
+        if num_pairs:
+            rows_dev, n0_dev, off_dev = self._dev(row_off, torch.int64), self._dev(n0, torch.int32), self._dev(match_off, torch.int64)  # keep alive
+            _lib.check(
+                self._lib.gtsfm_verify_compact_matches(
+                    matches.data_ptr(), rows_dev.data_ptr(), n0_dev.data_ptr(), off_dev.data_ptr(), num_pairs, idx.data_ptr(), count.data_ptr(),
+                    torch.cuda.current_stream(self.device).cuda_stream,
+                ),
+                "gtsfm_verify_compact_matches",
+            )
+        return idx, match_off.tolist(), count

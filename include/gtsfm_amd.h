@@ -229,7 +229,8 @@ int gtsfm_lg_forward(const float* blob_dev, int num_layers, const float* match_b
  * 256 hypotheses per round, at most 4 rounds, stop when (1 - w^5)^n <= 1e-6; see oracle/verifier_oracle.py.
  * kp_xy_dev [*][2] float32 pixel coordinates of all keypoint tables; pair p uses the tables starting at rows kp_off1_dev[p]
  * (image i1) and kp_off2_dev[p] (image i2). match_idx_dev [total_matches][2] int32 (row in i1's table, row in i2's table),
- * pair p owning rows match_off_dev[p] .. match_off_dev[p+1]. intrinsics_dev [num_pairs][8] = fx, fy, cx, cy of i1 then i2
+ * pair p owning rows match_off_dev[p] .. match_off_dev[p+1], or only the first match_count_dev[p] of them when match_count_dev
+ * is given (capacity layout, filled by gtsfm_verify_compact_matches; total_matches = match_off_dev[num_pairs]). intrinsics_dev [num_pairs][8] = fx, fy, cx, cy of i1 then i2
  * (pinhole; lens distortion is the caller's to remove). threshold_px is divided by max(fx1, fx2) as the reference does.
  * Outputs per pair: essential_dev [9] i2Ei1 (unnormalised), rotation_dev [9] i2Ri1 row-major, translation_dev [3] unit i2Ui1,
  * inlier_mask_dev [total_matches] (1 = verified), stats_dev [8] int32 = inliers, hypotheses drawn, winning hypothesis,
@@ -237,11 +238,20 @@ int gtsfm_lg_forward(const float* blob_dev, int num_layers, const float* match_b
  * NaN matrices (the reference's failure tuple is built by the caller). */
 size_t gtsfm_verify_workspace_bytes(long long total_matches);
 int gtsfm_verify_essential_f64(const float* kp_xy_dev, const long long* kp_off1_dev, const long long* kp_off2_dev,
-                               const int32_t* match_idx_dev, const long long* match_off_dev, long long total_matches,
-                               const double* intrinsics_dev, const unsigned long long* seeds_dev, double threshold_px,
+                               const int32_t* match_idx_dev, const long long* match_off_dev, const int32_t* match_count_dev,
+                               long long total_matches, const double* intrinsics_dev, const unsigned long long* seeds_dev, double threshold_px,
                                int num_pairs, void* workspace_dev, size_t workspace_bytes, double* essential_dev,
                                double* rotation_dev, double* translation_dev, uint8_t* inlier_mask_dev, int32_t* stats_dev,
                                void* stream);
+
+/* Matcher output -> the verifier's match lists on the device.   replaces the host marshalling of
+ * gtsfm/frontend/matcher/superglue_matcher.py:100-102 / lightglue_matcher.py:104-110 ((K, 2) arrays per pair) between the
+ * matcher and the verifier. matches_dev: gtsfm_sg_forward / gtsfm_lg_forward output; pair p's matches0 block starts at row
+ * row_off_dev[p] and has n0_dev[p] rows. Writes the (row, matches0[row]) pairs with matches0[row] > -1, in row order, at
+ * match_idx_dev + 2 * match_off_dev[p] (capacity n0_dev[p]) and their number to match_count_dev[p]. */
+int gtsfm_verify_compact_matches(const int32_t* matches_dev, const long long* row_off_dev, const int32_t* n0_dev,
+                                 const long long* match_off_dev, int num_pairs, int32_t* match_idx_dev, int32_t* match_count_dev,
+                                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -156,3 +156,60 @@ def test_plugin_contract_of_the_reference_verifier_suite(gpu_device):
         if verified.size:
             assert (verified[:, 0] < n1).all() and (verified[:, 1] < n2).all()
             assert set(map(tuple, verified.tolist())) <= set(map(tuple, idx.tolist()))
+
+
+def test_compaction_equals_the_plugins_match_arrays(gpu_device):
+    from gtsfm_amd.runtime.verifier_engine import VerifierEngine
+
+    rng = np.random.default_rng(4)
+    n0, n1 = [700, 0, 300, 1, 2048], [650, 10, 0, 1, 2048]
+    blocks, rows, row = [], [], 0
+    for a, b in zip(n0, n1):
+        m0 = np.where(rng.random(a) < 0.4, rng.integers(0, max(b, 1), a), -1).astype(np.int32)
+        blocks += [m0, rng.integers(-1, max(a, 1), b).astype(np.int32)]
+        rows.append(row)
+        row += a + b
+    matches = torch.from_numpy(np.concatenate(blocks)).to(gpu_device)
+    idx, off, count = VerifierEngine(gpu_device).compact_matches(matches, rows, n0)
+    idx, count = idx.cpu().numpy(), count.cpu().numpy()
+    for p, a in enumerate(n0):
+        m0 = blocks[2 * p]
+        valid = m0 > -1
+        expect = np.stack([np.flatnonzero(valid), m0[valid]], -1)  # superglue_matcher.py:100-102
+        assert count[p] == valid.sum() and off[p + 1] - off[p] == a
+        np.testing.assert_array_equal(idx[off[p] : off[p] + count[p]], expect)
+
+
+def test_pipeline_detect_match_verify_stays_on_the_device_and_equals_the_oracle(gpu_device):
+    """detect -> match -> verify through the resident pipeline on the benchmark's overlapping views; every pair's verified
+    set, pose and hypothesis count against the oracle run on the (K, 2) match arrays of the same pipeline."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+    from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+
+    views = synthetic.synthetic_overlapping_views(4, 512, 512)
+    det = SuperPointEngine(synthetic.synthetic_superpoint_state_dict(), gpu_device)
+    eng = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(num_layers=3), gpu_device)
+    pipe = FrontEndPipeline(det, eng, max_keypoints=1024, pair_chunk=2, num_streams=2)
+    feats = pipe.detect(torch.from_numpy(views).to(gpu_device))
+    pairs = [(0, 1), (0, 2), (1, 3), (2, 3), (0, 3)]
+    res = pipe.match(feats, pairs, [(512, 512)] * 4)
+    intr = np.array([[600.0 + 10 * i, 600.0 + 10 * i, 256.0, 256.0] for i in range(4)])
+    ver = pipe.verify(feats, res, intr, threshold_px=1.0)
+    got = pipe.verified_to_numpy(ver)
+    putative = pipe.matches_to_numpy(res)
+    xy, cnt = feats["xy"].cpu().numpy(), feats["count"].cpu().numpy()
+    some = 0
+    for i, j in pairs:
+        np.testing.assert_array_equal(got[(i, j)]["putative"], putative[(i, j)])
+        ref = vo.verify(xy[i, : cnt[i]], xy[j, : cnt[j]], putative[(i, j)], tuple(intr[i]), tuple(intr[j]), 1.0, seed=(i << 32) | j)
+        np.testing.assert_array_equal(got[(i, j)]["v_corr_idxs"], ref["v_corr_idxs"])
+        assert got[(i, j)]["hypotheses"] == ref["hypotheses"]
+        if ref["R"] is None:
+            assert got[(i, j)]["R"] is None and got[(i, j)]["inlier_ratio"] == 0.0
+        else:
+            some += 1
+            np.testing.assert_allclose(got[(i, j)]["R"], ref["R"], atol=1e-9)
+            np.testing.assert_allclose(got[(i, j)]["t"], ref["t"], atol=1e-9)
+            assert got[(i, j)]["inlier_ratio"] == ref["inlier_ratio"]
+    assert some >= 3
