@@ -605,6 +605,7 @@ def main() -> None:
                 result["roofline_other"] = [r for r in other if r is not None] + [conv_roof]
             if world == 1 and not args.no_secondary and not detect_only and not scene and args.pair_definition == "exhaustive":
                 result["secondary"] = secondary_rates(args, detector, matcher, device, h, w, mk)
+                result["secondary"]["verifier_stage"] = verifier_rate(pipe, feats, res, h, w, ms_per_step, device, not args.no_cpu_baseline)
             if world == 1 and not args.no_cpu_baseline:  # rank 0 at N = 1 only
                 first = all_pairs[0] if all_pairs else (0, min(1, len(views_np) - 1))
                 view_of = (lambda s: (5 * s) % args.images) if independent else (lambda s: s)  # noqa: E731
@@ -621,6 +622,71 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _verifier_kernel_ms(pipe, ver, feats, intr, thr, device):
+    """HIP-event time of one gtsfm_verify_essential_f64 call on the step's compacted match lists (gather + RANSAC kernels)."""
+    v = ver[0]
+    k = feats["xy"].shape[1]
+    pairs = v["pairs"]
+    intr8 = np.concatenate([intr[[i for i, _ in pairs]], intr[[j for _, j in pairs]]], axis=1)
+    args = (feats["xy"].reshape(-1, 2), [i * k for i, _ in pairs], [j * k for _, j in pairs], v["match_idx"], v["match_off"], intr8, thr)
+    kw = dict(seeds=[(i << 32) | j for i, j in pairs], match_count=v["match_count"])
+    # verify_batch uploads its small index arrays first; the events bracket uploads + both kernels on the current stream
+    pipe._verifier.verify_batch(*args, **kw)
+    torch.cuda.synchronize(device)
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(3):
+        pipe._verifier.verify_batch(*args, **kw)
+    end.record()
+    torch.cuda.synchronize(device)
+    return round(start.elapsed_time(end) / 3, 3)
+
+
+def verifier_rate(pipe, feats, res, h, w, ms_per_step, device, with_oracle: bool):
+    """The stage behind the path: five-point RANSAC + pose recovery over the match lists the
+    timed step just produced, device to device. Its own timed region; the headline value does not include it. With the
+    oracle leg: the first pair re-verified by oracle/verifier_oracle.py on the host (checker and CPU figure)."""
+    intr = np.tile(np.array([[1.2 * max(h, w), 1.2 * max(h, w), w / 2.0, h / 2.0]]), (int(feats["xy"].shape[0]), 1))
+    thr = 4.0  # estimation_threshold_px of gtsfm/configs/deep_front_end.yaml:49
+    ver = pipe.verify(feats, res, intr, thr)
+    torch.cuda.synchronize(device)
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ver = pipe.verify(feats, res, intr, thr)
+    torch.cuda.synchronize(device)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    kernel_ms = _verifier_kernel_ms(pipe, ver, feats, intr, thr, device)
+    npairs = sum(len(v["pairs"]) for v in ver)
+    stats = torch.cat([v["stats"] for v in ver]).cpu().numpy()
+    counts = torch.cat([v["match_count"] for v in ver]).cpu().numpy()
+    out = {
+        "value": round(npairs / (ms * 1e-3), 1), "unit": "image-pairs/s", "ms_per_step": round(ms, 3), "steps": steps, "pairs_per_step": npairs,
+        "share_of_detect_match_step": round(ms / ms_per_step, 4), "dtype": "f64", "threshold_px": thr,
+        "ransac_kernel_ms": kernel_ms,
+        "putative_per_pair": round(float(counts.mean()), 1), "verified_per_pair": round(float(stats[:, 0].mean()), 1),
+        "hypotheses_per_pair": round(float(stats[:, 1].mean()), 1), "pairs_with_model": int((stats[:, 0] > 0).sum()),
+        "workload": "gtsfm_verify_compact_matches + gtsfm_verify_essential_f64 on the match lists of the timed step (5-point MSAC RANSAC, "
+                    "<= 1024 hypotheses per pair + 256 drawn from the winner's inliers, cheirality pose choice); PARITY UNPINNED towards OpenCV's USAC",
+    }
+    if with_oracle:
+        from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+        from oracle import verifier_oracle as vo
+
+        got = FrontEndPipeline.verified_to_numpy(ver[:1])
+        (i, j) = ver[0]["pairs"][0]
+        xy, cnt = feats["xy"].cpu().numpy(), feats["count"].cpu().numpy()
+        t0 = time.perf_counter()
+        ref = vo.verify(xy[i, : cnt[i]], xy[j, : cnt[j]], got[(i, j)]["putative"], tuple(intr[i]), tuple(intr[j]), thr, seed=(i << 32) | j)
+        sec = time.perf_counter() - t0
+        same = bool(np.array_equal(ref["v_corr_idxs"], got[(i, j)]["v_corr_idxs"]) and ref["hypotheses"] == got[(i, j)]["hypotheses"])
+        if ref["R"] is not None and got[(i, j)]["R"] is not None:
+            same = same and bool(np.abs(ref["R"] - got[(i, j)]["R"]).max() < 1e-9 and np.abs(ref["t"] - got[(i, j)]["t"]).max() < 1e-9)
+        out["parity_check"] = {"verified_equal_oracle": same, "pair": [int(i), int(j)], "verified": int(len(ref["v_corr_idxs"]))}
+        out["cpu_baseline"] = {"value": round(1.0 / sec, 2), "unit": "image-pairs/s", "cores": 1, "kind": "port", "sample": "the first pair, numpy float64 oracle"}
+    return out
 
 
 def secondary_rates(args, detector, matcher, device, h, w, mk):

@@ -10,7 +10,8 @@
 // honours NaNs: a degenerate sample turns into NaN models that count zero inliers), so inlier masks are compared bit for bit.
 //
 // Mapping: one workgroup of 256 threads per pair; a round = 256 hypotheses, one per thread (sample, solve, score the <= 10
-// real solutions against all matches of the pair, MSAC cost); rounds stop by the (1 - w^5)^n <= 1 - p rule, at most 4. The solver's
+// real solutions against all matches of the pair, MSAC cost); rounds stop by the (1 - w^5)^n <= 1 - p rule, at most 4, and one
+// more round samples from the inliers of the winner (local optimisation). The solver's
 // 10x20 elimination matrix lives in per-thread scratch: the stage is latency-bound double-precision scalar work, a few
 // hundred microseconds per round, against ~2 ms of matcher time per pair -- no MFMA, no LDS tiling worth having.
 
@@ -420,13 +421,14 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
                                                             const int* __restrict__ match_count, const double* __restrict__ intrinsics, const unsigned long long* __restrict__ seeds,
                                                             double threshold_px, double* __restrict__ out_e, double* __restrict__ out_r,
                                                             double* __restrict__ out_t, unsigned char* __restrict__ out_mask,
-                                                            int* __restrict__ out_stats) {
+                                                            int* __restrict__ out_stats, int* __restrict__ inlier_lists) {
     __shared__ VfShared sh;
     const int pair = blockIdx.x, tid = threadIdx.x;
     const long long begin = match_off[pair];
     const int m = match_count ? match_count[pair] : (int)(match_off[pair + 1] - begin);
     const double* P = pts + 4 * begin;
     unsigned char* mask = out_mask + begin;
+    int* inl_list = inlier_lists + begin;
     int* stats = out_stats + 8 * (size_t)pair;
     for (long long i = m + tid; i < match_off[pair + 1] - begin; i += 256) mask[i] = 0;  // unused capacity behind the list
     if (m < 6) {  // NUM_MATCHES_REQ_E_MATRIX and the "< 6" guard of opencv_verifier_base.py:79
@@ -443,10 +445,13 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
     __syncthreads();
 
     int rounds = 0;
-    for (int rnd = 0; rnd < VF_MAX_ROUNDS; ++rnd) {
-        const int hyp = rnd * VF_ROUND + tid;
+    bool lo_round = false;  // the last round draws its minimal samples from the inliers of the best model so far
+    for (;;) {
+        const int hyp = (lo_round ? VF_MAX_ROUNDS : rounds) * VF_ROUND + tid;
         int idx[5];
-        vf_sample(seed, (unsigned long long)hyp, m, idx);
+        vf_sample(seed, (unsigned long long)hyp, lo_round ? sh.inliers : m, idx);
+        if (lo_round)
+            for (int k = 0; k < 5; ++k) idx[k] = inl_list[idx[k]];
         double basis[4][9];
         double my_e[9];
         double my_cost = INFINITY;
@@ -509,7 +514,8 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
             sh.best_index = win_index;
         }
         __syncthreads();
-        rounds = rnd + 1;
+        if (lo_round) break;
+        ++rounds;
         if (tid == 0 && sh.best_count > 0) {  // (1 - w^5)^(256 rounds) <= 1 - p, exact multiplication chain (oracle: _stop_after)
             const double w = (double)sh.best_count / (double)m;
             const double q = 1.0 - w * w * w * w * w;
@@ -520,18 +526,42 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
             sh.stop = acc <= 1.0 - VF_SUCCESS_PROB ? 1 : 0;
         }
         __syncthreads();
-        if (sh.stop) break;
+        if (!sh.stop && rounds < VF_MAX_ROUNDS) continue;
+        // local optimisation (LO-RANSAC's inner sampling, minimal samples): list the inliers of the best model in match order
+        if (sh.best_index < 0) break;
+        double e[9];
+        for (int k = 0; k < 9; ++k) e[k] = sh.best_e[k];
+        if (tid == 0) sh.inliers = 0;
+        __syncthreads();
+        for (int base = 0; base < m; base += 256) {
+            const int i = base + tid;
+            const bool in = i < m && vf_sampson_sq(e, P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]) < thr2;
+            const unsigned long long ballot = __ballot(in);
+            if ((tid & 63) == 0) sh.index[tid >> 6] = __popcll(ballot);
+            __syncthreads();
+            int offset = sh.inliers;
+            for (int w = 0; w < (tid >> 6); ++w) offset += sh.index[w];
+            if (in) inl_list[offset + __popcll(ballot & ((1ull << (tid & 63)) - 1ull))] = i;
+            __threadfence_block();
+            __syncthreads();
+            if (tid == 0) sh.inliers += sh.index[0] + sh.index[1] + sh.index[2] + sh.index[3];
+            __syncthreads();
+        }
+        if (sh.inliers < 6) break;
+        lo_round = true;
     }
+    const int hypotheses = (rounds + (lo_round ? 1 : 0)) * VF_ROUND;
 
     if (sh.best_index < 0) {  // no sample produced a model
         for (int i = tid; i < m; i += 256) mask[i] = 0;
-        if (tid < 8) stats[tid] = tid == 1 ? rounds * VF_ROUND : (tid >= 2 && tid < 4 ? -1 : 0);
+        if (tid < 8) stats[tid] = tid == 1 ? hypotheses : (tid >= 2 && tid < 4 ? -1 : 0);
         if (tid < 9) out_e[9 * (size_t)pair + tid] = out_r[9 * (size_t)pair + tid] = NAN;
         if (tid < 3) out_t[3 * (size_t)pair + tid] = NAN;
         return;
     }
     double e[9];
     for (int k = 0; k < 9; ++k) e[k] = sh.best_e[k];
+    __syncthreads();
     if (tid == 0) {
         sh.inliers = 0;
         for (int k = 0; k < 4; ++k) sh.good[k] = 0;
@@ -574,7 +604,7 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
             out_r[9 * (size_t)pair + k] = sh.pose[pick & 1][k];
         }
         for (int k = 0; k < 3; ++k) out_t[3 * (size_t)pair + k] = sign < 0 ? -sh.t[k] : sh.t[k];
-        stats[0] = sh.inliers, stats[1] = rounds * VF_ROUND, stats[2] = sh.best_index >> 4, stats[3] = sh.best_index & 15;
+        stats[0] = sh.inliers, stats[1] = hypotheses, stats[2] = sh.best_index >> 4, stats[3] = sh.best_index & 15;
         for (int k = 0; k < 4; ++k) stats[4 + k] = sh.good[k];
     }
 }
@@ -626,7 +656,8 @@ extern "C" int gtsfm_verify_compact_matches(const int32_t* matches_dev, const lo
 }
 
 extern "C" size_t gtsfm_verify_workspace_bytes(long long total_matches) {
-    return align_up((size_t)(total_matches > 0 ? total_matches : 0) * 4 * sizeof(double), 256) + 256;
+    const size_t n = (size_t)(total_matches > 0 ? total_matches : 0);
+    return align_up(n * 4 * sizeof(double), 256) + align_up(n * sizeof(int), 256) + 256;  // normalised points, inlier lists
 }
 
 extern "C" int gtsfm_verify_essential_f64(const float* kp_xy_dev, const long long* kp_off1_dev, const long long* kp_off2_dev,
@@ -646,13 +677,14 @@ extern "C" int gtsfm_verify_essential_f64(const float* kp_xy_dev, const long lon
         return GTSFM_ERR_WORKSPACE;
     }
     double* pts = (double*)align_up((size_t)workspace_dev, 256);
+    int* inlier_lists = (int*)((char*)pts + align_up((size_t)total_matches * 4 * sizeof(double), 256));
     if (total_matches > 0) {
         hipLaunchKernelGGL(verify_gather_kernel, dim3(4, num_pairs), dim3(256), 0, (hipStream_t)stream, kp_xy_dev, kp_off1_dev, kp_off2_dev,
                            match_idx_dev, match_off_dev, match_count_dev, intrinsics_dev, pts);
         GTSFM_CHECK_LAUNCH("verify_gather_kernel");
     }
     hipLaunchKernelGGL(verify_ransac_kernel, dim3(num_pairs), dim3(256), 0, (hipStream_t)stream, pts, match_off_dev, match_count_dev, intrinsics_dev, seeds_dev,
-                       threshold_px, essential_dev, rotation_dev, translation_dev, inlier_mask_dev, stats_dev);
+                       threshold_px, essential_dev, rotation_dev, translation_dev, inlier_mask_dev, stats_dev, inlier_lists);
     GTSFM_CHECK_LAUNCH("verify_ransac_kernel");
     return GTSFM_OK;
 }

@@ -169,10 +169,10 @@ class FrontEndPipeline:
     def verify(self, feats: Dict[str, torch.Tensor], results: List[Dict[str, torch.Tensor]], intrinsics: np.ndarray, threshold_px: float,
                engine=None) -> List[Dict[str, torch.Tensor]]:
         """The verifier stage on the matcher's device output (``two_view_estimator.py:391-397`` per pair in the reference):
-        per chunk of ``match()`` one compaction launch and one RANSAC launch, nothing copied to the host. ``intrinsics``
+        all chunks of ``match()`` together in one compaction launch and one RANSAC launch, nothing copied to the host. ``intrinsics``
         [num_images, 4] = (fx, fy, cx, cy) per row of the feature table. Pair (i, j) draws its minimal samples from the seed
-        ``i << 32 | j``, so a pair's result does not depend on how the pair list was chunked or sharded. Returns per chunk
-        E / R / t / mask / stats plus match_idx, match_off (host), match_count and the chunk's pair list."""
+        ``i << 32 | j``, so a pair's result does not depend on how the pair list was chunked or sharded. Returns a list (one
+        entry per 65535 pairs) of E / R / t / mask / stats plus match_idx, match_off (host), match_count and the pair list."""
         if engine is None:
             if getattr(self, "_verifier", None) is None:
                 from gtsfm_amd.runtime.verifier_engine import VerifierEngine
@@ -183,15 +183,24 @@ class FrontEndPipeline:
         table = feats["xy"].reshape(-1, 2)
         intrinsics = np.asarray(intrinsics, dtype=np.float64)
         out = []
-        for res in results:
-            pairs, n0, n1 = res["pairs"], res["n0"], res["n1"]
-            rows = np.concatenate([[0], np.cumsum([a + b for a, b in zip(n0, n1)])])[:-1]
-            idx, match_off, count = engine.compact_matches(res["matches"], rows.tolist(), n0)
-            intr = np.concatenate([intrinsics[[i for i, _ in pairs]], intrinsics[[j for _, j in pairs]]], axis=1)
-            ver = engine.verify_batch(table, [i * k for i, _ in pairs], [j * k for _, j in pairs], idx, match_off, intr, threshold_px,
-                                      seeds=[(i << 32) | j for i, j in pairs], match_count=count)
-            ver.update(match_idx=idx, match_off=match_off, match_count=count, pairs=pairs)
-            out.append(ver)
+        group: List[Dict[str, torch.Tensor]] = []
+        for res in list(results) + [None]:  # all chunks of the step in one launch pair (the ABI takes up to 65535 pairs per call)
+            if res is not None and sum(len(r["pairs"]) for r in group) + len(res["pairs"]) <= 65535:
+                group.append(res)
+                continue
+            if group:
+                pairs = [p for r in group for p in r["pairs"]]
+                n0 = [a for r in group for a in r["n0"]]
+                n1 = [b for r in group for b in r["n1"]]
+                matches = group[0]["matches"] if len(group) == 1 else torch.cat([r["matches"] for r in group])
+                rows = np.concatenate([[0], np.cumsum([a + b for a, b in zip(n0, n1)])])[:-1]
+                idx, match_off, count = engine.compact_matches(matches, rows.tolist(), n0)
+                intr = np.concatenate([intrinsics[[i for i, _ in pairs]], intrinsics[[j for _, j in pairs]]], axis=1)
+                ver = engine.verify_batch(table, [i * k for i, _ in pairs], [j * k for _, j in pairs], idx, match_off, intr, threshold_px,
+                                          seeds=[(i << 32) | j for i, j in pairs], match_count=count)
+                ver.update(match_idx=idx, match_off=match_off, match_count=count, pairs=pairs)
+                out.append(ver)
+            group = [res] if res is not None else []
         return out
 
     @staticmethod

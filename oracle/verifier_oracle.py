@@ -20,7 +20,8 @@ another either. What is restated here is the published mathematics --
 * the squared Sampson error exactly as ``gtsfm/utils/verification.py:172-220`` computes it;
 * RANSAC scored as USAC scores by default -- MSAC, the sum of min(error, threshold^2), ties to the earlier hypothesis --
   with the standard stopping rule (1 - w^5)^n <= 1 - p on the winner's inlier share and OpenCV's default cap of 1000
-  iterations for ``findEssentialMat`` (here 4 rounds of 256);
+  iterations for ``findEssentialMat`` (here 4 rounds of 256), followed by one round of LO-RANSAC-style inner sampling
+  (Chum, Matas, Kittler 2003): 256 minimal samples drawn from the inliers of the winner, scored on all matches;
 * ``recoverPose``'s choice among (R1, t), (R2, t), (R1, -t), (R2, -t) by counting points with depth in (0, 50) in both
   cameras (OpenCV triangulates with a DLT; here the two depths come from the 2x2 normal equations of
   ``l1 R x1 + t = l2 x2`` -- same sign decisions away from degenerate geometry)
@@ -29,7 +30,8 @@ another either. What is restated here is the published mathematics --
 SAME minimal samples and are compared bit-for-bit on the inlier masks (``tests/test_verifier_gpu.py``). The anchor towards
 the reference is its own verifier contract suite, ``tests/frontend/verifier/test_verifier_base.py`` (two-plane scene: pose
 within 2 degrees and every match verified; empty input; index validity; pickling), restated in ``tests/test_verifier.py``.
-No local optimisation / final polish (USAC_ACCURATE's graph-cut step) is restated.
+USAC_ACCURATE's graph-cut local optimisation and its final least-squares polish are NOT restated; the inner-sampling round
+above stands in for them.
 
 Every arithmetic step below is written as an explicit sequence of IEEE double operations (no ``np.dot`` / ``np.sum`` / BLAS,
 no fused multiply-add), vectorised over the hypothesis axis only, so the device code can follow the same sequence."""
@@ -415,7 +417,26 @@ def ransac_essential(x1: np.ndarray, x2: np.ndarray, threshold: float, seed: int
         return {"E": None, "mask": np.zeros(m, dtype=bool), "hypotheses": done * ROUND, "winner": None}
     with np.errstate(all="ignore"):
         mask = sampson_sq(best_e, x1, x2) < thr2
-    return {"E": best_e, "mask": mask, "hypotheses": done * ROUND, "winner": winner, "cost": best_cost}
+    hypotheses = done * ROUND
+    inliers = np.flatnonzero(mask)
+    if inliers.shape[0] >= 6:
+        # local optimisation, LO-RANSAC's inner sampling with minimal samples: one more round whose samples come from the
+        # inliers of the winner (hypothesis numbers MAX_ROUNDS * ROUND ...), scored on all matches as before
+        hyp = np.arange(MAX_ROUNDS * ROUND, (MAX_ROUNDS + 1) * ROUND)
+        idx = inliers[sample_indices(seed, hyp, inliers.shape[0])]
+        models, nroots = five_point_models(x1[idx], x2[idx])
+        with np.errstate(all="ignore"):
+            err = sampson_sq(models, x1, x2)
+            inl = err < thr2
+            cost = np.cumsum(np.where(inl, err, thr2), axis=-1)[..., -1]
+        cost = np.where(np.arange(10)[None, :] < nroots[:, None], cost, np.inf)
+        flat = cost.reshape(-1)
+        k = int(np.argmin(flat))
+        if flat[k] < best_cost:
+            best_cost, best_e, winner = float(flat[k]), models.reshape(-1, 3, 3)[k].copy(), (int(hyp[k // 10]), k % 10)
+            mask = inl.reshape(-1, m)[k].copy()
+        hypotheses += ROUND
+    return {"E": best_e, "mask": mask, "hypotheses": hypotheses, "winner": winner, "cost": best_cost}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
