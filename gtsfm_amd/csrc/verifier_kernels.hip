@@ -39,10 +39,10 @@ __device__ __forceinline__ unsigned long long vf_splitmix64(unsigned long long x
     return x ^ (x >> 31);
 }
 
-// Five distinct match indices of hypothesis `hyp` (oracle: sample_indices).
-__device__ void vf_sample(unsigned long long seed, unsigned long long hyp, int m, int out[5]) {
+// `size` (5 or 7) distinct match indices of hypothesis `hyp` (oracle: sample_indices).
+__device__ void vf_sample(unsigned long long seed, unsigned long long hyp, int m, int* out, int size) {
     unsigned long long attempt = 0;
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < size; ++k) {
         for (;;) {
             const bool exhausted = attempt >= 64;
             int draw = (int)(vf_splitmix64(seed ^ vf_splitmix64((hyp << 8) | attempt)) % (unsigned long long)m);
@@ -66,14 +66,16 @@ __device__ void vf_sample(unsigned long long seed, unsigned long long hyp, int m
     }
 }
 
-// Null space of the 5x9 epipolar system: Gauss-Jordan with complete pivoting (oracle: _null_space).
-__device__ void vf_null_space(double a[5][9], double basis[4][9]) {
+// Null space of the NRx9 epipolar system (NR = 5: essential, 7: fundamental): Gauss-Jordan with complete pivoting
+// (oracle: _null_space).
+template <int NR>
+__device__ void vf_null_space(double a[NR][9], double basis[9 - NR][9]) {
     int perm[9];
     for (int j = 0; j < 9; ++j) perm[j] = j;
-    for (int r = 0; r < 5; ++r) {
+    for (int r = 0; r < NR; ++r) {
         double best = -1.0;
         int pr = r, pc = r;
-        for (int i = r; i < 5; ++i)
+        for (int i = r; i < NR; ++i)
             for (int j = r; j < 9; ++j) {
                 const double v = fabs(a[i][j]);
                 if (v > best) {
@@ -87,7 +89,7 @@ __device__ void vf_null_space(double a[5][9], double basis[4][9]) {
             a[r][j] = a[pr][j];
             a[pr][j] = t;
         }
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const double t = a[i][r];
             a[i][r] = a[i][pc];
             a[i][pc] = t;
@@ -99,17 +101,17 @@ __device__ void vf_null_space(double a[5][9], double basis[4][9]) {
         }
         const double piv = a[r][r];
         for (int j = r; j < 9; ++j) a[r][j] = a[r][j] / piv;
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < NR; ++i) {
             if (i == r) continue;
             const double f = a[i][r];
             for (int j = r + 1; j < 9; ++j) a[i][j] = a[i][j] - f * a[r][j];
             a[i][r] = 0.0;
         }
     }
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 9 - NR; ++k) {
         for (int j = 0; j < 9; ++j) basis[k][j] = 0.0;
-        basis[k][perm[5 + k]] = 1.0;
-        for (int i = 0; i < 5; ++i) basis[k][perm[i]] = -a[i][5 + k];
+        basis[k][perm[NR + k]] = 1.0;
+        for (int i = 0; i < NR; ++i) basis[k][perm[i]] = -a[i][NR + k];
     }
 }
 
@@ -238,19 +240,19 @@ __device__ void vf_hidden_variable(const double a[10][20], double p1[8], double 
     for (int k = 0; k < 11; ++k) det[k] = (u[k] + v[k]) + w[k];
 }
 
-// Real roots of a tenth-degree polynomial in [-R, R] through the chain of its derivatives (oracle: real_roots_deg10).
-__device__ int vf_real_roots(const double p[11], double roots[10]) {
+// Real roots of a degree-n polynomial (n <= 10) in [-R, R] through the chain of its derivatives (oracle: real_roots).
+__device__ int vf_real_roots(const double* p, int n, double* roots) {
     double big = 0.0;
-    for (int k = 0; k < 10; ++k) {
-        const double v = fabs(p[k] / p[10]);
+    for (int k = 0; k < n; ++k) {
+        const double v = fabs(p[k] / p[n]);
         if (v > big) big = v;
     }
     double rng = 1.0 + big;
     if (rng > VF_ROOT_RANGE_CAP) rng = VF_ROOT_RANGE_CAP;
     double prev[10], cur[10], d[11];
     int nprev = 0;
-    for (int deg = 1; deg <= 10; ++deg) {
-        const int s = 10 - deg;
+    for (int deg = 1; deg <= n; ++deg) {
+        const int s = n - deg;
         for (int k = 0; k <= deg; ++k) {
             double factor = 1.0;
             for (int i = 1; i <= s; ++i) factor *= (double)(k + i);
@@ -281,6 +283,41 @@ __device__ int vf_real_roots(const double p[11], double roots[10]) {
     return nprev;
 }
 
+// The residual of OpenCV's fundamental-matrix RANSAC: the larger squared point-to-epipolar-line distance of the two images
+// (oracle: epipolar_distance_sq_max).
+__device__ __forceinline__ double vf_epipolar_sq_max(const double* f, double a, double b, double c, double d) {
+    const double l2x = (f[0] * a + f[1] * b) + f[2];
+    const double l2y = (f[3] * a + f[4] * b) + f[5];
+    const double l2z = (f[6] * a + f[7] * b) + f[8];
+    const double l1x = (f[0] * c + f[3] * d) + f[6];
+    const double l1y = (f[1] * c + f[4] * d) + f[7];
+    const double r = (c * l2x + d * l2y) + l2z;
+    const double d2 = (r * r) / (l2x * l2x + l2y * l2y);
+    const double d1 = (r * r) / (l1x * l1x + l1y * l1y);
+    return d1 > d2 ? d1 : d2;
+}
+
+// Seven-point solver: the cubic det(x F1 + F2) on the two-dimensional null space (oracle: seven_point_models).
+__device__ void vf_seven_point_cubic(const double basis[2][9], double det[4]) {
+    double e[3][3][2];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) e[i][j][0] = basis[1][3 * i + j], e[i][j][1] = basis[0][3 * i + j];
+    double c[3][3], u[3], v[3], t0[4], t1[4], t2[4];
+    vf_poly_mul(e[1][1], 2, e[2][2], 2, u);
+    vf_poly_mul(e[1][2], 2, e[2][1], 2, v);
+    for (int k = 0; k < 3; ++k) c[0][k] = u[k] - v[k];
+    vf_poly_mul(e[1][2], 2, e[2][0], 2, u);
+    vf_poly_mul(e[1][0], 2, e[2][2], 2, v);
+    for (int k = 0; k < 3; ++k) c[1][k] = u[k] - v[k];
+    vf_poly_mul(e[1][0], 2, e[2][1], 2, u);
+    vf_poly_mul(e[1][1], 2, e[2][0], 2, v);
+    for (int k = 0; k < 3; ++k) c[2][k] = u[k] - v[k];
+    vf_poly_mul(e[0][0], 2, c[0], 3, t0);
+    vf_poly_mul(e[0][1], 2, c[1], 3, t1);
+    vf_poly_mul(e[0][2], 2, c[2], 3, t2);
+    for (int k = 0; k < 4; ++k) det[k] = (t0[k] + t1[k]) + t2[k];
+}
+
 // Squared Sampson error of one correspondence (gtsfm/utils/verification.py:172-220; oracle: sampson_sq).
 __device__ __forceinline__ double vf_sampson_sq(const double* e, double a, double b, double c, double d) {
     const double l2x = (e[0] * a + e[1] * b) + e[2];
@@ -296,7 +333,7 @@ __device__ __forceinline__ double vf_sampson_sq(const double* e, double a, doubl
 __global__ __launch_bounds__(256) void verify_gather_kernel(const float* __restrict__ kp_xy, const long long* __restrict__ kp_off1,
                                                             const long long* __restrict__ kp_off2, const int* __restrict__ match_idx,
                                                             const long long* __restrict__ match_off, const int* __restrict__ match_count,
-                                                            const double* __restrict__ intrinsics, double* __restrict__ pts) {
+                                                            const double* __restrict__ intrinsics, int normalise, double* __restrict__ pts) {
     const int pair = blockIdx.y;
     const long long begin = match_off[pair], m = match_count ? (long long)match_count[pair] : match_off[pair + 1] - begin;
     const double* K = intrinsics + 8 * (size_t)pair;
@@ -305,10 +342,14 @@ __global__ __launch_bounds__(256) void verify_gather_kernel(const float* __restr
         const float* a = kp_xy + 2 * (kp_off1[pair] + mi[0]);
         const float* b = kp_xy + 2 * (kp_off2[pair] + mi[1]);
         double* o = pts + 4 * (begin + i);
-        o[0] = ((double)a[0] - K[2]) / K[0];
-        o[1] = ((double)a[1] - K[3]) / K[1];
-        o[2] = ((double)b[0] - K[6]) / K[4];
-        o[3] = ((double)b[1] - K[7]) / K[5];
+        if (normalise) {  // Cal3Bundler.calibrate without distortion, gtsfm/utils/features.py:41-51
+            o[0] = ((double)a[0] - K[2]) / K[0];
+            o[1] = ((double)a[1] - K[3]) / K[1];
+            o[2] = ((double)b[0] - K[6]) / K[4];
+            o[3] = ((double)b[1] - K[7]) / K[5];
+        } else {  // fundamental-matrix mode works on pixels
+            o[0] = (double)a[0], o[1] = (double)a[1], o[2] = (double)b[0], o[3] = (double)b[1];
+        }
     }
 }
 
@@ -417,52 +458,19 @@ __device__ __forceinline__ bool vf_in_front(const double* r, double t0, double t
     return l1 > 0 && l2 > 0 && l1 < VF_DEPTH_LIMIT && l2 < VF_DEPTH_LIMIT;
 }
 
-__global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __restrict__ pts, const long long* __restrict__ match_off,
-                                                            const int* __restrict__ match_count, const double* __restrict__ intrinsics, const unsigned long long* __restrict__ seeds,
-                                                            double threshold_px, double* __restrict__ out_e, double* __restrict__ out_r,
-                                                            double* __restrict__ out_t, unsigned char* __restrict__ out_mask,
-                                                            int* __restrict__ out_stats, int* __restrict__ inlier_lists) {
-    __shared__ VfShared sh;
-    const int pair = blockIdx.x, tid = threadIdx.x;
-    const long long begin = match_off[pair];
-    const int m = match_count ? match_count[pair] : (int)(match_off[pair + 1] - begin);
-    const double* P = pts + 4 * begin;
-    unsigned char* mask = out_mask + begin;
-    int* inl_list = inlier_lists + begin;
-    int* stats = out_stats + 8 * (size_t)pair;
-    for (long long i = m + tid; i < match_off[pair + 1] - begin; i += 256) mask[i] = 0;  // unused capacity behind the list
-    if (m < 6) {  // NUM_MATCHES_REQ_E_MATRIX and the "< 6" guard of opencv_verifier_base.py:79
-        for (int i = tid; i < m; i += 256) mask[i] = 0;
-        if (tid < 8) stats[tid] = tid >= 2 && tid < 4 ? -1 : 0;
-        if (tid < 9) out_e[9 * (size_t)pair + tid] = out_r[9 * (size_t)pair + tid] = NAN;
-        if (tid < 3) out_t[3 * (size_t)pair + tid] = NAN;
-        return;
-    }
-    const double fx = intrinsics[8 * (size_t)pair] > intrinsics[8 * (size_t)pair + 4] ? intrinsics[8 * (size_t)pair] : intrinsics[8 * (size_t)pair + 4];
-    const double thr = threshold_px / fx, thr2 = thr * thr;
-    const unsigned long long seed = seeds[pair];
-    if (tid == 0) sh.best_cost = INFINITY, sh.best_count = 0, sh.best_index = -1, sh.stop = 0;
-    __syncthreads();
-
-    int rounds = 0;
-    bool lo_round = false;  // the last round draws its minimal samples from the inliers of the best model so far
-    for (;;) {
-        const int hyp = (lo_round ? VF_MAX_ROUNDS : rounds) * VF_ROUND + tid;
-        int idx[5];
-        vf_sample(seed, (unsigned long long)hyp, lo_round ? sh.inliers : m, idx);
-        if (lo_round)
-            for (int k = 0; k < 5; ++k) idx[k] = inl_list[idx[k]];
+// All real solutions of one minimal sample. MODE 0: five-point essential matrices (<= 10); MODE 1: seven-point fundamental
+// matrices (<= 3). P = the pair's points (x1, y1, x2, y2), normalised (MODE 0) or pixels (MODE 1).
+template <int MODE>
+__device__ int vf_solve(const double* __restrict__ P, const int* idx, double models[][9]) {
+    if (MODE == 0) {
         double basis[4][9];
-        double my_e[9];
-        double my_cost = INFINITY;
-        int my_count = 0, my_root = 0;
         {
             double q[5][9];
             for (int k = 0; k < 5; ++k) {
                 const double a = P[4 * idx[k]], b = P[4 * idx[k] + 1], c = P[4 * idx[k] + 2], d = P[4 * idx[k] + 3];
                 q[k][0] = c * a, q[k][1] = c * b, q[k][2] = c, q[k][3] = d * a, q[k][4] = d * b, q[k][5] = d, q[k][6] = a, q[k][7] = b, q[k][8] = 1.0;
             }
-            vf_null_space(q, basis);
+            vf_null_space<5>(q, basis);
         }
         double p1[8], p2[8], p3[7], det[11], roots[10];
         {
@@ -471,26 +479,95 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
             vf_gauss_jordan(mat);
             vf_hidden_variable(mat, p1, p2, p3, det);
         }
-        const int nroots = vf_real_roots(det, roots);
+        const int nroots = vf_real_roots(det, 10, roots);
         for (int r = 0; r < nroots; ++r) {
             const double z = roots[r];
             const double x = vf_horner(p1, 7, z) / vf_horner(p3, 6, z);
             const double y = vf_horner(p2, 7, z) / vf_horner(p3, 6, z);
-            double e[9];
-            for (int k = 0; k < 9; ++k) e[k] = ((x * basis[0][k] + y * basis[1][k]) + z * basis[2][k]) + basis[3][k];
+            for (int k = 0; k < 9; ++k) models[r][k] = ((x * basis[0][k] + y * basis[1][k]) + z * basis[2][k]) + basis[3][k];
+        }
+        return nroots;
+    } else {
+        double basis[2][9];
+        {
+            double q[7][9];
+            for (int k = 0; k < 7; ++k) {
+                const double a = P[4 * idx[k]], b = P[4 * idx[k] + 1], c = P[4 * idx[k] + 2], d = P[4 * idx[k] + 3];
+                q[k][0] = c * a, q[k][1] = c * b, q[k][2] = c, q[k][3] = d * a, q[k][4] = d * b, q[k][5] = d, q[k][6] = a, q[k][7] = b, q[k][8] = 1.0;
+            }
+            vf_null_space<7>(q, basis);
+        }
+        double det[4], roots[3];
+        vf_seven_point_cubic(basis, det);
+        const int nroots = vf_real_roots(det, 3, roots);
+        for (int r = 0; r < nroots; ++r)
+            for (int k = 0; k < 9; ++k) models[r][k] = roots[r] * basis[0][k] + basis[1][k];
+        return nroots;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ double vf_residual(const double* model, double a, double b, double c, double d) {
+    return MODE == 0 ? vf_sampson_sq(model, a, b, c, d) : vf_epipolar_sq_max(model, a, b, c, d);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __restrict__ pts, const long long* __restrict__ match_off,
+                                                            const int* __restrict__ match_count, const double* __restrict__ intrinsics, const unsigned long long* __restrict__ seeds,
+                                                            double threshold_px, double* __restrict__ out_e, double* __restrict__ out_r,
+                                                            double* __restrict__ out_t, unsigned char* __restrict__ out_mask,
+                                                            int* __restrict__ out_stats, int* __restrict__ inlier_lists, double* __restrict__ out_f) {
+    constexpr int SIZE = MODE == 0 ? 5 : 7;      // minimal sample
+    constexpr int MAX_MODELS = MODE == 0 ? 10 : 3;
+    constexpr int MIN_MATCHES = MODE == 0 ? 6 : 8;  // opencv_verifier_base.py:71-80 (NUM_MATCHES_REQ_E_MATRIX and the "< 6" guard; NUM_MATCHES_REQ_F_MATRIX)
+    __shared__ VfShared sh;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const long long begin = match_off[pair];
+    const int m = match_count ? match_count[pair] : (int)(match_off[pair + 1] - begin);
+    const double* P = pts + 4 * begin;
+    const double* K = intrinsics + 8 * (size_t)pair;
+    unsigned char* mask = out_mask + begin;
+    int* inl_list = inlier_lists + begin;
+    int* stats = out_stats + 8 * (size_t)pair;
+    for (long long i = m + tid; i < match_off[pair + 1] - begin; i += 256) mask[i] = 0;  // unused capacity behind the list
+    if (m < MIN_MATCHES) {
+        for (int i = tid; i < m; i += 256) mask[i] = 0;
+        if (tid < 8) stats[tid] = tid >= 2 && tid < 4 ? -1 : 0;
+        if (tid < 9) out_e[9 * (size_t)pair + tid] = out_r[9 * (size_t)pair + tid] = NAN;
+        if (MODE == 1 && tid < 9) out_f[9 * (size_t)pair + tid] = NAN;
+        if (tid < 3) out_t[3 * (size_t)pair + tid] = NAN;
+        return;
+    }
+    // essential mode: px / max(fx1, fx2) in normalised units (opencv_verifier_base.py:86-90); fundamental mode: pixels
+    const double thr = MODE == 0 ? threshold_px / (K[0] > K[4] ? K[0] : K[4]) : threshold_px;
+    const double thr2 = thr * thr;
+    const unsigned long long seed = seeds[pair];
+    if (tid == 0) sh.best_cost = INFINITY, sh.best_count = 0, sh.best_index = -1, sh.stop = 0;
+    __syncthreads();
+
+    int rounds = 0;
+    bool lo_round = false;  // the last round draws its minimal samples from the inliers of the best model so far
+    for (;;) {
+        const int hyp = (lo_round ? VF_MAX_ROUNDS : rounds) * VF_ROUND + tid;
+        int idx[SIZE];
+        vf_sample(seed, (unsigned long long)hyp, lo_round ? sh.inliers : m, idx, SIZE);
+        if (lo_round)
+            for (int k = 0; k < SIZE; ++k) idx[k] = inl_list[idx[k]];
+        double models[MAX_MODELS][9];
+        const int nroots = vf_solve<MODE>(P, idx, models);
+        double my_cost = INFINITY;
+        int my_count = 0, my_root = 0;
+        for (int r = 0; r < nroots; ++r) {
             // MSAC cost (USAC's default score): sum of min(error, thr^2), added in match order; NaN errors are outliers
             double cost = 0.0;
             int count = 0;
             for (int i = 0; i < m; ++i) {
-                const double err = vf_sampson_sq(e, P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]);
+                const double err = vf_residual<MODE>(models[r], P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]);
                 const bool in = err < thr2;
                 cost = cost + (in ? err : thr2);
                 count += in ? 1 : 0;
             }
-            if (cost < my_cost) {
-                my_cost = cost, my_count = count, my_root = r;
-                for (int k = 0; k < 9; ++k) my_e[k] = e[k];
-            }
+            if (cost < my_cost) my_cost = cost, my_count = count, my_root = r;
         }
         // round winner: lowest cost, then the smallest (hypothesis, root)
         sh.cost[tid] = my_cost;
@@ -508,7 +585,7 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
         const bool improves = win_cost < sh.best_cost;
         __syncthreads();
         if (improves && hyp * 16 + my_root == win_index) {
-            for (int k = 0; k < 9; ++k) sh.best_e[k] = my_e[k];
+            for (int k = 0; k < 9; ++k) sh.best_e[k] = models[my_root][k];
             sh.best_cost = win_cost;
             sh.best_count = my_count;
             sh.best_index = win_index;
@@ -516,9 +593,11 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
         __syncthreads();
         if (lo_round) break;
         ++rounds;
-        if (tid == 0 && sh.best_count > 0) {  // (1 - w^5)^(256 rounds) <= 1 - p, exact multiplication chain (oracle: _stop_after)
+        if (tid == 0 && sh.best_count > 0) {  // (1 - w^SIZE)^(256 rounds) <= 1 - p, exact multiplication chain (oracle: _stop_after)
             const double w = (double)sh.best_count / (double)m;
-            const double q = 1.0 - w * w * w * w * w;
+            double ws = w;
+            for (int k = 0; k < SIZE - 1; ++k) ws = ws * w;
+            const double q = 1.0 - ws;
             double p256 = q;
             for (int k = 0; k < 8; ++k) p256 = p256 * p256;
             double acc = p256;
@@ -535,7 +614,7 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
         __syncthreads();
         for (int base = 0; base < m; base += 256) {
             const int i = base + tid;
-            const bool in = i < m && vf_sampson_sq(e, P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]) < thr2;
+            const bool in = i < m && vf_residual<MODE>(e, P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]) < thr2;
             const unsigned long long ballot = __ballot(in);
             if ((tid & 63) == 0) sh.index[tid >> 6] = __popcll(ballot);
             __syncthreads();
@@ -547,7 +626,7 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
             if (tid == 0) sh.inliers += sh.index[0] + sh.index[1] + sh.index[2] + sh.index[3];
             __syncthreads();
         }
-        if (sh.inliers < 6) break;
+        if (sh.inliers < SIZE + 1) break;
         lo_round = true;
     }
     const int hypotheses = (rounds + (lo_round ? 1 : 0)) * VF_ROUND;
@@ -556,11 +635,23 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
         for (int i = tid; i < m; i += 256) mask[i] = 0;
         if (tid < 8) stats[tid] = tid == 1 ? hypotheses : (tid >= 2 && tid < 4 ? -1 : 0);
         if (tid < 9) out_e[9 * (size_t)pair + tid] = out_r[9 * (size_t)pair + tid] = NAN;
+        if (MODE == 1 && tid < 9) out_f[9 * (size_t)pair + tid] = NAN;
         if (tid < 3) out_t[3 * (size_t)pair + tid] = NAN;
         return;
     }
-    double e[9];
-    for (int k = 0; k < 9; ++k) e[k] = sh.best_e[k];
+    double model[9], e[9];
+    for (int k = 0; k < 9; ++k) model[k] = e[k] = sh.best_e[k];
+    if (MODE == 1) {  // E = K2^T F K1 (gtsfm/utils/verification.py:99-112), products in the oracle's order
+        const double k2t[3][3] = {{K[4], 0.0, 0.0}, {0.0, K[5], 0.0}, {K[6], K[7], 1.0}};
+        const double k1[3][3] = {{K[0], 0.0, K[2]}, {0.0, K[1], K[3]}, {0.0, 0.0, 1.0}};
+        double f[3][3], t[3][3], em[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) f[i][j] = model[3 * i + j];
+        vf_mat3(k2t, f, t);
+        vf_mat3(t, k1, em);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) e[3 * i + j] = em[i][j];
+    }
     __syncthreads();
     if (tid == 0) {
         sh.inliers = 0;
@@ -574,11 +665,12 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
     int inl = 0, good[4] = {0, 0, 0, 0};
     const double t0 = sh.t[0], t1 = sh.t[1], t2 = sh.t[2];
     for (int i = tid; i < m; i += 256) {
-        const double a = P[4 * i], b = P[4 * i + 1], c = P[4 * i + 2], d = P[4 * i + 3];
-        const bool in = vf_sampson_sq(e, a, b, c, d) < thr2;
+        double a = P[4 * i], b = P[4 * i + 1], c = P[4 * i + 2], d = P[4 * i + 3];
+        const bool in = vf_residual<MODE>(model, a, b, c, d) < thr2;
         mask[i] = in ? 1 : 0;
         if (in) {
             ++inl;
+            if (MODE == 1) a = (a - K[2]) / K[0], b = (b - K[3]) / K[1], c = (c - K[6]) / K[4], d = (d - K[7]) / K[5];  // recoverPose works on normalised points
             good[0] += vf_in_front(sh.pose[0], t0, t1, t2, a, b, c, d) ? 1 : 0;
             good[1] += vf_in_front(sh.pose[1], t0, t1, t2, a, b, c, d) ? 1 : 0;
             good[2] += vf_in_front(sh.pose[0], -t0, -t1, -t2, a, b, c, d) ? 1 : 0;
@@ -598,12 +690,12 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
                 break;
             }
         }
-        const double sign = pick >= 2 ? -1.0 : 1.0;
         for (int k = 0; k < 9; ++k) {
             out_e[9 * (size_t)pair + k] = e[k];
             out_r[9 * (size_t)pair + k] = sh.pose[pick & 1][k];
+            if (MODE == 1) out_f[9 * (size_t)pair + k] = model[k];
         }
-        for (int k = 0; k < 3; ++k) out_t[3 * (size_t)pair + k] = sign < 0 ? -sh.t[k] : sh.t[k];
+        for (int k = 0; k < 3; ++k) out_t[3 * (size_t)pair + k] = pick >= 2 ? -sh.t[k] : sh.t[k];
         stats[0] = sh.inliers, stats[1] = hypotheses, stats[2] = sh.best_index >> 4, stats[3] = sh.best_index & 15;
         for (int k = 0; k < 4; ++k) stats[4 + k] = sh.good[k];
     }
@@ -660,31 +752,56 @@ extern "C" size_t gtsfm_verify_workspace_bytes(long long total_matches) {
     return align_up(n * 4 * sizeof(double), 256) + align_up(n * sizeof(int), 256) + 256;  // normalised points, inlier lists
 }
 
-extern "C" int gtsfm_verify_essential_f64(const float* kp_xy_dev, const long long* kp_off1_dev, const long long* kp_off2_dev,
-                                          const int32_t* match_idx_dev, const long long* match_off_dev, const int32_t* match_count_dev,
-                                          long long total_matches, const double* intrinsics_dev, const unsigned long long* seeds_dev, double threshold_px,
-                                          int num_pairs, void* workspace_dev, size_t workspace_bytes, double* essential_dev,
-                                          double* rotation_dev, double* translation_dev, uint8_t* inlier_mask_dev, int32_t* stats_dev,
-                                          void* stream) {
-    GTSFM_CHECK_ARG(num_pairs >= 0 && total_matches >= 0 && threshold_px > 0, "verify_essential: bad sizes or threshold");
+static int verify_two_view(int mode, const float* kp_xy_dev, const long long* kp_off1_dev, const long long* kp_off2_dev, const int32_t* match_idx_dev,
+                           const long long* match_off_dev, const int32_t* match_count_dev, long long total_matches, const double* intrinsics_dev,
+                           const unsigned long long* seeds_dev, double threshold_px, int num_pairs, void* workspace_dev, size_t workspace_bytes,
+                           double* fundamental_dev, double* essential_dev, double* rotation_dev, double* translation_dev, uint8_t* inlier_mask_dev,
+                           int32_t* stats_dev, void* stream) {
+    GTSFM_CHECK_ARG(num_pairs >= 0 && total_matches >= 0 && threshold_px > 0, "verify: bad sizes or threshold");
     if (num_pairs == 0) return GTSFM_OK;
-    GTSFM_CHECK_ARG(kp_xy_dev && kp_off1_dev && kp_off2_dev && match_off_dev && intrinsics_dev && seeds_dev, "verify_essential: null input");
-    GTSFM_CHECK_ARG(essential_dev && rotation_dev && translation_dev && stats_dev, "verify_essential: null output");
-    GTSFM_CHECK_ARG(total_matches == 0 || (match_idx_dev && inlier_mask_dev), "verify_essential: null match arrays");
-    GTSFM_CHECK_ARG(num_pairs <= 65535, "verify_essential: at most 65535 pairs per call");
+    GTSFM_CHECK_ARG(kp_xy_dev && kp_off1_dev && kp_off2_dev && match_off_dev && intrinsics_dev && seeds_dev, "verify: null input");
+    GTSFM_CHECK_ARG(essential_dev && rotation_dev && translation_dev && stats_dev && (mode == 0 || fundamental_dev), "verify: null output");
+    GTSFM_CHECK_ARG(total_matches == 0 || (match_idx_dev && inlier_mask_dev), "verify: null match arrays");
+    GTSFM_CHECK_ARG(num_pairs <= 65535, "verify: at most 65535 pairs per call");
     if (workspace_bytes < gtsfm_verify_workspace_bytes(total_matches) || !workspace_dev) {
-        gtsfm_set_error("verify_essential: workspace too small (%zu < %zu)", workspace_bytes, gtsfm_verify_workspace_bytes(total_matches));
+        gtsfm_set_error("verify: workspace too small (%zu < %zu)", workspace_bytes, gtsfm_verify_workspace_bytes(total_matches));
         return GTSFM_ERR_WORKSPACE;
     }
     double* pts = (double*)align_up((size_t)workspace_dev, 256);
     int* inlier_lists = (int*)((char*)pts + align_up((size_t)total_matches * 4 * sizeof(double), 256));
     if (total_matches > 0) {
         hipLaunchKernelGGL(verify_gather_kernel, dim3(4, num_pairs), dim3(256), 0, (hipStream_t)stream, kp_xy_dev, kp_off1_dev, kp_off2_dev,
-                           match_idx_dev, match_off_dev, match_count_dev, intrinsics_dev, pts);
+                           match_idx_dev, match_off_dev, match_count_dev, intrinsics_dev, mode == 0 ? 1 : 0, pts);
         GTSFM_CHECK_LAUNCH("verify_gather_kernel");
     }
-    hipLaunchKernelGGL(verify_ransac_kernel, dim3(num_pairs), dim3(256), 0, (hipStream_t)stream, pts, match_off_dev, match_count_dev, intrinsics_dev, seeds_dev,
-                       threshold_px, essential_dev, rotation_dev, translation_dev, inlier_mask_dev, stats_dev, inlier_lists);
+    if (mode == 0)
+        hipLaunchKernelGGL(verify_ransac_kernel<0>, dim3(num_pairs), dim3(256), 0, (hipStream_t)stream, pts, match_off_dev, match_count_dev, intrinsics_dev,
+                           seeds_dev, threshold_px, essential_dev, rotation_dev, translation_dev, inlier_mask_dev, stats_dev, inlier_lists, (double*)nullptr);
+    else
+        hipLaunchKernelGGL(verify_ransac_kernel<1>, dim3(num_pairs), dim3(256), 0, (hipStream_t)stream, pts, match_off_dev, match_count_dev, intrinsics_dev,
+                           seeds_dev, threshold_px, essential_dev, rotation_dev, translation_dev, inlier_mask_dev, stats_dev, inlier_lists, fundamental_dev);
     GTSFM_CHECK_LAUNCH("verify_ransac_kernel");
     return GTSFM_OK;
+}
+
+extern "C" int gtsfm_verify_essential_f64(const float* kp_xy_dev, const long long* kp_off1_dev, const long long* kp_off2_dev,
+                                          const int32_t* match_idx_dev, const long long* match_off_dev, const int32_t* match_count_dev,
+                                          long long total_matches, const double* intrinsics_dev, const unsigned long long* seeds_dev, double threshold_px,
+                                          int num_pairs, void* workspace_dev, size_t workspace_bytes, double* essential_dev,
+                                          double* rotation_dev, double* translation_dev, uint8_t* inlier_mask_dev, int32_t* stats_dev,
+                                          void* stream) {
+    return verify_two_view(0, kp_xy_dev, kp_off1_dev, kp_off2_dev, match_idx_dev, match_off_dev, match_count_dev, total_matches, intrinsics_dev, seeds_dev,
+                           threshold_px, num_pairs, workspace_dev, workspace_bytes, nullptr, essential_dev, rotation_dev, translation_dev, inlier_mask_dev,
+                           stats_dev, stream);
+}
+
+extern "C" int gtsfm_verify_fundamental_f64(const float* kp_xy_dev, const long long* kp_off1_dev, const long long* kp_off2_dev,
+                                            const int32_t* match_idx_dev, const long long* match_off_dev, const int32_t* match_count_dev,
+                                            long long total_matches, const double* intrinsics_dev, const unsigned long long* seeds_dev, double threshold_px,
+                                            int num_pairs, void* workspace_dev, size_t workspace_bytes, double* fundamental_dev, double* essential_dev,
+                                            double* rotation_dev, double* translation_dev, uint8_t* inlier_mask_dev, int32_t* stats_dev,
+                                            void* stream) {
+    return verify_two_view(1, kp_xy_dev, kp_off1_dev, kp_off2_dev, match_idx_dev, match_off_dev, match_count_dev, total_matches, intrinsics_dev, seeds_dev,
+                           threshold_px, num_pairs, workspace_dev, workspace_bytes, fundamental_dev, essential_dev, rotation_dev, translation_dev,
+                           inlier_mask_dev, stats_dev, stream);
 }

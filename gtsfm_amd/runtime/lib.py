@@ -98,6 +98,11 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
          C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "gtsfm_verify_fundamental_f64": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+         C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
     "gtsfm_verify_compact_matches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gtsfm_lg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p]),
     "gtsfm_lg_forward": (

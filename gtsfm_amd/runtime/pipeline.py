@@ -167,7 +167,7 @@ class FrontEndPipeline:
         return out
 
     def verify(self, feats: Dict[str, torch.Tensor], results: List[Dict[str, torch.Tensor]], intrinsics: np.ndarray, threshold_px: float,
-               engine=None) -> List[Dict[str, torch.Tensor]]:
+               engine=None, use_intrinsics: bool = True) -> List[Dict[str, torch.Tensor]]:
         """The verifier stage on the matcher's device output (``two_view_estimator.py:391-397`` per pair in the reference):
         all chunks of ``match()`` together in one compaction launch and one RANSAC launch, nothing copied to the host. ``intrinsics``
         [num_images, 4] = (fx, fy, cx, cy) per row of the feature table. Pair (i, j) draws its minimal samples from the seed
@@ -197,7 +197,7 @@ class FrontEndPipeline:
                 idx, match_off, count = engine.compact_matches(matches, rows.tolist(), n0)
                 intr = np.concatenate([intrinsics[[i for i, _ in pairs]], intrinsics[[j for _, j in pairs]]], axis=1)
                 ver = engine.verify_batch(table, [i * k for i, _ in pairs], [j * k for _, j in pairs], idx, match_off, intr, threshold_px,
-                                          seeds=[(i << 32) | j for i, j in pairs], match_count=count)
+                                          seeds=[(i << 32) | j for i, j in pairs], match_count=count, use_intrinsics=use_intrinsics)
                 ver.update(match_idx=idx, match_off=match_off, match_count=count, pairs=pairs)
                 out.append(ver)
             group = [res] if res is not None else []

@@ -47,11 +47,13 @@ class VerifierEngine:
         threshold_px: float,
         seeds: Optional[Sequence[int]] = None,
         match_count: Optional[torch.Tensor] = None,
+        use_intrinsics: bool = True,
     ) -> Dict[str, torch.Tensor]:
         """kp_xy [*,2] float32 pixel coordinates (device); pair p reads image i1's rows from kp_off1[p] and image i2's from
         kp_off2[p]; match_idx [M,2] int32 (device) rows relative to those offsets, pair p owning match_off[p]:match_off[p+1];
         intrinsics [P,8] = (fx, fy, cx, cy) of i1 then i2; match_count [P] int32 (device, optional): only the first
-        match_count[p] rows of pair p's slice are matches (capacity layout of ``compact_matches``). Returns device tensors: E [P,3,3], R [P,3,3], t [P,3] (NaN when a
+        match_count[p] rows of pair p's slice are matches (capacity layout of ``compact_matches``). ``use_intrinsics=False``:
+        fundamental-matrix estimation on pixel coordinates (adds "F" [P,3,3]; E = K2^T F K1). Returns device tensors: E [P,3,3], R [P,3,3], t [P,3] (NaN when a
         pair has no model), mask [M] uint8, stats [P,8] int32 (``STATS_FIELDS``). Enqueued on the current stream."""
         num_pairs = len(kp_off1)
         assert len(kp_off2) == num_pairs and len(match_off) == num_pairs + 1
@@ -72,19 +74,20 @@ class VerifierEngine:
             "mask": torch.empty(total, dtype=torch.uint8, device=dev),
             "stats": torch.empty((num_pairs, 8), dtype=torch.int32, device=dev),
         }
+        if not use_intrinsics:
+            out["F"] = torch.empty((num_pairs, 3, 3), dtype=torch.float64, device=dev)
         if num_pairs == 0:
             return out
         ws = self._workspace(total)
-        _lib.check(
-            self._lib.gtsfm_verify_essential_f64(
-                kp_xy.data_ptr(), off1.data_ptr(), off2.data_ptr(), match_idx.data_ptr() if total else None, moff.data_ptr(),
-                match_count.data_ptr() if match_count is not None else None, total,
-                intr.data_ptr(), seeds_dev.data_ptr(), float(threshold_px), num_pairs, ws.data_ptr(), ws.numel(), out["E"].data_ptr(),
-                out["R"].data_ptr(), out["t"].data_ptr(), out["mask"].data_ptr() if total else None, out["stats"].data_ptr(),
-                torch.cuda.current_stream(dev).cuda_stream,
-            ),
-            "gtsfm_verify_essential_f64",
-        )
+        head = (kp_xy.data_ptr(), off1.data_ptr(), off2.data_ptr(), match_idx.data_ptr() if total else None, moff.data_ptr(),
+                match_count.data_ptr() if match_count is not None else None, total, intr.data_ptr(), seeds_dev.data_ptr(), float(threshold_px),
+                num_pairs, ws.data_ptr(), ws.numel())
+        tail = (out["E"].data_ptr(), out["R"].data_ptr(), out["t"].data_ptr(), out["mask"].data_ptr() if total else None,
+                out["stats"].data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if use_intrinsics:
+            _lib.check(self._lib.gtsfm_verify_essential_f64(*head, *tail), "gtsfm_verify_essential_f64")
+        else:
+            _lib.check(self._lib.gtsfm_verify_fundamental_f64(*head, out["F"].data_ptr(), *tail), "gtsfm_verify_fundamental_f64")
         return out
 
     def compact_matches(self, matches: torch.Tensor, row_off: Sequence[int], n0: Sequence[int]):

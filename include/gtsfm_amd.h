@@ -245,6 +245,19 @@ int gtsfm_verify_essential_f64(const float* kp_xy_dev, const long long* kp_off1_
                                double* rotation_dev, double* translation_dev, uint8_t* inlier_mask_dev, int32_t* stats_dev,
                                void* stream);
 
+/* The same with use_intrinsics_in_verification=False: fundamental matrix from pixel coordinates, then E = K2^T F K1.
+ *                                  replaces opencv_verifier_base.py:91-97 + ransac.py:86-112 (cv2.findFundamentalMat(FM_RANSAC),
+ *                                  seven-point samples) + gtsfm/utils/verification.py:99-112 (fundamental_to_essential_matrix).
+ * Residual = OpenCV's for this estimator, the larger squared point-to-epipolar-line distance, against threshold_px^2 (not
+ * divided by a focal length); minimal sample 7, at least 8 matches (NUM_MATCHES_REQ_F_MATRIX). fundamental_dev [9] = i2Fi1;
+ * essential_dev [9] = K2^T F K1; pose and cheirality on the normalised coordinates as above. PARITY UNPINNED as above. */
+int gtsfm_verify_fundamental_f64(const float* kp_xy_dev, const long long* kp_off1_dev, const long long* kp_off2_dev,
+                                 const int32_t* match_idx_dev, const long long* match_off_dev, const int32_t* match_count_dev,
+                                 long long total_matches, const double* intrinsics_dev, const unsigned long long* seeds_dev,
+                                 double threshold_px, int num_pairs, void* workspace_dev, size_t workspace_bytes, double* fundamental_dev,
+                                 double* essential_dev, double* rotation_dev, double* translation_dev, uint8_t* inlier_mask_dev,
+                                 int32_t* stats_dev, void* stream);
+
 /* Matcher output -> the verifier's match lists on the device.   replaces the host marshalling of
  * gtsfm/frontend/matcher/superglue_matcher.py:100-102 / lightglue_matcher.py:104-110 ((K, 2) arrays per pair) between the
  * matcher and the verifier. matches_dev: gtsfm_sg_forward / gtsfm_lg_forward output; pair p's matches0 block starts at row

@@ -74,15 +74,15 @@ def splitmix64(x: np.ndarray) -> np.ndarray:
     return x ^ (x >> np.uint64(31))
 
 
-def sample_indices(seed: int, hyp: np.ndarray, m: int) -> np.ndarray:
-    """Five distinct match indices per hypothesis: draw k takes ``splitmix64(seed ^ splitmix64(hyp << 8 | attempt)) % m``
+def sample_indices(seed: int, hyp: np.ndarray, m: int, size: int = 5) -> np.ndarray:
+    """``size`` distinct match indices per hypothesis (5 for the essential, 7 for the fundamental matrix): draw k takes ``splitmix64(seed ^ splitmix64(hyp << 8 | attempt)) % m``
     and repeats with the next attempt while it collides with an earlier draw; after 64 attempts the remaining draws take the
     smallest unused indices (only reachable for tiny m)."""
     with np.errstate(over="ignore"):
         hyp = hyp.astype(np.uint64)
-        out = np.zeros((hyp.shape[0], 5), dtype=np.int64)
+        out = np.zeros((hyp.shape[0], size), dtype=np.int64)
         attempt = np.zeros(hyp.shape[0], dtype=np.uint64)
-        for k in range(5):
+        for k in range(size):
             done = np.zeros(hyp.shape[0], dtype=bool)
             while not done.all():
                 key = (hyp << np.uint64(8)) | attempt
@@ -108,16 +108,17 @@ def sample_indices(seed: int, hyp: np.ndarray, m: int) -> np.ndarray:
 
 
 def _null_space(q: np.ndarray) -> np.ndarray:
-    """q [H,5,9] -> basis [H,4,9] of the null space by Gauss-Jordan with complete pivoting (first maximum wins)."""
+    """q [H,R,9] -> basis [H,9-R,9] of the null space by Gauss-Jordan with complete pivoting (first maximum wins); R = 5
+    (essential matrix) or 7 (fundamental matrix)."""
     a = q.copy()
-    h = a.shape[0]
+    h, nr = a.shape[0], a.shape[1]
     rows = np.arange(h)
     perm = np.tile(np.arange(9), (h, 1))
-    for r in range(5):
+    for r in range(nr):
         best = np.full(h, -1.0)
         pr = np.full(h, r)
         pc = np.full(h, r)
-        for i in range(r, 5):
+        for i in range(r, nr):
             for j in range(r, 9):
                 v = np.abs(a[:, i, j])
                 better = v > best
@@ -136,18 +137,18 @@ def _null_space(q: np.ndarray) -> np.ndarray:
         piv = a[:, r, r].copy()
         for j in range(r, 9):
             a[:, r, j] = a[:, r, j] / piv
-        for i in range(5):
+        for i in range(nr):
             if i == r:
                 continue
             f = a[:, i, r].copy()
             for j in range(r + 1, 9):
                 a[:, i, j] = a[:, i, j] - f * a[:, r, j]
             a[:, i, r] = 0.0
-    basis = np.zeros((h, 4, 9))
-    for k in range(4):
-        basis[rows, k, perm[:, 5 + k]] = 1.0
-        for i in range(5):
-            basis[rows, k, perm[:, i]] = -a[:, i, 5 + k]
+    basis = np.zeros((h, 9 - nr, 9))
+    for k in range(9 - nr):
+        basis[rows, k, perm[:, nr + k]] = 1.0
+        for i in range(nr):
+            basis[rows, k, perm[:, i]] = -a[:, i, nr + k]
     return basis
 
 
@@ -274,34 +275,34 @@ def _horner(coeffs: np.ndarray, deg: int, x: np.ndarray) -> np.ndarray:
     return v
 
 
-def real_roots_deg10(p: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """Real roots of [H,11] polynomials in [-R, R], R = min(1 + max|a_k / a_10|, 1e8): the roots of the (10-d)-th derivative
-    split the line into intervals on which the (9-d)-th derivative is monotonic; every sign change is bisected until the
-    midpoint stops moving. Returns (roots [H,10] ascending, count [H])."""
+def real_roots(p: np.ndarray, n: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Real roots of [H,n+1] polynomials of degree n in [-R, R], R = min(1 + max|a_k / a_n|, 1e8): the roots of the (n-d)-th
+    derivative split the line into intervals on which the (n-1-d)-th derivative is monotonic; every sign change is bisected until
+    the midpoint stops moving. Returns (roots [H,n] ascending, count [H]). n = 10 (five-point solver), 3 (seven-point)."""
     h = p.shape[0]
     with np.errstate(all="ignore"):
         big = np.zeros(h)
-        for k in range(10):
-            v = np.abs(p[:, k] / p[:, 10])
+        for k in range(n):
+            v = np.abs(p[:, k] / p[:, n])
             big = np.where(v > big, v, big)
         rng = 1.0 + big
         rng = np.where(rng > ROOT_RANGE_CAP, ROOT_RANGE_CAP, rng)
-        prev = np.zeros((h, 10))
+        prev = np.zeros((h, n))
         nprev = np.zeros(h, dtype=np.int64)
-        for deg in range(1, 11):
-            s = 10 - deg
+        for deg in range(1, n + 1):
+            s = n - deg
             d = np.zeros((h, deg + 1))
             for k in range(deg + 1):
                 factor = 1.0
                 for i in range(1, s + 1):
                     factor *= float(k + i)
                 d[:, k] = p[:, k + s] * factor
-            cur = np.zeros((h, 10))
+            cur = np.zeros((h, n))
             ncur = np.zeros(h, dtype=np.int64)
             for j in range(deg):  # at most deg intervals (nprev <= deg - 1)
                 active = j <= nprev
                 lo = -rng if j == 0 else np.where(active, prev[:, j - 1], 0.0)
-                hi = np.where(j == nprev, rng, prev[:, min(j, 9)])
+                hi = np.where(j == nprev, rng, prev[:, min(j, n - 1)])
                 flo = _horner(d, deg, lo)
                 fhi = _horner(d, deg, hi)
                 has = active & ((flo < 0) != (fhi < 0))
@@ -326,6 +327,10 @@ def real_roots_deg10(p: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         return prev, nprev
 
 
+def real_roots_deg10(p: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    return real_roots(p, 10)
+
+
 def five_point_models(x1: np.ndarray, x2: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """x1, x2 [H,5,2] normalised coordinates -> (E [H,10,3,3], count [H]): all real solutions with x2^T E x1 = 0."""
     h = x1.shape[0]
@@ -339,7 +344,7 @@ def five_point_models(x1: np.ndarray, x2: np.ndarray) -> Tuple[np.ndarray, np.nd
         basis = _null_space(q)
         tail = _gauss_jordan_10x20(_constraints(basis))
         p1, p2, p3, det = _hidden_variable(tail)
-        roots, count = real_roots_deg10(det)
+        roots, count = real_roots(det, 10)
         models = np.full((h, 10, 3, 3), np.nan)
         for r in range(10):
             z = roots[:, r]
@@ -367,15 +372,63 @@ def sampson_sq(e: np.ndarray, x1: np.ndarray, x2: np.ndarray) -> np.ndarray:
         return (r * r) / den
 
 
+def seven_point_models(x1: np.ndarray, x2: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """x1, x2 [H,7,2] pixel coordinates -> (F [H,3,3,3], count [H]): the real solutions of det(x F1 + F2) = 0 on the
+    two-dimensional null space of the 7x9 epipolar system (Hartley & Zisserman, Multiple View Geometry, algorithm 11.x "7-point";
+    what ``cv2.findFundamentalMat(FM_RANSAC)`` draws its hypotheses from, ``ransac.py:103-110``)."""
+    h = x1.shape[0]
+    with np.errstate(all="ignore"):
+        q = np.empty((h, 7, 9))
+        a, b = x1[:, :, 0], x1[:, :, 1]
+        c, d = x2[:, :, 0], x2[:, :, 1]
+        q[:, :, 0], q[:, :, 1], q[:, :, 2] = c * a, c * b, c
+        q[:, :, 3], q[:, :, 4], q[:, :, 5] = d * a, d * b, d
+        q[:, :, 6], q[:, :, 7], q[:, :, 8] = a, b, 1.0
+        basis = _null_space(q)  # [H,2,9]
+        e = [[np.stack([basis[:, 1, 3 * i + j], basis[:, 0, 3 * i + j]], axis=1) for j in range(3)] for i in range(3)]  # F2 + x F1
+        c0 = _poly_mul(e[1][1], e[2][2]) - _poly_mul(e[1][2], e[2][1])
+        c1 = _poly_mul(e[1][2], e[2][0]) - _poly_mul(e[1][0], e[2][2])
+        c2 = _poly_mul(e[1][0], e[2][1]) - _poly_mul(e[1][1], e[2][0])
+        det = (_poly_mul(e[0][0], c0) + _poly_mul(e[0][1], c1)) + _poly_mul(e[0][2], c2)  # degree 3
+        roots, count = real_roots(det, 3)
+        models = np.full((h, 3, 3, 3), np.nan)
+        for r in range(3):
+            x = roots[:, r]
+            f = x[:, None] * basis[:, 0] + basis[:, 1]
+            models[:, r] = np.where((r < count)[:, None, None], f.reshape(h, 3, 3), np.nan)
+        return models, count
+
+
+def epipolar_distance_sq_max(f: np.ndarray, x1: np.ndarray, x2: np.ndarray) -> np.ndarray:
+    """The residual of OpenCV's fundamental-matrix RANSAC: the larger of the two squared point-to-epipolar-line distances
+    (calib3d/src/fundam.cpp, FMEstimatorCallback::computeError). f [...,3,3], x1, x2 [M,2] pixels -> [..., M]."""
+    with np.errstate(all="ignore"):
+        a, b = x1[:, 0], x1[:, 1]
+        c, d = x2[:, 0], x2[:, 1]
+        g = lambda i, j: f[..., i, j][..., None]  # noqa: E731
+        l2x = (g(0, 0) * a + g(0, 1) * b) + g(0, 2)
+        l2y = (g(1, 0) * a + g(1, 1) * b) + g(1, 2)
+        l2z = (g(2, 0) * a + g(2, 1) * b) + g(2, 2)
+        l1x = (g(0, 0) * c + g(1, 0) * d) + g(2, 0)
+        l1y = (g(0, 1) * c + g(1, 1) * d) + g(2, 1)
+        r = (c * l2x + d * l2y) + l2z
+        d2 = (r * r) / (l2x * l2x + l2y * l2y)
+        d1 = (r * r) / (l1x * l1x + l1y * l1y)
+        return np.where(d1 > d2, d1, d2)
+
+
 def normalize_pinhole(xy: np.ndarray, fx: float, fy: float, cx: float, cy: float) -> np.ndarray:
     """``Cal3Bundler.calibrate`` without distortion (``gtsfm/utils/features.py:41-51``): float64 ((u - cx)/fx, (v - cy)/fy)."""
     xy = np.asarray(xy, dtype=np.float64)
     return np.stack([(xy[:, 0] - cx) / fx, (xy[:, 1] - cy) / fy], axis=1)
 
 
-def _stop_after(rounds_done: int, inliers: int, m: int) -> bool:
+def _stop_after(rounds_done: int, inliers: int, m: int, size: int = 5) -> bool:
     w = float(inliers) / float(m)
-    q = 1.0 - w * w * w * w * w
+    ws = w
+    for _ in range(size - 1):
+        ws = ws * w
+    q = 1.0 - ws
     p256 = q
     for _ in range(8):
         p256 = p256 * p256
@@ -385,58 +438,64 @@ def _stop_after(rounds_done: int, inliers: int, m: int) -> bool:
     return acc <= 1.0 - SUCCESS_PROB
 
 
+def _ransac(x1: np.ndarray, x2: np.ndarray, thr2: float, seed: int, solver, size: int, max_models: int, error) -> Dict[str, object]:
+    m = x1.shape[0]
+    if m < size:
+        return {"model": None, "mask": np.zeros(m, dtype=bool), "hypotheses": 0, "winner": None}
+    best_cost, best_count, best_e, winner = np.inf, 0, None, None
+
+    def one_round(hyp, idx):
+        models, nroots = solver(x1[idx], x2[idx])
+        with np.errstate(all="ignore"):
+            err = error(models, x1, x2)  # [ROUND,max_models,M]
+            inl = err < thr2  # NaN errors are outliers
+            # MSAC cost, summed left to right (np.cumsum accumulates sequentially; np.sum would add pairwise)
+            cost = np.cumsum(np.where(inl, err, thr2), axis=-1)[..., -1]
+        cost = np.where(np.arange(max_models)[None, :] < nroots[:, None], cost, np.inf)  # roots that do not exist
+        flat = cost.reshape(-1)
+        k = int(np.argmin(flat))  # first minimum = smallest (hypothesis, root)
+        return float(flat[k]), inl.reshape(-1, m)[k].copy(), models.reshape(-1, 3, 3)[k].copy(), (int(hyp[k // max_models]), k % max_models)
+
+    done = 0
+    for rnd in range(MAX_ROUNDS):
+        hyp = np.arange(rnd * ROUND, (rnd + 1) * ROUND)
+        cost, inl, model, who = one_round(hyp, sample_indices(seed, hyp, m, size))
+        if cost < best_cost:
+            best_cost, best_count, best_e, winner = cost, int(inl.sum()), model, who
+        done = rnd + 1
+        if best_count > 0 and _stop_after(done, best_count, m, size):
+            break
+    if best_e is None:
+        return {"model": None, "mask": np.zeros(m, dtype=bool), "hypotheses": done * ROUND, "winner": None}
+    with np.errstate(all="ignore"):
+        mask = error(best_e, x1, x2) < thr2
+    hypotheses = done * ROUND
+    inliers = np.flatnonzero(mask)
+    if inliers.shape[0] >= size + 1:
+        # local optimisation, LO-RANSAC's inner sampling with minimal samples: one more round whose samples come from the
+        # inliers of the winner (hypothesis numbers MAX_ROUNDS * ROUND ...), scored on all matches as before
+        hyp = np.arange(MAX_ROUNDS * ROUND, (MAX_ROUNDS + 1) * ROUND)
+        cost, inl, model, who = one_round(hyp, inliers[sample_indices(seed, hyp, inliers.shape[0], size)])
+        if cost < best_cost:
+            best_cost, best_e, winner, mask = cost, model, who, inl
+        hypotheses += ROUND
+    return {"model": best_e, "mask": mask, "hypotheses": hypotheses, "winner": winner, "cost": best_cost}
+
+
 def ransac_essential(x1: np.ndarray, x2: np.ndarray, threshold: float, seed: int = 0) -> Dict[str, object]:
     """x1, x2 [M,2] normalised matched coordinates, threshold in normalised units (px / fx) -> best model.
 
     Returns {"E" [3,3] or None, "mask" [M] bool, "hypotheses" int, "winner" (hypothesis, root)}."""
-    m = x1.shape[0]
-    if m < 5:
-        return {"E": None, "mask": np.zeros(m, dtype=bool), "hypotheses": 0, "winner": None}
-    thr2 = threshold * threshold
-    best_cost, best_count, best_e, winner = np.inf, 0, None, None
-    done = 0
-    for rnd in range(MAX_ROUNDS):
-        hyp = np.arange(rnd * ROUND, (rnd + 1) * ROUND)
-        idx = sample_indices(seed, hyp, m)
-        models, nroots = five_point_models(x1[idx], x2[idx])
-        with np.errstate(all="ignore"):
-            err = sampson_sq(models, x1, x2)  # [ROUND,10,M]
-            inl = err < thr2  # NaN errors are outliers
-            # MSAC cost, summed left to right (np.cumsum accumulates sequentially; np.sum would add pairwise)
-            cost = np.cumsum(np.where(inl, err, thr2), axis=-1)[..., -1]
-        cost = np.where(np.arange(10)[None, :] < nroots[:, None], cost, np.inf)  # roots that do not exist
-        flat = cost.reshape(-1)
-        k = int(np.argmin(flat))  # first minimum = smallest (hypothesis, root)
-        if flat[k] < best_cost:
-            best_cost, best_count = float(flat[k]), int(inl.reshape(-1, m)[k].sum())
-            best_e, winner = models.reshape(-1, 3, 3)[k].copy(), (int(hyp[k // 10]), k % 10)
-        done = rnd + 1
-        if best_count > 0 and _stop_after(done, best_count, m):
-            break
-    if best_e is None:
-        return {"E": None, "mask": np.zeros(m, dtype=bool), "hypotheses": done * ROUND, "winner": None}
-    with np.errstate(all="ignore"):
-        mask = sampson_sq(best_e, x1, x2) < thr2
-    hypotheses = done * ROUND
-    inliers = np.flatnonzero(mask)
-    if inliers.shape[0] >= 6:
-        # local optimisation, LO-RANSAC's inner sampling with minimal samples: one more round whose samples come from the
-        # inliers of the winner (hypothesis numbers MAX_ROUNDS * ROUND ...), scored on all matches as before
-        hyp = np.arange(MAX_ROUNDS * ROUND, (MAX_ROUNDS + 1) * ROUND)
-        idx = inliers[sample_indices(seed, hyp, inliers.shape[0])]
-        models, nroots = five_point_models(x1[idx], x2[idx])
-        with np.errstate(all="ignore"):
-            err = sampson_sq(models, x1, x2)
-            inl = err < thr2
-            cost = np.cumsum(np.where(inl, err, thr2), axis=-1)[..., -1]
-        cost = np.where(np.arange(10)[None, :] < nroots[:, None], cost, np.inf)
-        flat = cost.reshape(-1)
-        k = int(np.argmin(flat))
-        if flat[k] < best_cost:
-            best_cost, best_e, winner = float(flat[k]), models.reshape(-1, 3, 3)[k].copy(), (int(hyp[k // 10]), k % 10)
-            mask = inl.reshape(-1, m)[k].copy()
-        hypotheses += ROUND
-    return {"E": best_e, "mask": mask, "hypotheses": hypotheses, "winner": winner, "cost": best_cost}
+    res = _ransac(x1, x2, threshold * threshold, seed, five_point_models, 5, 10, sampson_sq)
+    res["E"] = res.pop("model")
+    return res
+
+
+def ransac_fundamental(x1: np.ndarray, x2: np.ndarray, threshold_px: float, seed: int = 0) -> Dict[str, object]:
+    """x1, x2 [M,2] matched PIXEL coordinates -> best fundamental matrix ("F"), seven-point samples, OpenCV's residual."""
+    res = _ransac(x1, x2, threshold_px * threshold_px, seed, seven_point_models, 7, 3, epipolar_distance_sq_max)
+    res["F"] = res.pop("model")
+    return res
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -552,28 +611,42 @@ def verify(
     intrinsics_i2: Tuple[float, float, float, float],
     estimation_threshold_px: float,
     seed: int = 0,
+    use_intrinsics_in_verification: bool = True,
 ) -> Dict[str, object]:
-    """The whole of ``OpencvVerifierBase.verify`` with ``use_intrinsics_in_verification=True``
-    (``opencv_verifier_base.py:47-111``). intrinsics = (fx, fy, cx, cy). Returns R, t (None on failure), v_corr_idxs,
-    inlier_ratio, E, mask."""
+    """The whole of ``OpencvVerifierBase.verify`` (``opencv_verifier_base.py:47-111``). intrinsics = (fx, fy, cx, cy).
+    ``use_intrinsics_in_verification``: essential matrix on normalised coordinates with threshold px / max(fx) (:74-90), else
+    fundamental matrix on pixel coordinates and E = K2^T F K1 (:91-97, ``verification.py:99-112``). Returns R, t (None on
+    failure), v_corr_idxs, inlier_ratio, E, mask."""
     match_indices = np.asarray(match_indices)
     failure = {"R": None, "t": None, "v_corr_idxs": np.array([], dtype=np.uint64), "inlier_ratio": 0.0, "E": None,
                "mask": np.zeros(match_indices.shape[0] if match_indices.ndim == 2 else 0, dtype=bool), "hypotheses": 0}
-    if match_indices.ndim != 2 or match_indices.shape[0] < 6:  # NUM_MATCHES_REQ_E_MATRIX = 5 and the "< 6" guard at :79
+    need = 6 if use_intrinsics_in_verification else 8  # NUM_MATCHES_REQ_E_MATRIX = 5 plus the "< 6" guard at :79; NUM_MATCHES_REQ_F_MATRIX = 8
+    if match_indices.ndim != 2 or match_indices.shape[0] < need:
         return failure
     n1 = normalize_pinhole(coords_i1, *intrinsics_i1)
     n2 = normalize_pinhole(coords_i2, *intrinsics_i2)
     x1 = n1[match_indices[:, 0].astype(np.int64)]
     x2 = n2[match_indices[:, 1].astype(np.int64)]
-    fx = max(intrinsics_i1[0], intrinsics_i2[0])
-    res = ransac_essential(x1, x2, estimation_threshold_px / fx, seed)
-    if res["E"] is None:
+    if use_intrinsics_in_verification:
+        fx = max(intrinsics_i1[0], intrinsics_i2[0])
+        res = ransac_essential(x1, x2, estimation_threshold_px / fx, seed)
+        essential = res["E"]
+    else:
+        p1 = np.asarray(coords_i1, dtype=np.float64)[match_indices[:, 0].astype(np.int64)]
+        p2 = np.asarray(coords_i2, dtype=np.float64)[match_indices[:, 1].astype(np.int64)]
+        res = ransac_fundamental(p1, p2, estimation_threshold_px, seed)
+        essential = None
+        if res["F"] is not None:
+            k1 = np.array([[intrinsics_i1[0], 0.0, intrinsics_i1[2]], [0.0, intrinsics_i1[1], intrinsics_i1[3]], [0.0, 0.0, 1.0]])
+            k2 = np.array([[intrinsics_i2[0], 0.0, intrinsics_i2[2]], [0.0, intrinsics_i2[1], intrinsics_i2[3]], [0.0, 0.0, 1.0]])
+            essential = _mat3(_mat3(k2.T, res["F"]), k1)
+    if essential is None:
         failure["hypotheses"] = res["hypotheses"]
         return failure
     mask = res["mask"]
     if not mask.any():
         failure["hypotheses"] = res["hypotheses"]
         return failure
-    r, t, good = recover_pose(res["E"], x1[mask], x2[mask])
-    return {"R": r, "t": t, "v_corr_idxs": match_indices[mask], "inlier_ratio": float(mask.mean()), "E": res["E"],
-            "mask": mask, "hypotheses": res["hypotheses"], "cheirality": good, "winner": res["winner"]}
+    r, t, good = recover_pose(essential, x1[mask], x2[mask])
+    return {"R": r, "t": t, "v_corr_idxs": match_indices[mask], "inlier_ratio": float(mask.mean()), "E": essential,
+            "F": res.get("F"), "mask": mask, "hypotheses": res["hypotheses"], "cheirality": good, "winner": res["winner"]}

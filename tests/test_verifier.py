@@ -115,6 +115,45 @@ def test_ransac_recovers_planted_geometry(m, outliers, noise, thr):
     assert res["inlier_ratio"] == res["mask"].mean()
 
 
+def test_seven_point_solutions_and_the_fundamental_mode():
+    """Seven-point solver: every solution is singular and satisfies the epipolar constraint on its sample; the planted F is
+    among them. Fundamental-mode RANSAC on pixel coordinates recovers the planted geometry through E = K2^T F K1."""
+    s = synthetic.synthetic_two_view_matches(200, seed=1)
+    p1 = s["coordinates_i1"].astype(np.float64)[s["match_indices"][:, 0]]
+    p2 = s["coordinates_i2"].astype(np.float64)[s["match_indices"][:, 1]]
+    idx = vo.sample_indices(0, np.arange(128), 200, 7)
+    assert idx.shape == (128, 7) and all(len(set(r)) == 7 for r in idx.tolist())
+    models, count = vo.seven_point_models(p1[idx], p2[idx])
+    fx, fy, cx, cy = s["intrinsics"]
+    k_inv = np.linalg.inv(np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]]))
+    t = s["i2Ui1"]
+    f_true = k_inv.T @ (np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ s["i2Ri1"]) @ k_inv
+    f_true /= np.linalg.norm(f_true)
+    found = []
+    for h in range(128):
+        assert 1 <= count[h] <= 3
+        closest = np.inf
+        for r in range(count[h]):
+            f = models[h, r] / np.linalg.norm(models[h, r])
+            assert abs(np.linalg.det(f)) < 1e-9
+            for k in idx[h]:
+                assert abs(np.array([*p2[k], 1.0]) @ f @ np.array([*p1[k], 1.0])) < 1e-7
+            closest = min(closest, np.abs(f - f_true).max(), np.abs(f + f_true).max())
+        found.append(closest)
+    assert np.median(found) < 1e-6  # pixel coordinates rounded to float32 (3e-5 px) bound this, not the solver
+    err = vo.epipolar_distance_sq_max(f_true, p1, p2)
+    assert err.max() < 1e-6  # squared pixels: the planted F explains the float32-rounded projections
+    for m, outliers, noise, thr in ((100, 0.0, 0.0, 0.5), (300, 0.5, 0.5, 2.0)):
+        s = synthetic.synthetic_two_view_matches(m, outliers, noise, seed=4, num_extra_keypoints=20)
+        res = vo.verify(s["coordinates_i1"], s["coordinates_i2"], s["match_indices"], s["intrinsics"], s["intrinsics"], thr, seed=2,
+                        use_intrinsics_in_verification=False)
+        assert (res["mask"] & s["is_inlier"]).sum() >= 0.9 * s["is_inlier"].sum() and (res["mask"] & ~s["is_inlier"]).sum() <= 0.05 * m
+        assert _angle(res["R"], s["i2Ri1"]) < 2.0 and res["F"].shape == (3, 3)
+    short = vo.verify(s["coordinates_i1"], s["coordinates_i2"], s["match_indices"][:7], s["intrinsics"], s["intrinsics"], 2.0,
+                      use_intrinsics_in_verification=False)
+    assert short["R"] is None and short["v_corr_idxs"].size == 0  # fewer than NUM_MATCHES_REQ_F_MATRIX = 8
+
+
 def test_reference_contract_suite_on_the_oracle():
     """two-plane scene: pose within 2 degrees and every match verified (test_verifier_base.py:80-99); fewer than six
     matches / empty input: the failure tuple (:117-135, opencv_verifier_base.py:71-80)."""
@@ -122,22 +161,23 @@ def test_reference_contract_suite_on_the_oracle():
 
     uv1, uv2, rot, direction = _two_planes_scene(4, 4)
     matches = np.stack([np.arange(8), np.arange(8)], 1)
-    res = vo.verify(uv1, uv2, matches, (1, 1, 0, 0), (1, 1, 0, 0), 0.5)
-    assert _angle(res["R"], rot) < 2 and np.degrees(np.arccos(np.clip(res["t"] @ direction, -1, 1))) < 2
-    np.testing.assert_array_equal(res["v_corr_idxs"], matches)
+    for use_intrinsics in (True, False):  # TestRansacForEssentialMatrix / TestRansacForFundamentalMatrix (test_ransac.py:12-31)
+        res = vo.verify(uv1, uv2, matches, (1, 1, 0, 0), (1, 1, 0, 0), 0.5, use_intrinsics_in_verification=use_intrinsics)
+        assert _angle(res["R"], rot) < 2 and np.degrees(np.arccos(np.clip(res["t"] @ direction, -1, 1))) < 2
+        np.testing.assert_array_equal(res["v_corr_idxs"], matches)
     for bad in (np.zeros((0, 2), dtype=np.int32), np.array([], dtype=np.int32), matches[:5]):
         fail = vo.verify(uv1, uv2, bad, (1, 1, 0, 0), (1, 1, 0, 0), 0.5)
         assert fail["R"] is None and fail["t"] is None and fail["v_corr_idxs"].size == 0 and fail["inlier_ratio"] == 0.0
 
 
-def test_plugin_constructs_pickles_and_refuses_what_it_does_not_do():
+def test_plugin_constructs_pickles_and_returns_the_failure_tuple_early():
     from gtsfm_amd.common.calibration import PinholeIntrinsics, pinhole_parameters
     from gtsfm_amd.frontend.verifier.ransac import Ransac
 
     v = pickle.loads(pickle.dumps(Ransac(use_intrinsics_in_verification=True, estimation_threshold_px=4)))
     assert repr(v) == "Ransac__use_intrinsicsTrue_4px"  # verifier_base.py:37-41: the cache / report key of the reference
-    with pytest.raises(ValueError):
-        Ransac(use_intrinsics_in_verification=False, estimation_threshold_px=4)
+    f_mode = Ransac(use_intrinsics_in_verification=False, estimation_threshold_px=4)
+    assert repr(f_mode) == "Ransac__use_intrinsicsFalse_4px" and f_mode._min_matches == 8  # NUM_MATCHES_REQ_F_MATRIX
     assert pinhole_parameters(PinholeIntrinsics(500.0, 320.0, 240.0)) == (500.0, 500.0, 320.0, 240.0, True)
 
     class Distorted(PinholeIntrinsics):

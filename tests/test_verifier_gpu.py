@@ -74,6 +74,27 @@ def test_batch_of_scenes_equals_oracle_and_single_calls(gpu_device):
             assert torch.equal(single["mask"], out["mask"][moff[p] : moff[p + 1]])
 
 
+def test_fundamental_mode_equals_oracle(gpu_device):
+    """use_intrinsics_in_verification=False: seven-point samples on pixel coordinates, OpenCV's point-to-line residual,
+    E = K2^T F K1 -- same bit-for-bit criteria as the essential mode."""
+    from gtsfm_amd.runtime.verifier_engine import VerifierEngine
+
+    engine = VerifierEngine(gpu_device)
+    scenes = [synthetic.synthetic_two_view_matches(m, o, n, seed=40 + k, num_extra_keypoints=x, fx=700.0 + 30 * k) for k, (m, o, n, _, x) in enumerate(SCENES)]
+    scenes.append(synthetic.synthetic_two_view_matches(7, seed=3))  # fewer than NUM_MATCHES_REQ_F_MATRIX
+    seeds = [5 + 11 * k for k in range(len(scenes))]
+    kp, off1, off2, mi, moff, intr = _batch(scenes, gpu_device)
+    out = engine.verify_batch(kp, off1, off2, mi, moff, intr, 2.0, seeds, use_intrinsics=False)
+    for p, s in enumerate(scenes):
+        ref = vo.verify(s["coordinates_i1"], s["coordinates_i2"], s["match_indices"], s["intrinsics"], s["intrinsics"], 2.0, seed=seeds[p],
+                        use_intrinsics_in_verification=False)
+        if ref["R"] is None:
+            assert out["stats"][p, 0].item() == 0 and torch.isnan(out["F"][p]).all()
+            continue
+        _compare(out, p, moff[p], moff[p + 1], ref)
+        np.testing.assert_allclose(out["F"][p].cpu().numpy(), ref["F"], rtol=0, atol=1e-9 * np.abs(ref["F"]).max())
+
+
 @pytest.mark.parametrize("m,outliers,noise,thr,extra", SCENES[2:5])
 def test_recovers_the_planted_geometry(gpu_device, m, outliers, noise, thr, extra):
     from gtsfm_amd.runtime.verifier_engine import VerifierEngine
@@ -132,16 +153,18 @@ def test_plugin_contract_of_the_reference_verifier_suite(gpu_device):
     from gtsfm_amd.common.keypoints import Keypoints
     from gtsfm_amd.frontend.verifier.ransac import Ransac
 
-    verifier = Ransac(use_intrinsics_in_verification=True, estimation_threshold_px=0.5)
-    pickle.loads(pickle.dumps(verifier))  # test_pickleable
     uv1, uv2, rot, direction = _two_planes_scene(4, 4)
     matches = np.stack([np.arange(8), np.arange(8)], 1)
-    r, u, verified, ratio = verifier.verify(Keypoints(uv1), Keypoints(uv2), matches, PinholeIntrinsics(), PinholeIntrinsics())  # two_plane_scene
-    r, u = np.asarray(getattr(r, "matrix", lambda: r)()), np.asarray(getattr(u, "point3", lambda: u)())
-    assert np.degrees(np.arccos(np.clip((np.trace(r.T @ rot) - 1) / 2, -1, 1))) < 2
-    assert np.degrees(np.arccos(np.clip(u @ direction, -1, 1))) < 2
-    np.testing.assert_array_equal(verified, matches)
-    assert ratio == 1.0
+    for use_intrinsics in (True, False):  # TestRansacForEssentialMatrix, TestRansacForFundamentalMatrix (test_ransac.py:12-31)
+        verifier = Ransac(use_intrinsics_in_verification=use_intrinsics, estimation_threshold_px=0.5)
+        pickle.loads(pickle.dumps(verifier))  # test_pickleable
+        r, u, verified, ratio = verifier.verify(Keypoints(uv1), Keypoints(uv2), matches, PinholeIntrinsics(), PinholeIntrinsics())  # two_plane_scene
+        r, u = np.asarray(getattr(r, "matrix", lambda: r)()), np.asarray(getattr(u, "point3", lambda: u)())
+        assert np.degrees(np.arccos(np.clip((np.trace(r.T @ rot) - 1) / 2, -1, 1))) < 2
+        assert np.degrees(np.arccos(np.clip(u @ direction, -1, 1))) < 2
+        np.testing.assert_array_equal(verified, matches)
+        assert ratio == 1.0
+    verifier = Ransac(use_intrinsics_in_verification=True, estimation_threshold_px=0.5)
     r, u, verified, ratio = verifier.verify(Keypoints(uv1), Keypoints(uv2), np.array([], dtype=np.int32), PinholeIntrinsics(), PinholeIntrinsics())
     assert r is None and u is None and verified.size == 0 and ratio == 0.0  # test_verify_empty_matches
     rng = np.random.default_rng(15)
