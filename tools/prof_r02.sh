@@ -7,6 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lg -o lg -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --streams 1 --graphs 0 --no-cpu-baseline --no-secondary > $OUT/lg.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sg -o sg -- python $GRAFT_REPO_ROOT/bench.py --matcher superglue --sinkhorn 100 --pairs 256 --steps 1 --warmup 1 --streams 1 --graphs 0 --no-cpu-baseline --no-secondary > $OUT/sg.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vf -o vf -- python $GRAFT_REPO_ROOT/tools/prof_verifier.py > $OUT/vf.log 2>&1
 find $OUT -name "*kernel_trace.csv" -delete
 for W in "attention" "gemm 256 768" "gemm 512 512" "gemm 512 256" "sinkhorn"; do
   TAG=$(echo $W | tr ' ' '_')
@@ -32,5 +33,5 @@ for tag, ks in summary.items():
     for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["avg"])[:4]:
         print(tag, k[:50], v["dispatches"], round(v["avg"]))
 PY
-for f in $OUT/lg/*/*_kernel_stats.csv $OUT/lg/*_kernel_stats.csv $OUT/sg/*/*_kernel_stats.csv $OUT/sg/*_kernel_stats.csv; do [ -f $f ] && { echo "== $f"; head -12 $f | cut -c1-150; }; done
+for f in $OUT/lg/*/*_kernel_stats.csv $OUT/lg/*_kernel_stats.csv $OUT/sg/*/*_kernel_stats.csv $OUT/sg/*_kernel_stats.csv $OUT/vf/*/*_kernel_stats.csv $OUT/vf/*_kernel_stats.csv; do [ -f $f ] && { echo "== $f"; head -12 $f | cut -c1-150; }; done
 rm -rf $OUT/pmc_*_*SIZE
