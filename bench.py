@@ -76,6 +76,13 @@ def matcher_flops(matcher: str, n: int, layers: float, sinkhorn: int) -> float:
     return layers * 2 * (2490368 * n + 1792 * n * n) + 262144 * n + 512 * n * n
 
 
+def first_block_flops(matcher: str, n: int) -> float:
+    """Dense FLOP of the block of the first matcher layer that sees ONE image (N keypoints): SuperGlue's keypoint encoder
+    (217 280 N) + one GNN layer (1 310 720 N + 1024 N^2); LightGlue's first self block (Wqkv, out_proj, FFN: 1 310 720 N;
+    self-attention 1024 N^2). With --share-first-layer it is counted once per image instead of twice per pair."""
+    return (217280 * n if matcher == "superglue" else 0) + 1310720 * n + 1024 * n * n
+
+
 def pmc_traffic(kernel: str):
     """HBM bytes per launch measured with rocprofv3 PMC passes and committed under profiles/ (bench.py cannot collect
     counters itself); None when no file holds the kernel."""
@@ -340,6 +347,9 @@ def parse_args(argv=None):
     ap.add_argument("--pair-chunk", type=int, default=32)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the pair chunks alternate over")
     ap.add_argument("--graphs", type=int, default=1, help="1: full pair chunks replay a captured hipGraph of the matcher's launch sequence")
+    ap.add_argument("--share-first-layer", type=int, default=1,
+                    help="1: the matcher block that sees one image (SuperGlue: keypoint encoder + first self layer; LightGlue: first self block) "
+                         "runs once per image per step when the pair list reuses images; 0: once per pair side, as the per-pair plugin API does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates (cap 5000; independent pairs)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help='"nccl" = RCCL; "gloo" only with --plumbing-only')
@@ -451,7 +461,7 @@ def main() -> None:
             blob = matcher.weights if rank == 0 else None
             matcher.weights = parallel.broadcast_packed_weights(blob, matcher.weights.numel(), device)
         pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams,
-                                use_graphs=bool(args.graphs))
+                                use_graphs=bool(args.graphs), share_first_layer=bool(args.share_first_layer))
     have_matcher = args.matcher != "none"
     mk = {"sinkhorn_iterations": args.sinkhorn} if (args.matcher == "superglue" and not plumbing) else {}
 
@@ -537,6 +547,9 @@ def main() -> None:
         flops_step = superpoint_flops(h, w) * n_img_total
         if res:
             flops_step += matcher_flops(args.matcher, args.keypoints, layers, args.sinkhorn) * units_per_step
+            shared_images = int(getattr(pipe, "last_shared_images", 0))
+            if shared_images:  # executed work: the per-image block once per image of this rank's table, not twice per pair
+                flops_step -= first_block_flops(args.matcher, args.keypoints) * (2 * len(pairs) - shared_images) * world  # ranks are balanced
         if detect_only:
             workload = f"SuperPoint-only: {n} synthetic {h}x{w} gray images per GPU per step"
         elif scene:
@@ -582,6 +595,9 @@ def main() -> None:
                 "pair_chunk": args.pair_chunk,
                 "streams": args.streams,
                 "hip_graphs": bool(args.graphs),
+                "first_layer_block_per_image": (f"once per image per step ({int(getattr(pipe, 'last_shared_images', 0))} images) instead of twice per pair; "
+                                                "bit-identical matches (tests/test_matchers_gpu.py)") if getattr(pipe, "last_shared_images", 0)
+                                               else "per pair side (nothing shared)",
             },
             "tflops": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2),
         }
@@ -720,7 +736,8 @@ def secondary_rates(args, detector, matcher, device, h, w, mk):
     # (1) GTSfM's cap: 21 views -> 210 exhaustive pairs, first 200; top-5000 keypoints per image
     views = torch.from_numpy(synthetic.synthetic_overlapping_views(21, h, w, 2000)).to(device)
     pairs = parallel.exhaustive_pairs(21)[:200]
-    pipe = FrontEndPipeline(detector, matcher, max_keypoints=5000, pair_chunk=8, num_streams=args.streams, use_graphs=bool(args.graphs))
+    pipe = FrontEndPipeline(detector, matcher, max_keypoints=5000, pair_chunk=8, num_streams=args.streams, use_graphs=bool(args.graphs),
+                            share_first_layer=bool(args.share_first_layer))
     out["exhaustive_cap5000"] = dict(timed(pipe, views, pairs, [(h, w)] * 21, 2, 1), workload=(
         f"SuperPoint+{args.matcher}: 200 exhaustive pairs of 21 synthetic {h}x{w} views, top-5000 keypoints per image (GTSfM's default cap)"))
     del pipe, views
@@ -730,7 +747,7 @@ def secondary_rates(args, detector, matcher, device, h, w, mk):
     images = base[(5 * torch.arange(2 * p, device=device)) % 46].contiguous()
     pairs = [(2 * q, 2 * q + 1) for q in range(p)]
     pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams,
-                            use_graphs=bool(args.graphs))
+                            use_graphs=bool(args.graphs), share_first_layer=bool(args.share_first_layer))
     out["independent_pairs"] = dict(timed(pipe, images, pairs, [(h, w)] * (2 * p), 1, 1), workload=(
         f"SuperPoint+{args.matcher}: {p} independent pairs = {2 * p} fresh detections of synthetic {h}x{w} views, top-{args.keypoints} keypoints per image"))
     return out

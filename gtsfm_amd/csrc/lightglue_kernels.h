@@ -3,6 +3,7 @@
 
 #include "matcher_kernels.h"
 
+int launch_lg_store_rows(const float* X, int ldx, const SeqDesc* seqs, const int* counts, int nseq, int max_n, float* out, hipStream_t stream);
 int launch_lg_load_inputs(const float* desc, const SeqDesc* seqs, const int* counts, int nseq, int max_n, float* X, int ldx, int* ind,
                           hipStream_t stream);
 int launch_lg_stop_check(const float* conf, const SeqDesc* seqs, int* live, int* final_cnt, int* assign, const int* orig, int* stop_layer,

@@ -21,6 +21,17 @@ __global__ __launch_bounds__(256) void lg_load_inputs_kernel(const float* __rest
     if (lane == 0) ind[sq.row_off + i] = i;
 }
 
+// out[in_off + i][0:256] = X[row_off + i][0:256]: the inverse of lg_load_inputs (x after the first self block, per image)
+__global__ __launch_bounds__(256) void lg_store_rows_kernel(const float* __restrict__ X, int ldx, const SeqDesc* __restrict__ seqs,
+                                                            const int* __restrict__ counts, float* __restrict__ out) {
+    const SeqDesc sq = seqs[blockIdx.y];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= counts[sq.cnt_idx]) return;
+    const int lane = threadIdx.x & 63;
+    *reinterpret_cast<f32x4*>(out + (size_t)(sq.in_off + i) * 256 + lane * 4) =
+        *reinterpret_cast<const f32x4*>(X + (size_t)(sq.row_off + i) * ldx + lane * 4);
+}
+
 // check_if_stop for layer `layer`: ratio of confident points (pruned points count as confident) > depth_confidence.
 // One workgroup per pair. Also maintains the per-layer "assign" counts: the keypoint sets of the pairs that stop at
 // this layer (or at the last layer) get their final / assign counts set and their live counts zeroed.
@@ -147,6 +158,13 @@ int launch_lg_load_inputs(const float* desc, const SeqDesc* seqs, const int* cou
     if (nseq <= 0 || max_n <= 0) return GTSFM_OK;
     hipLaunchKernelGGL(lg_load_inputs_kernel, dim3(ceil_div(max_n, 4), nseq), dim3(256), 0, stream, desc, seqs, counts, X, ldx, ind);
     GTSFM_CHECK_LAUNCH("lg_load_inputs_kernel");
+    return GTSFM_OK;
+}
+
+int launch_lg_store_rows(const float* X, int ldx, const SeqDesc* seqs, const int* counts, int nseq, int max_n, float* out, hipStream_t stream) {
+    if (nseq <= 0 || max_n <= 0) return GTSFM_OK;
+    hipLaunchKernelGGL(lg_store_rows_kernel, dim3(ceil_div(max_n, 4), nseq), dim3(256), 0, stream, X, ldx, seqs, counts, out);
+    GTSFM_CHECK_LAUNCH("lg_store_rows_kernel");
     return GTSFM_OK;
 }
 

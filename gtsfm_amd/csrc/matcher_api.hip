@@ -262,13 +262,19 @@ extern "C" size_t gtsfm_sg_workspace_bytes(int npairs, const int32_t* n0, const 
     return sg_workspace_layout(batch_dims(npairs, n0, n1, 1)).total;
 }
 
-extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_score, int npairs, const int32_t* n0, const int32_t* n1,
-                                const int32_t* desc_dev, const float* kpts_dev, const float* scores_dev, const float* descriptors_dev,
-                                int sinkhorn_iters, float match_threshold, void* workspace_dev, size_t workspace_bytes,
-                                int32_t* matches_dev, float* mscores_dev, float* ot_dev, void* stream_) {
+// phase 0: the whole forward. phase 1: only what depends on ONE image -- keypoint encoder and the first (self) GNN layer --
+// written to x_out_dev [T][256] in the input's row order. phase 2: descriptors_dev holds that result; the encoder and the first
+// layer are skipped. An image that takes part in many pairs runs phase 1 once (FrontEndPipeline); the arithmetic per row is the
+// same in either split, so the results are bit-identical to phase 0.
+static int sg_forward_phased(const float* wts, int num_layers, float bin_score, int npairs, const int32_t* n0, const int32_t* n1,
+                             const int32_t* desc_dev, const float* kpts_dev, const float* scores_dev, const float* descriptors_dev,
+                             int sinkhorn_iters, float match_threshold, void* workspace_dev, size_t workspace_bytes,
+                             int32_t* matches_dev, float* mscores_dev, float* ot_dev, int phase, float* x_out_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    GTSFM_CHECK_ARG(wts && n0 && n1 && desc_dev && kpts_dev && scores_dev && descriptors_dev && workspace_dev && matches_dev && mscores_dev,
-                    "sg_forward: null pointer");
+    GTSFM_CHECK_ARG(wts && n0 && n1 && desc_dev && descriptors_dev && workspace_dev, "sg_forward: null pointer");
+    GTSFM_CHECK_ARG(phase == 1 ? x_out_dev != nullptr : (matches_dev && mscores_dev), "sg_forward: null output");
+    GTSFM_CHECK_ARG(phase == 2 || (kpts_dev && scores_dev), "sg_forward: null keypoints / scores");
+    GTSFM_CHECK_ARG(phase >= 0 && phase <= 2 && (phase == 0 || num_layers >= 1), "sg_forward: bad phase");
     GTSFM_CHECK_ARG(npairs > 0 && num_layers >= 0 && sinkhorn_iters >= 0, "sg_forward: bad arguments");
     const BatchDims d = batch_dims(npairs, n0, n1, 1);
     const SgWorkspace ws = sg_workspace_layout(d);
@@ -311,16 +317,26 @@ extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_scor
         return launch_gemm(g, stream);
     };
 
-    // keypoint encoder (superglue.py:73-82, BatchNorm folded into the convolutions at load time)
-    TRY(launch_sg_encode_input(kpts_dev, scores_dev, seqs, counts, 2 * npairs, d.max_n, enc_in, stream));
-    TRY(gemm(enc_in, 8, 3, 32, ka, 256, 0, nullptr, 0, 1));
-    TRY(gemm(ka, 256, 32, 64, kb, 256, 0, nullptr, 0, 1));
-    TRY(gemm(kb, 256, 64, 128, ka, 256, 0, nullptr, 0, 1));
-    TRY(gemm(ka, 256, 128, 256, kb, 256, 0, nullptr, 0, 1));
-    TRY(gemm(kb, 256, 256, 256, X, 512, 0, descriptors_dev, 256, 0));  // desc + kenc(kpts, scores)
+    auto skip = [&](int N, int K) {
+        const float *w, *b, *raw;
+        cur.linear(N, K, &w, &b, &raw);
+    };
+    if (phase == 2) {  // x after the encoder and the first layer comes in; step over their weights
+        skip(32, 3), skip(64, 32), skip(128, 64), skip(256, 128), skip(256, 256);
+        skip(768, 256), skip(512, 512), skip(256, 512);
+        TRY(launch_copy_rows256(descriptors_dev, 256, X, 512, T, stream));
+    } else {
+        // keypoint encoder (superglue.py:73-82, BatchNorm folded into the convolutions at load time)
+        TRY(launch_sg_encode_input(kpts_dev, scores_dev, seqs, counts, 2 * npairs, d.max_n, enc_in, stream));
+        TRY(gemm(enc_in, 8, 3, 32, ka, 256, 0, nullptr, 0, 1));
+        TRY(gemm(ka, 256, 32, 64, kb, 256, 0, nullptr, 0, 1));
+        TRY(gemm(kb, 256, 64, 128, ka, 256, 0, nullptr, 0, 1));
+        TRY(gemm(ka, 256, 128, 256, kb, 256, 0, nullptr, 0, 1));
+        TRY(gemm(kb, 256, 256, 256, X, 512, 0, descriptors_dev, 256, 0));  // desc + kenc(kpts, scores)
+    }
 
     // attentional GNN (superglue.py:122-138): alternating self / cross layers, both images per launch
-    for (int l = 0; l < num_layers; ++l) {
+    for (int l = (phase == 2 ? 1 : 0); l < (phase == 1 ? 1 : num_layers); ++l) {
         TRY(gemm(X, 512, 256, 768, QKV, 768, 0, nullptr, 0, 0));
         AttnParams ap;
         // the attention output lands in the second half of cat([x, .]); attn.merge is folded into mlp.0 at load time
@@ -329,6 +345,10 @@ extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_scor
         TRY(launch_attention(ap, 2 * npairs, d.max_n, stream));
         TRY(gemm(X, 512, 512, 512, MLP, 512, 0, nullptr, 0, 1));       // mlp.0 (+BN, merge folded) + ReLU
         TRY(gemm(MLP, 512, 512, 256, X, 512, 0, X, 512, 0));           // mlp.3, desc += delta
+    }
+    if (phase == 1) {
+        TRY(launch_copy_rows256(X, 512, x_out_dev, 256, T, stream));
+        return GTSFM_OK;
     }
     TRY(gemm(X, 512, 256, 256, MD, 256, 0, nullptr, 0, 0));  // final_proj
 
@@ -366,6 +386,22 @@ extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_scor
     TRY(launch_extract_matches(sa, 1, nullptr, match_threshold, max0, idx0, idx1, matches_dev, mscores_dev, stream));
     if (ot_dev) TRY(launch_materialize_assignment(sa, 1, nullptr, ot_dev, stream));
     return GTSFM_OK;
+}
+
+extern "C" int gtsfm_sg_forward(const float* wts, int num_layers, float bin_score, int npairs, const int32_t* n0, const int32_t* n1,
+                                const int32_t* desc_dev, const float* kpts_dev, const float* scores_dev, const float* descriptors_dev,
+                                int sinkhorn_iters, float match_threshold, void* workspace_dev, size_t workspace_bytes,
+                                int32_t* matches_dev, float* mscores_dev, float* ot_dev, void* stream_) {
+    return sg_forward_phased(wts, num_layers, bin_score, npairs, n0, n1, desc_dev, kpts_dev, scores_dev, descriptors_dev, sinkhorn_iters,
+                             match_threshold, workspace_dev, workspace_bytes, matches_dev, mscores_dev, ot_dev, 0, nullptr, stream_);
+}
+
+extern "C" int gtsfm_sg_forward_phase(const float* wts, int num_layers, float bin_score, int npairs, const int32_t* n0, const int32_t* n1,
+                                      const int32_t* desc_dev, const float* kpts_dev, const float* scores_dev, const float* descriptors_dev,
+                                      int sinkhorn_iters, float match_threshold, void* workspace_dev, size_t workspace_bytes,
+                                      int32_t* matches_dev, float* mscores_dev, float* ot_dev, int phase, float* x_out_dev, void* stream_) {
+    return sg_forward_phased(wts, num_layers, bin_score, npairs, n0, n1, desc_dev, kpts_dev, scores_dev, descriptors_dev, sinkhorn_iters,
+                             match_threshold, workspace_dev, workspace_bytes, matches_dev, mscores_dev, ot_dev, phase, x_out_dev, stream_);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -507,14 +543,16 @@ extern "C" size_t gtsfm_lg_workspace_bytes(int npairs, const int32_t* n0, const 
     return lg_workspace_layout(lg_dims(npairs, n0, n1)).total;
 }
 
-extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* match_bias_host, const float* conf_bias_host, int npairs,
-                                const int32_t* n0, const int32_t* n1, int32_t* desc_dev, const float* kpts_dev, const float* descriptors_dev,
-                                float depth_confidence, float width_confidence, float filter_threshold, int pruning_threshold,
-                                void* workspace_dev, size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev,
-                                void* stream_) {
+// Phases as for SuperGlue: 1 = only the first layer's SELF block (the part of LightGlue that sees one image), x to x_out_dev
+// [T][256] in the input's row order; 2 = descriptors_dev holds that x, the first self block is skipped; bit-identical to phase 0.
+static int lg_forward_phased(const float* wts, int num_layers, const float* match_bias_host, const float* conf_bias_host, int npairs,
+                             const int32_t* n0, const int32_t* n1, int32_t* desc_dev, const float* kpts_dev, const float* descriptors_dev,
+                             float depth_confidence, float width_confidence, float filter_threshold, int pruning_threshold,
+                             void* workspace_dev, size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev,
+                             int phase, float* x_out_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    GTSFM_CHECK_ARG(wts && match_bias_host && n0 && n1 && desc_dev && kpts_dev && descriptors_dev && workspace_dev && matches_dev && mscores_dev,
-                    "lg_forward: null pointer");
+    GTSFM_CHECK_ARG(wts && match_bias_host && n0 && n1 && desc_dev && kpts_dev && descriptors_dev && workspace_dev, "lg_forward: null pointer");
+    GTSFM_CHECK_ARG(phase >= 0 && phase <= 2 && (phase == 1 ? x_out_dev != nullptr : (matches_dev && mscores_dev)), "lg_forward: bad phase / null output");
     GTSFM_CHECK_ARG(npairs > 0 && num_layers > 0 && (num_layers == 1 || conf_bias_host), "lg_forward: bad arguments");
     const LgDims d = lg_dims(npairs, n0, n1);
     const LgWorkspace ws = lg_workspace_layout(d);
@@ -610,17 +648,29 @@ extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* m
     TRY(launch_lg_posenc(kpts_dev, seqs, live, nseq, d.max_n, Wr, enc, stream));
 
     for (int l = 0; l < num_layers; ++l) {
-        // self block: Wqkv, rotary on q and k, attention, out_proj, ffn
-        // rotary on q and k: in the Wqkv epilogue of the LDS-DMA GEMM, a kernel of its own otherwise
-        const bool fused_rotary = gemm_uses_dma(256, 256);
-        TRY(gemm(X, 512, 256, 768, QKV, 768, 0, nullptr, 0, 1.0f, live, fused_rotary ? enc : nullptr, 512));
-        if (!fused_rotary) TRY(launch_lg_rotary(QKV, 768, 512, enc, seqs, live, nseq, d.max_n, stream));
         AttnParams ap;
         // the attention context lands in the second half of cat([x, .]); out_proj / to_out are folded into ffn.0 at load time
         ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = X + 256, ap.ldo = 512;
-        ap.problems = self_p, ap.counts = live, ap.scale = 0.125f, ap.heads = 4;
-        TRY(launch_attention(ap, nseq, d.max_n, stream));
-        TRY(ffn(X));
+        ap.counts = live, ap.scale = 0.125f, ap.heads = 4;
+        if (l == 0 && phase == 2) {  // the first self block was run per image (phase 1): step over its weights
+            const float *w, *b, *raw;
+            cur.linear(768, 256, &w, &b, &raw), cur.linear(512, 512, &w, &b, &raw);
+            cur.raw(512), cur.raw(512);
+            cur.linear(256, 512, &w, &b, &raw);
+        } else {
+            // self block: Wqkv, rotary on q and k, attention, out_proj, ffn
+            // rotary on q and k: in the Wqkv epilogue of the LDS-DMA GEMM, a kernel of its own otherwise
+            const bool fused_rotary = gemm_uses_dma(256, 256);
+            TRY(gemm(X, 512, 256, 768, QKV, 768, 0, nullptr, 0, 1.0f, live, fused_rotary ? enc : nullptr, 512));
+            if (!fused_rotary) TRY(launch_lg_rotary(QKV, 768, 512, enc, seqs, live, nseq, d.max_n, stream));
+            ap.problems = self_p;
+            TRY(launch_attention(ap, nseq, d.max_n, stream));
+            TRY(ffn(X));
+        }
+        if (phase == 1) {
+            TRY(launch_lg_store_rows(X, 512, seqs, live, nseq, d.max_n, x_out_dev, stream));
+            return GTSFM_OK;
+        }
         // cross block: shared to_qk | to_v, both directions of the bidirectional attention, to_out, ffn
         TRY(gemm(X, 512, 256, 512, QKV, 768, 0, nullptr, 0, 1.0f, live));
         ap.q = QKV, ap.k = QKV, ap.v = QKV + 256, ap.problems = cross_p;
@@ -685,4 +735,24 @@ extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* m
     TRY(launch_extract_matches(sa, 0, z_logit, filter_threshold, max0, idx0, idx1, m_int, ms_int, stream));
     TRY(launch_lg_scatter_matches(seqs, final_cnt, ind_final, m_int, ms_int, nseq, d.max_n, d.T, matches_dev, mscores_dev, stream));
     return GTSFM_OK;
+}
+
+extern "C" int gtsfm_lg_forward(const float* wts, int num_layers, const float* match_bias_host, const float* conf_bias_host, int npairs,
+                                const int32_t* n0, const int32_t* n1, int32_t* desc_dev, const float* kpts_dev, const float* descriptors_dev,
+                                float depth_confidence, float width_confidence, float filter_threshold, int pruning_threshold,
+                                void* workspace_dev, size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev,
+                                void* stream_) {
+    return lg_forward_phased(wts, num_layers, match_bias_host, conf_bias_host, npairs, n0, n1, desc_dev, kpts_dev, descriptors_dev, depth_confidence,
+                             width_confidence, filter_threshold, pruning_threshold, workspace_dev, workspace_bytes, matches_dev, mscores_dev, sim_dev,
+                             0, nullptr, stream_);
+}
+
+extern "C" int gtsfm_lg_forward_phase(const float* wts, int num_layers, const float* match_bias_host, const float* conf_bias_host, int npairs,
+                                      const int32_t* n0, const int32_t* n1, int32_t* desc_dev, const float* kpts_dev, const float* descriptors_dev,
+                                      float depth_confidence, float width_confidence, float filter_threshold, int pruning_threshold,
+                                      void* workspace_dev, size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev,
+                                      int phase, float* x_out_dev, void* stream_) {
+    return lg_forward_phased(wts, num_layers, match_bias_host, conf_bias_host, npairs, n0, n1, desc_dev, kpts_dev, descriptors_dev, depth_confidence,
+                             width_confidence, filter_threshold, pruning_threshold, workspace_dev, workspace_bytes, matches_dev, mscores_dev, sim_dev,
+                             phase, x_out_dev, stream_);
 }

@@ -47,6 +47,8 @@ __device__ __forceinline__ float assign_value(float z, float a_i, float b_j, flo
 __device__ __forceinline__ float logsigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
 #endif
 
+// dst[r][0:256] = src[r][0:256] for r < rows (row strides lds / ldd floats)
+int launch_copy_rows256(const float* src, int lds, float* dst, int ldd, int rows, hipStream_t stream);
 int launch_sg_encode_input(const float* kpts, const float* scores, const SeqDesc* seqs, const int* counts, int nseq, int max_n,
                            float* enc_in, hipStream_t stream);
 int launch_lg_posenc(const float* kpts, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* Wr, float* enc,

@@ -144,6 +144,18 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x
     if (lane == 0) out[row] = s;
 }
 
+__global__ __launch_bounds__(256) void copy_rows256_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r < rows) *reinterpret_cast<f32x4*>(dst + (size_t)r * ldd + lane * 4) = *reinterpret_cast<const f32x4*>(src + (size_t)r * lds + lane * 4);
+}
+
+int launch_copy_rows256(const float* src, int lds, float* dst, int ldd, int rows, hipStream_t stream) {
+    if (rows <= 0) return GTSFM_OK;
+    hipLaunchKernelGGL(copy_rows256_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, src, lds, dst, ldd, rows);
+    GTSFM_CHECK_LAUNCH("copy_rows256_kernel");
+    return GTSFM_OK;
+}
+
 int launch_sg_encode_input(const float* kpts, const float* scores, const SeqDesc* seqs, const int* counts, int nseq, int max_n,
                            float* enc_in, hipStream_t stream) {
     if (nseq <= 0 || max_n <= 0) return GTSFM_OK;

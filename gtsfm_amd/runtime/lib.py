@@ -81,6 +81,11 @@ SIGNATURES = {
         [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "gtsfm_sg_forward_phase": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    ),
     "gtsfm_prep_rgb_to_gray_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gtsfm_prep_cubic_taps": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gtsfm_prep_resize_cubic_u8": (
@@ -109,6 +114,12 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "gtsfm_lg_forward_phase": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+         C.c_void_p],
     ),
     "gtsfm_sp_select_topk": (
         C.c_int,

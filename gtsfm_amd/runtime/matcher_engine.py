@@ -169,9 +169,11 @@ class SuperGlueEngine(_MatcherBase):
         match_threshold: float = 0.2,
         return_ot: bool = False,
         workspace: Optional[torch.Tensor] = None,
+        first_layer_done: bool = False,
     ) -> Dict[str, torch.Tensor]:
         """Token-major device inputs concatenated as pair0/img0, pair0/img1, pair1/img0, ...: kpts [T,2], scores [T],
-        desc [T,256]; n0/n1 per-pair keypoint counts (all > 0); hw per pair (H0, W0, H1, W1).
+        desc [T,256]; n0/n1 per-pair keypoint counts (all > 0); hw per pair (H0, W0, H1, W1). ``first_layer_done``: desc holds
+        the output of ``prepare_images`` (keypoint encoder + first self layer already applied per image).
         Returns matches [T] int32 (matches0 for img0 rows, matches1 for img1 rows) and mscores [T]."""
         n0 = np.ascontiguousarray(n0, dtype=np.int32)
         n1 = np.ascontiguousarray(n1, dtype=np.int32)
@@ -190,17 +192,48 @@ class SuperGlueEngine(_MatcherBase):
         if return_ot:
             zf = sum((int(a) + 1) * ((int(b) + 1 + 3) // 4 * 4) for a, b in zip(n0, n1))
             ot = torch.empty(zf, dtype=torch.float32, device=self.device)
-        rc = self._lib.gtsfm_sg_forward(
+        rc = self._lib.gtsfm_sg_forward_phase(
             self.weights.data_ptr(), self.num_layers, self.bin_score, p, n0.ctypes.data, n1.ctypes.data, dsc.data_ptr(),
             kpts.data_ptr(), scores.data_ptr(), desc.data_ptr(), int(sinkhorn_iterations), float(match_threshold),
-            ws.data_ptr(), ws.numel(), matches.data_ptr(), mscores.data_ptr(), _lib.ptr(ot),
+            ws.data_ptr(), ws.numel(), matches.data_ptr(), mscores.data_ptr(), _lib.ptr(ot), 2 if first_layer_done else 0, None,
             torch.cuda.current_stream(self.device).cuda_stream,
         )
-        _lib.check(rc, "gtsfm_sg_forward")
+        _lib.check(rc, "gtsfm_sg_forward_phase")
         out = {"matches": matches, "mscores": mscores, "_desc": dsc}
         if return_ot:
             out["ot"] = ot
         return out
+
+    def prepare_images(self, kpts: torch.Tensor, scores: torch.Tensor, desc: torch.Tensor, counts: Sequence[int], shapes: Sequence[Sequence[int]],
+                       workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The part of SuperGlue that sees ONE image -- keypoint encoder and the first (self) GNN layer (superglue.py:243-248 and
+        the first iteration of :126-137) -- for the keypoint sets of `counts` images concatenated in kpts / scores / desc.
+        Returns x [T,256] in the same row order; feed it to ``match_batch(..., first_layer_done=True)`` in place of desc. An image
+        in k pairs then pays for this once instead of k times, with bit-identical matches."""
+        if self.num_layers < 1:
+            raise ValueError("prepare_images needs at least one GNN layer")
+        counts = [int(c) for c in counts]
+        shapes = [tuple(int(v) for v in s) for s in shapes]
+        t = sum(counts)
+        assert kpts.shape == (t, 2) and scores.shape == (t,) and desc.shape == (t, 256) and min(counts) > 0
+        if len(counts) % 2:  # the ABI works on pairs of keypoint sets: run the last image twice
+            last = counts[-1]
+            kpts, scores, desc = torch.cat([kpts, kpts[t - last :]]), torch.cat([scores, scores[t - last :]]), torch.cat([desc, desc[t - last :]])
+            counts, shapes = counts + [last], shapes + [shapes[-1]]
+        n0 = np.ascontiguousarray(counts[0::2], dtype=np.int32)
+        n1 = np.ascontiguousarray(counts[1::2], dtype=np.int32)
+        hw = np.ascontiguousarray([[*shapes[2 * q], *shapes[2 * q + 1]] for q in range(len(n0))], dtype=np.int32)
+        dsc = self._build_desc(True, n0, n1, hw)
+        need = self._lib.gtsfm_sg_workspace_bytes(len(n0), n0.ctypes.data, n1.ctypes.data)
+        ws = workspace if workspace is not None and workspace.numel() >= need else self._get_workspace(need)
+        x = torch.empty((kpts.shape[0], 256), dtype=torch.float32, device=self.device)
+        rc = self._lib.gtsfm_sg_forward_phase(
+            self.weights.data_ptr(), self.num_layers, self.bin_score, len(n0), n0.ctypes.data, n1.ctypes.data, dsc.data_ptr(),
+            kpts.contiguous().data_ptr(), scores.contiguous().data_ptr(), desc.contiguous().data_ptr(), 0, 0.0, ws.data_ptr(), ws.numel(),
+            None, None, None, 1, x.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream,
+        )
+        _lib.check(rc, "gtsfm_sg_forward_phase")
+        return x[:t]
 
     def match_pair(
         self, k0: np.ndarray, s0: np.ndarray, d0: np.ndarray, k1: np.ndarray, s1: np.ndarray, d1: np.ndarray,
@@ -324,8 +357,10 @@ class LightGlueEngine(_MatcherBase):
         pruning_threshold: Optional[int] = LIGHTGLUE_PRUNING_THRESHOLD,
         return_sim: bool = False,
         workspace: Optional[torch.Tensor] = None,
+        first_layer_done: bool = False,
     ) -> Dict[str, torch.Tensor]:
-        """kpts [T,2], desc [T,256] concatenated as pair0/img0, pair0/img1, ...; returns matches [T] int32 in ORIGINAL
+        """kpts [T,2], desc [T,256] concatenated as pair0/img0, pair0/img1, ...; ``first_layer_done``: desc holds the output of
+        ``prepare_images`` (first self block already applied per image). Returns matches [T] int32 in ORIGINAL
         keypoint indices, mscores [T], stop [P] (layers run), kept [2P] (keypoints alive at the final assignment)."""
         n0 = np.ascontiguousarray(n0, dtype=np.int32)
         n1 = np.ascontiguousarray(n1, dtype=np.int32)
@@ -342,14 +377,14 @@ class LightGlueEngine(_MatcherBase):
         sim = None
         if return_sim:
             sim = torch.zeros(sum(int(a) * ((int(b) + 3) // 4 * 4) for a, b in zip(n0, n1)), dtype=torch.float32, device=self.device)
-        rc = self._lib.gtsfm_lg_forward(
+        rc = self._lib.gtsfm_lg_forward_phase(
             self.weights.data_ptr(), self.num_layers, self.match_bias.ctypes.data, self.conf_bias.ctypes.data, p,
             n0.ctypes.data, n1.ctypes.data, dsc.data_ptr(), kpts.data_ptr(), desc.data_ptr(), float(depth_confidence),
             float(width_confidence), float(filter_threshold), NO_PRUNING if pruning_threshold is None else int(pruning_threshold),
-            ws.data_ptr(), ws.numel(), matches.data_ptr(), mscores.data_ptr(), _lib.ptr(sim),
+            ws.data_ptr(), ws.numel(), matches.data_ptr(), mscores.data_ptr(), _lib.ptr(sim), 2 if first_layer_done else 0, None,
             torch.cuda.current_stream(self.device).cuda_stream,
         )
-        _lib.check(rc, "gtsfm_lg_forward")
+        _lib.check(rc, "gtsfm_lg_forward_phase")
         out = {
             "matches": matches, "mscores": mscores,
             "kept": dsc[2 * p : 4 * p],        # final counts section of the descriptor block
@@ -358,6 +393,34 @@ class LightGlueEngine(_MatcherBase):
         if return_sim:
             out["sim"] = sim
         return out
+
+    def prepare_images(self, kpts: torch.Tensor, desc: torch.Tensor, counts: Sequence[int], shapes: Sequence[Sequence[int]],
+                       workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The part of LightGlue that sees ONE image: the first layer's self block (rotary self-attention + FFN) on the keypoint
+        sets of `counts` images concatenated in kpts / desc. Returns x [T,256]; feed it to ``match_batch(..., first_layer_done=True)``
+        in place of desc. Bit-identical matches; an image in k pairs pays for the block once instead of k times."""
+        counts = [int(c) for c in counts]
+        shapes = [tuple(int(v) for v in s) for s in shapes]
+        t = sum(counts)
+        assert kpts.shape == (t, 2) and desc.shape == (t, 256) and min(counts) > 0
+        if len(counts) % 2:  # the ABI works on pairs of keypoint sets: run the last image twice
+            last = counts[-1]
+            kpts, desc = torch.cat([kpts, kpts[t - last :]]), torch.cat([desc, desc[t - last :]])
+            counts, shapes = counts + [last], shapes + [shapes[-1]]
+        n0 = np.ascontiguousarray(counts[0::2], dtype=np.int32)
+        n1 = np.ascontiguousarray(counts[1::2], dtype=np.int32)
+        hw = np.ascontiguousarray([[*shapes[2 * q], *shapes[2 * q + 1]] for q in range(len(n0))], dtype=np.int32)
+        dsc = self._build_desc(False, n0, n1, hw)
+        need = self._lib.gtsfm_lg_workspace_bytes(len(n0), n0.ctypes.data, n1.ctypes.data)
+        ws = workspace if workspace is not None and workspace.numel() >= need else self._get_workspace(need)
+        x = torch.empty((kpts.shape[0], 256), dtype=torch.float32, device=self.device)
+        rc = self._lib.gtsfm_lg_forward_phase(
+            self.weights.data_ptr(), self.num_layers, self.match_bias.ctypes.data, self.conf_bias.ctypes.data, len(n0),
+            n0.ctypes.data, n1.ctypes.data, dsc.data_ptr(), kpts.contiguous().data_ptr(), desc.contiguous().data_ptr(), 0.0, 0.0, 0.0, NO_PRUNING,
+            ws.data_ptr(), ws.numel(), None, None, None, 1, x.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream,
+        )
+        _lib.check(rc, "gtsfm_lg_forward_phase")
+        return x[:t]
 
     def match_pair(
         self, k0: np.ndarray, d0: np.ndarray, k1: np.ndarray, d1: np.ndarray, shape0: Tuple[int, int], shape1: Tuple[int, int],

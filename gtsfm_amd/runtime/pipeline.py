@@ -61,8 +61,12 @@ class _GraphedChunk:
 
 class FrontEndPipeline:
     def __init__(self, detector: SuperPointEngine, matcher, max_keypoints: int = 5000, pair_chunk: int = 32, num_streams: int = 2,
-                 use_graphs: bool = False):
+                 use_graphs: bool = False, share_first_layer: bool = True):
         self.detector = detector
+        # The matchers' first layer begins with a block that sees ONE image (SuperGlue: keypoint encoder + first self layer;
+        # LightGlue: first self block). When the pair list reuses images -- exhaustive or retrieval pairs do -- that block runs
+        # once per image per match() call instead of once per pair side; same arithmetic per row, bit-identical matches.
+        self.share_first_layer = share_first_layer
         self.matcher = matcher
         self.max_keypoints = max_keypoints
         self.pair_chunk = pair_chunk
@@ -100,6 +104,11 @@ class FrontEndPipeline:
             self._streams = [torch.cuda.Stream(device) for _ in range(nstreams)]
             self._stream_ws = [None] * nstreams
         main = torch.cuda.current_stream(device)
+        self.last_shared_images = 0
+        if self.share_first_layer and len(used) and 2 * len(pairs) > len(used) and getattr(self.matcher, "num_layers", 0) >= 1:
+            feats = dict(feats, descriptors=self._first_layer_per_image(feats, used, shapes, counts, full))
+            matcher_kwargs = dict(matcher_kwargs, first_layer_done=True)
+            self.last_shared_images = int(len(used))
         ready = torch.cuda.Event()
         ready.record(main)
         chunks = [list(pairs[c0 : c0 + self.pair_chunk]) for c0 in range(0, len(pairs), self.pair_chunk)]
@@ -133,6 +142,42 @@ class FrontEndPipeline:
             for stream in self._streams[:nstreams]:
                 main.wait_stream(stream)  # the caller's stream sees every chunk's outputs
         return results
+
+    def _first_layer_per_image(self, feats, used, shapes, counts, full) -> torch.Tensor:
+        """x after the matcher's per-image first block for the images in `used`, as a table shaped like feats["descriptors"]
+        (rows of other images keep their descriptors; they are never read). On the caller's stream, 2 * pair_chunk images per
+        launch sequence (the matcher workspace a pair chunk needs anyway)."""
+        table = feats["descriptors"].clone()
+        is_sg = isinstance(self.matcher, SuperGlueEngine)
+        step = 2 * self.pair_chunk
+        for c0 in range(0, len(used), step):
+            ids = [int(i) for i in used[c0 : c0 + step]]
+            idx = torch.tensor(ids, dtype=torch.long, device=table.device)
+            cnt = [int(counts[i]) for i in ids]
+            if min(cnt) == 0:  # an empty keypoint set never reaches the matcher (empty-input early-out): drop it here too
+                keep = [q for q, c in enumerate(cnt) if c > 0]
+                ids, cnt = [ids[q] for q in keep], [cnt[q] for q in keep]
+                if not ids:
+                    continue
+                idx = torch.tensor(ids, dtype=torch.long, device=table.device)
+            hw = [shapes[i] for i in ids]
+            if full:
+                kp = feats["xy"].index_select(0, idx).reshape(-1, 2)
+                de = feats["descriptors"].index_select(0, idx).reshape(-1, 256)
+                sc = feats["scores"].index_select(0, idx).reshape(-1) if is_sg else None
+            else:
+                kp = torch.cat([feats["xy"][i, :c] for i, c in zip(ids, cnt)], 0)
+                de = torch.cat([feats["descriptors"][i, :c] for i, c in zip(ids, cnt)], 0)
+                sc = torch.cat([feats["scores"][i, :c] for i, c in zip(ids, cnt)], 0) if is_sg else None
+            x = self.matcher.prepare_images(kp, sc, de, cnt, hw) if is_sg else self.matcher.prepare_images(kp, de, cnt, hw)
+            if full:
+                table.index_copy_(0, idx, x.reshape(len(ids), -1, 256))
+            else:
+                row = 0
+                for i, c in zip(ids, cnt):
+                    table[i, :c] = x[row : row + c]
+                    row += c
+        return table
 
     def _replay_chunk(self, feats, chunk, k, hw0, matcher_kwargs, si, stream):
         key = (si, len(chunk), k, tuple(hw0), tuple(sorted(matcher_kwargs.items())))

@@ -202,6 +202,17 @@ size_t gtsfm_sinkhorn_workspace_bytes(int npairs, const int32_t* m_host, const i
 int gtsfm_sinkhorn_f32(float* z_dev, int npairs, const int32_t* m_host, const int32_t* n_host, float bin_score, int iters,
                        void* workspace_dev, size_t workspace_bytes, float* u_dev, float* v_dev, void* stream);
 
+/* The same, split at the point where a pair's two images first see each other (for callers that match one image against
+ * many: the per-image part runs once per image instead of once per pair; results are bit-identical to gtsfm_sg_forward).
+ * phase 1: keypoint encoder + the first (self) GNN layer of every keypoint set of the batch (superglue.py:243-248, first
+ * iteration of :126-137) -> x_out_dev [T][256] in the input's row order; matches / scores outputs unused (may be NULL).
+ * phase 2: descriptors_dev holds that x; kpts_dev / scores_dev unused; the rest of the forward. phase 0 = gtsfm_sg_forward. */
+int gtsfm_sg_forward_phase(const float* blob_dev, int num_layers, float bin_score, int npairs, const int32_t* n0_host,
+                           const int32_t* n1_host, const int32_t* desc_dev, const float* kpts_dev, const float* scores_dev,
+                           const float* descriptors_dev, int sinkhorn_iterations, float match_threshold, void* workspace_dev,
+                           size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* ot_dev, int phase, float* x_out_dev,
+                           void* stream);
+
 /* LightGlue(features="superpoint").forward for a batch of pairs.          replaces LG (upstream LightGlue._forward;
  * reference call site gtsfm/frontend/matcher/lightglue_matcher.py:88-110). PARITY UNPINNED: the reference does not
  * vendor LightGlue's source; this follows the published upstream algorithm (see oracle/lightglue_oracle.py).
@@ -218,6 +229,14 @@ int gtsfm_lg_forward(const float* blob_dev, int num_layers, const float* match_b
                      const float* kpts_dev, const float* descriptors_dev, float depth_confidence,
                      float width_confidence, float filter_threshold, int pruning_threshold, void* workspace_dev,
                      size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev, void* stream);
+
+/* LightGlue split the same way: phase 1 = the first layer's SELF block (rotary self-attention + FFN of one image) -> x_out_dev;
+ * phase 2 = descriptors_dev holds that x, the first self block is skipped. Bit-identical to gtsfm_lg_forward (phase 0). */
+int gtsfm_lg_forward_phase(const float* blob_dev, int num_layers, const float* match_bias_host, const float* conf_bias_host,
+                           int npairs, const int32_t* n0_host, const int32_t* n1_host, int32_t* desc_dev, const float* kpts_dev,
+                           const float* descriptors_dev, float depth_confidence, float width_confidence, float filter_threshold,
+                           int pruning_threshold, void* workspace_dev, size_t workspace_bytes, int32_t* matches_dev,
+                           float* mscores_dev, float* sim_dev, int phase, float* x_out_dev, void* stream);
 
 /* ---- verifier stage behind the matcher (float64) ----
  * OpencvVerifierBase.verify with use_intrinsics_in_verification=True for a batch of pairs.
