@@ -621,6 +621,8 @@ def main() -> None:
                 result["roofline_other"] = [r for r in other if r is not None] + [conv_roof]
             if world == 1 and not args.no_secondary and not detect_only and not scene and args.pair_definition == "exhaustive":
                 result["secondary"] = secondary_rates(args, detector, matcher, device, h, w, mk)
+                if getattr(pipe, "last_shared_images", 0):
+                    result["secondary"]["headline_per_pair_first_layer"] = unshared_rate(args, detector, matcher, images, pairs, shapes, mk)
                 result["secondary"]["verifier_stage"] = verifier_rate(pipe, feats, res, h, w, ms_per_step, device, not args.no_cpu_baseline)
             if world == 1 and not args.no_cpu_baseline:  # rank 0 at N = 1 only
                 first = all_pairs[0] if all_pairs else (0, min(1, len(views_np) - 1))
@@ -703,6 +705,26 @@ def verifier_rate(pipe, feats, res, h, w, ms_per_step, device, with_oracle: bool
         out["parity_check"] = {"verified_equal_oracle": same, "pair": [int(i), int(j)], "verified": int(len(ref["v_corr_idxs"]))}
         out["cpu_baseline"] = {"value": round(1.0 / sec, 2), "unit": "image-pairs/s", "cores": 1, "kind": "port", "sample": "the first pair, numpy float64 oracle"}
     return out
+
+
+def unshared_rate(args, detector, matcher, images, pairs, shapes, mk):
+    """The headline workload with every pair running the matcher's full forward (the per-image first block NOT shared between
+    the pairs of an image: what the reference's per-pair match() calls amount to), own timed region, for comparison."""
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+
+    pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams,
+                            use_graphs=bool(args.graphs), share_first_layer=False)
+    steps, warmup = 2, 1
+    for _ in range(warmup):
+        pipe.match(pipe.detect(images), pairs, shapes, **mk)
+    torch.cuda.synchronize(images.device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.match(pipe.detect(images), pairs, shapes, **mk)
+    torch.cuda.synchronize(images.device)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+            "pairs_per_step": len(pairs), "workload": "the headline workload with --share-first-layer 0 (first matcher block once per pair side)"}
 
 
 def secondary_rates(args, detector, matcher, device, h, w, mk):
