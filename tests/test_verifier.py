@@ -154,6 +154,26 @@ def test_seven_point_solutions_and_the_fundamental_mode():
     assert short["R"] is None and short["v_corr_idxs"].size == 0  # fewer than NUM_MATCHES_REQ_F_MATRIX = 8
 
 
+def test_noise_free_winner_equals_the_eight_point_solution():
+    """Independent estimator: on exact correspondences the linear eight-point solution (LAPACK SVD of the 9-column system) and
+    the RANSAC winner -- a five-point solution of some minimal sample -- must be the same essential matrix."""
+    rng = np.random.default_rng(12)
+    pts = np.stack([rng.uniform(-4, 4, 80), rng.uniform(-3, 3, 80), rng.uniform(6, 14, 80)], 1)
+    rot = synthetic._rotation_about(rng.normal(size=3), 0.3)
+    t = rng.normal(size=3)
+    t /= np.linalg.norm(t)
+    p2 = pts @ rot.T + t
+    x1, x2 = pts[:, :2] / pts[:, 2:], p2[:, :2] / p2[:, 2:]
+    res = vo.ransac_essential(x1, x2, 1e-6, seed=3)
+    assert res["mask"].all() and res["hypotheses"] == 512
+    a = np.stack([x2[:, 0] * x1[:, 0], x2[:, 0] * x1[:, 1], x2[:, 0], x2[:, 1] * x1[:, 0], x2[:, 1] * x1[:, 1], x2[:, 1], x1[:, 0], x1[:, 1], np.ones(80)], 1)
+    e8 = np.linalg.svd(a)[2][-1].reshape(3, 3)
+    e5 = res["E"] / np.linalg.norm(res["E"])
+    assert min(np.abs(e5 - e8).max(), np.abs(e5 + e8).max()) < 1e-8
+    r, tt, _ = vo.recover_pose(res["E"], x1, x2)
+    assert np.abs(r - rot).max() < 1e-8 and np.abs(tt - t).max() < 1e-8
+
+
 def test_reference_contract_suite_on_the_oracle():
     """two-plane scene: pose within 2 degrees and every match verified (test_verifier_base.py:80-99); fewer than six
     matches / empty input: the failure tuple (:117-135, opencv_verifier_base.py:71-80)."""
