@@ -27,6 +27,8 @@
 #define VF_JACOBI_SWEEPS 8
 #define VF_DEPTH_LIMIT 50.0
 #define VF_SUCCESS_PROB 0.999999
+#define VF_POLISH_ITERS 6
+#define VF_POLISH_STEP 1.0e-6
 
 __constant__ int VF_LIN_LIN[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
 __constant__ int VF_QUAD_LIN[10][4] = {{0, 2, 4, 5},     {2, 3, 8, 9},     {4, 8, 10, 11},   {5, 9, 11, 12},   {3, 1, 6, 7},
@@ -362,6 +364,7 @@ struct VfShared {
     double pose[2][9];
     double t[3];
     int good[4];
+    double part[256][20];  // polish: per-thread partial sums of J^T J (15) and J^T r (5)
 };
 
 // Cyclic Jacobi eigen-decomposition of a symmetric 3x3 (oracle: _jacobi_eigen_sym3).
@@ -456,6 +459,85 @@ __device__ __forceinline__ bool vf_in_front(const double* r, double t0, double t
     const double l1 = (ab * bt - at * bb) / det;
     const double l2 = (aa * bt - ab * at) / det;
     return l1 > 0 && l2 > 0 && l1 < VF_DEPTH_LIMIT && l2 < VF_DEPTH_LIMIT;
+}
+
+// ---- final polish of the pose (oracle: polish_pose and helpers) ----
+__device__ __forceinline__ void vf_essential_from_pose(const double r[3][3], const double t[3], double e[9]) {
+    const double sk[3][3] = {{0.0, -t[2], t[1]}, {t[2], 0.0, -t[0]}, {-t[1], t[0], 0.0}};
+    double em[3][3];
+    vf_mat3(sk, r, em);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) e[3 * i + j] = em[i][j];
+}
+
+__device__ void vf_tangent_basis(const double t[3], double b1[3], double b2[3]) {
+    int k = 0;
+    for (int i = 1; i < 3; ++i)
+        if (fabs(t[i]) < fabs(t[k])) k = i;
+    double a[3] = {0.0, 0.0, 0.0};
+    a[k] = 1.0;
+    b1[0] = t[1] * a[2] - t[2] * a[1], b1[1] = t[2] * a[0] - t[0] * a[2], b1[2] = t[0] * a[1] - t[1] * a[0];
+    const double n = sqrt((b1[0] * b1[0] + b1[1] * b1[1]) + b1[2] * b1[2]);
+    for (int i = 0; i < 3; ++i) b1[i] = b1[i] / n;
+    b2[0] = t[1] * b1[2] - t[2] * b1[1], b2[1] = t[2] * b1[0] - t[0] * b1[2], b2[2] = t[0] * b1[1] - t[1] * b1[0];
+}
+
+// R <- R cayley(d[0:3]), t <- unit(t + d3 b1 + d4 b2)
+__device__ void vf_perturb_pose(const double r[3][3], const double t[3], const double b1[3], const double b2[3], const double d[5], double rn[3][3],
+                                double tn[3]) {
+    const double wx = 0.5 * d[0], wy = 0.5 * d[1], wz = 0.5 * d[2];
+    const double a[3][3] = {{1.0, wz, -wy}, {-wz, 1.0, wx}, {wy, -wx, 1.0}};
+    const double b[3][3] = {{1.0, -wz, wy}, {wz, 1.0, -wx}, {-wy, wx, 1.0}};
+    double adj[3][3];
+    adj[0][0] = a[1][1] * a[2][2] - a[1][2] * a[2][1], adj[0][1] = a[0][2] * a[2][1] - a[0][1] * a[2][2], adj[0][2] = a[0][1] * a[1][2] - a[0][2] * a[1][1];
+    adj[1][0] = a[1][2] * a[2][0] - a[1][0] * a[2][2], adj[1][1] = a[0][0] * a[2][2] - a[0][2] * a[2][0], adj[1][2] = a[0][2] * a[1][0] - a[0][0] * a[1][2];
+    adj[2][0] = a[1][0] * a[2][1] - a[1][1] * a[2][0], adj[2][1] = a[0][1] * a[2][0] - a[0][0] * a[2][1], adj[2][2] = a[0][0] * a[1][1] - a[0][1] * a[1][0];
+    const double det = (a[0][0] * adj[0][0] + a[0][1] * adj[1][0]) + a[0][2] * adj[2][0];
+    double inv[3][3], q[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) inv[i][j] = adj[i][j] / det;
+    vf_mat3(inv, b, q);
+    vf_mat3(r, q, rn);
+    for (int i = 0; i < 3; ++i) tn[i] = (t[i] + d[3] * b1[i]) + d[4] * b2[i];
+    const double n = sqrt((tn[0] * tn[0] + tn[1] * tn[1]) + tn[2] * tn[2]);
+    for (int i = 0; i < 3; ++i) tn[i] = tn[i] / n;
+}
+
+__device__ __forceinline__ double vf_signed_sampson(const double* e, double a, double b, double c, double d) {
+    const double l2x = (e[0] * a + e[1] * b) + e[2];
+    const double l2y = (e[3] * a + e[4] * b) + e[5];
+    const double l2z = (e[6] * a + e[7] * b) + e[8];
+    const double l1x = (e[0] * c + e[3] * d) + e[6];
+    const double l1y = (e[1] * c + e[4] * d) + e[7];
+    const double r = (c * l2x + d * l2y) + l2z;
+    const double den = ((l2x * l2x + l2y * l2y) + l1x * l1x) + l1y * l1y;
+    return r / sqrt(den);
+}
+
+// h d = -g, Gaussian elimination with row pivoting (oracle: _solve5)
+__device__ void vf_solve5(const double h[5][5], const double g[5], double d[5]) {
+    double a[5][6];
+    for (int i = 0; i < 5; ++i) {
+        for (int j = 0; j < 5; ++j) a[i][j] = h[i][j];
+        a[i][5] = -g[i];
+    }
+    for (int c = 0; c < 5; ++c) {
+        int pr = c;
+        for (int i = c + 1; i < 5; ++i)
+            if (fabs(a[i][c]) > fabs(a[pr][c])) pr = i;
+        for (int j = 0; j < 6; ++j) {
+            const double tmp = a[c][j];
+            a[c][j] = a[pr][j];
+            a[pr][j] = tmp;
+        }
+        for (int j = 5; j >= c; --j) a[c][j] = a[c][j] / a[c][c];
+        for (int i = 0; i < 5; ++i) {
+            if (i == c) continue;
+            const double f = a[i][c];
+            for (int j = c; j < 6; ++j) a[i][j] = a[i][j] - f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 5; ++i) d[i] = a[i][5];
 }
 
 // All real solutions of one minimal sample. MODE 0: five-point essential matrices (<= 10); MODE 1: seven-point fundamental
@@ -680,24 +762,108 @@ __global__ __launch_bounds__(256) void verify_ransac_kernel(const double* __rest
     atomicAdd(&sh.inliers, inl);
     for (int k = 0; k < 4; ++k) atomicAdd(&sh.good[k], good[k]);
     __syncthreads();
-    if (tid == 0) {
-        int pick = 3;
-        for (int k = 0; k < 4; ++k) {
-            bool top = true;
-            for (int j = 0; j < 4; ++j) top &= sh.good[k] >= sh.good[j];
-            if (top) {
-                pick = k;
-                break;
+    int pick = 3;
+    for (int k = 0; k < 4; ++k) {  // cv.recoverPose's order: the first candidate whose count is >= all others
+        bool top = true;
+        for (int j = 0; j < 4; ++j) top &= sh.good[k] >= sh.good[j];
+        if (top) {
+            pick = k;
+            break;
+        }
+    }
+    double rot[3][3], tr[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) rot[i][j] = sh.pose[pick & 1][3 * i + j];
+    for (int k = 0; k < 3; ++k) tr[k] = pick >= 2 ? -sh.t[k] : sh.t[k];
+    int inliers = sh.inliers;
+    const int good0 = sh.good[0], good1 = sh.good[1], good2 = sh.good[2], good3 = sh.good[3];
+
+    if (MODE == 0) {
+        // final polish (oracle: polish_pose): Gauss-Newton on the winner's inliers over (rotation vector, 2 tangent directions of t),
+        // forward-difference Jacobian; every thread carries the same pose, the 20 sums are reduced in a fixed order
+        for (int it = 0; it < VF_POLISH_ITERS; ++it) {
+            double b1[3], b2[3], ev[6][9];
+            vf_tangent_basis(tr, b1, b2);
+            vf_essential_from_pose(rot, tr, ev[0]);
+            for (int k = 0; k < 5; ++k) {
+                double d[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, rk[3][3], tk[3];
+                d[k] = VF_POLISH_STEP;
+                vf_perturb_pose(rot, tr, b1, b2, d, rk, tk);
+                vf_essential_from_pose(rk, tk, ev[k + 1]);
+            }
+            double acc[20];
+            for (int k = 0; k < 20; ++k) acc[k] = 0.0;
+            for (int i = tid; i < m; i += 256) {
+                const double a = P[4 * i], b = P[4 * i + 1], c = P[4 * i + 2], d = P[4 * i + 3];
+                const bool in = vf_sampson_sq(model, a, b, c, d) < thr2;  // the winner's inliers, fixed during the polish
+                const double r0 = vf_signed_sampson(ev[0], a, b, c, d);
+                double col[5];
+                for (int k = 0; k < 5; ++k) col[k] = (vf_signed_sampson(ev[k + 1], a, b, c, d) - r0) / VF_POLISH_STEP;
+                int n = 0;
+                for (int u = 0; u < 5; ++u)
+                    for (int v = u; v < 5; ++v, ++n) acc[n] = acc[n] + (in ? col[u] * col[v] : 0.0);
+                for (int u = 0; u < 5; ++u) acc[15 + u] = acc[15 + u] + (in ? col[u] * r0 : 0.0);
+            }
+            for (int k = 0; k < 20; ++k) sh.part[tid][k] = acc[k];
+            __syncthreads();
+            for (int step = 128; step > 0; step >>= 1) {
+                if (tid < step)
+                    for (int k = 0; k < 20; ++k) sh.part[tid][k] = sh.part[tid][k] + sh.part[tid + step][k];
+                __syncthreads();
+            }
+            double h[5][5], g[5], delta[5];
+            {
+                int n = 0;
+                for (int u = 0; u < 5; ++u)
+                    for (int v = u; v < 5; ++v, ++n) h[u][v] = h[v][u] = sh.part[0][n];
+                for (int u = 0; u < 5; ++u) g[u] = sh.part[0][15 + u];
+            }
+            __syncthreads();  // part[0] is rewritten in the next iteration
+            for (int u = 0; u < 5; ++u) h[u][u] = h[u][u] + 1.0e-12 * (1.0 + h[u][u]);
+            vf_solve5(h, g, delta);
+            double rn[3][3], tn[3];
+            vf_perturb_pose(rot, tr, b1, b2, delta, rn, tn);
+            for (int i = 0; i < 3; ++i) {
+                tr[i] = tn[i];
+                for (int j = 0; j < 3; ++j) rot[i][j] = rn[i][j];
             }
         }
+        double e2[9];
+        vf_essential_from_pose(rot, tr, e2);
+        double cost2 = 0.0;  // MSAC cost over ALL matches, in match order (every thread: same value)
+        for (int i = 0; i < m; ++i) {
+            const double err = vf_sampson_sq(e2, P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]);
+            cost2 = cost2 + (err < thr2 ? err : thr2);
+        }
+        if (cost2 < sh.best_cost) {  // keep the polished pose; the verified set is the one of the polished model
+            for (int k = 0; k < 9; ++k) e[k] = e2[k];
+            if (tid == 0) sh.inliers = 0;
+            __syncthreads();
+            int cnt = 0;
+            for (int i = tid; i < m; i += 256) {
+                const bool in = vf_sampson_sq(e2, P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]) < thr2;
+                mask[i] = in ? 1 : 0;
+                cnt += in ? 1 : 0;
+            }
+            atomicAdd(&sh.inliers, cnt);
+            __syncthreads();
+            inliers = sh.inliers;
+        } else {
+            for (int i = 0; i < 3; ++i) {
+                tr[i] = pick >= 2 ? -sh.t[i] : sh.t[i];
+                for (int j = 0; j < 3; ++j) rot[i][j] = sh.pose[pick & 1][3 * i + j];
+            }
+        }
+    }
+    if (tid == 0) {
         for (int k = 0; k < 9; ++k) {
             out_e[9 * (size_t)pair + k] = e[k];
-            out_r[9 * (size_t)pair + k] = sh.pose[pick & 1][k];
+            out_r[9 * (size_t)pair + k] = rot[k / 3][k % 3];
             if (MODE == 1) out_f[9 * (size_t)pair + k] = model[k];
         }
-        for (int k = 0; k < 3; ++k) out_t[3 * (size_t)pair + k] = pick >= 2 ? -sh.t[k] : sh.t[k];
-        stats[0] = sh.inliers, stats[1] = hypotheses, stats[2] = sh.best_index >> 4, stats[3] = sh.best_index & 15;
-        for (int k = 0; k < 4; ++k) stats[4 + k] = sh.good[k];
+        for (int k = 0; k < 3; ++k) out_t[3 * (size_t)pair + k] = tr[k];
+        stats[0] = inliers, stats[1] = hypotheses, stats[2] = sh.best_index >> 4, stats[3] = sh.best_index & 15;
+        stats[4] = good0, stats[5] = good1, stats[6] = good2, stats[7] = good3;
     }
 }
 

@@ -9,8 +9,8 @@ samples on pixel coordinates, residual = the larger squared point-to-epipolar-li
 container) as a 3x3 and a 3-vector.
 
 Differences, stated rather than hidden: the estimator is five-point RANSAC with a counter-based sampler
-(``gtsfm_verify_essential_f64``; OpenCV's ``USAC_ACCURATE`` adds a graph-cut local optimisation and draws from its own
-generator -- PARITY UNPINNED, ``oracle/verifier_oracle.py``); at most 1024 + 256 hypotheses per pair (OpenCV: 1000 for the
+(``gtsfm_verify_essential_f64``: MSAC scoring, one round of inner sampling, Gauss-Newton polish of the pose; OpenCV's
+``USAC_ACCURATE`` uses a graph-cut local optimisation and draws from its own generator -- PARITY UNPINNED, ``oracle/verifier_oracle.py``); at most 1024 + 256 hypotheses per pair (OpenCV: 1000 for the
 essential matrix, ``RANSAC_MAX_ITERS`` = 10^6 for the fundamental matrix); lens distortion / skew are removed on the host with
 the calibration's own ``calibrate`` before upload (essential mode), pure pinhole models are normalised on the device; the
 fundamental mode uses K() only, as ``fundamental_to_essential_matrix`` does.

@@ -246,7 +246,8 @@ int gtsfm_lg_forward_phase(const float* blob_dev, int num_layers, const float* m
  * PARITY UNPINNED (OpenCV absent, its sampler not reproducible): Nister's five-point solver, squared Sampson error
  * (gtsfm/utils/verification.py:172-220), RANSAC with a counter-based sampler (splitmix64 of seed / hypothesis / attempt),
  * 256 hypotheses per round scored by MSAC, at most 4 rounds, stop when (1 - w^5)^n <= 1e-6, then one round of 256 samples
- * drawn from the winner's inliers (LO-RANSAC inner sampling); see oracle/verifier_oracle.py.
+ * drawn from the winner's inliers (LO-RANSAC inner sampling), cheirality choice, and six Gauss-Newton steps on the inliers'
+ * Sampson error over the pose (kept when the MSAC cost drops); see oracle/verifier_oracle.py.
  * kp_xy_dev [*][2] float32 pixel coordinates of all keypoint tables; pair p uses the tables starting at rows kp_off1_dev[p]
  * (image i1) and kp_off2_dev[p] (image i2). match_idx_dev [total_matches][2] int32 (row in i1's table, row in i2's table),
  * pair p owning rows match_off_dev[p] .. match_off_dev[p+1], or only the first match_count_dev[p] of them when match_count_dev

@@ -30,8 +30,9 @@ another either. What is restated here is the published mathematics --
 SAME minimal samples and are compared bit-for-bit on the inlier masks (``tests/test_verifier_gpu.py``). The anchor towards
 the reference is its own verifier contract suite, ``tests/frontend/verifier/test_verifier_base.py`` (two-plane scene: pose
 within 2 degrees and every match verified; empty input; index validity; pickling), restated in ``tests/test_verifier.py``.
-USAC_ACCURATE's graph-cut local optimisation and its final least-squares polish are NOT restated; the inner-sampling round
-above stands in for them.
+USAC_ACCURATE's graph-cut local optimisation is NOT restated (the inner-sampling round stands in for it); its final polish is
+restated in spirit: six Gauss-Newton steps on the inliers' Sampson error over the five pose parameters (``polish_pose``), kept
+when the MSAC cost over all matches decreases.
 
 Every arithmetic step below is written as an explicit sequence of IEEE double operations (no ``np.dot`` / ``np.sum`` / BLAS,
 no fused multiply-add), vectorised over the hypothesis axis only, so the device code can follow the same sequence."""
@@ -603,6 +604,136 @@ def recover_pose(e: np.ndarray, x1: np.ndarray, x2: np.ndarray) -> Tuple[np.ndar
     raise AssertionError("unreachable")
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# final polish: Gauss-Newton on the squared Sampson error of the inliers, over the pose (what OpenCV's USAC does last)
+POLISH_ITERS = 6
+POLISH_STEP = 1.0e-6
+REDUCE_LANES = 256  # the device sums per thread (i = tid, tid + 256, ...) and then halves the 256 partial sums 8 times
+
+
+def _reduce_like_the_device(c: np.ndarray) -> np.ndarray:
+    """c [M, C] per-match contributions -> [C] totals, added in the order the workgroup adds them."""
+    m = c.shape[0]
+    rows = -(-m // REDUCE_LANES)
+    pad = np.zeros((rows * REDUCE_LANES, c.shape[1]))
+    pad[:m] = c
+    part = np.zeros((REDUCE_LANES, c.shape[1]))
+    for k in range(rows):  # acc = acc + c[tid + 256 k]
+        part = part + pad[k * REDUCE_LANES : (k + 1) * REDUCE_LANES]
+    step = REDUCE_LANES // 2
+    while step > 0:
+        part[:step] = part[:step] + part[step : 2 * step]
+        step //= 2
+    return part[0]
+
+
+def _essential_from_pose(r: np.ndarray, t: np.ndarray) -> np.ndarray:
+    sk = np.array([[0.0, -t[2], t[1]], [t[2], 0.0, -t[0]], [-t[1], t[0], 0.0]])
+    return _mat3(sk, r)
+
+
+def _tangent_basis(t: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    k = 0
+    for i in (1, 2):  # axis of the smallest |t_k|, first minimum
+        if abs(t[i]) < abs(t[k]):
+            k = i
+    a = np.zeros(3)
+    a[k] = 1.0
+    b1 = _cross(t, a)
+    b1 = b1 / np.sqrt((b1[0] * b1[0] + b1[1] * b1[1]) + b1[2] * b1[2])
+    return b1, _cross(t, b1)
+
+
+def _perturb_pose(r: np.ndarray, t: np.ndarray, b1: np.ndarray, b2: np.ndarray, d: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """R <- R cayley(d[0:3]) (a rotation without trigonometry: (I - W/2)^-1 (I + W/2), W = [w]x); t <- unit(t + d3 b1 + d4 b2)."""
+    wx, wy, wz = 0.5 * d[0], 0.5 * d[1], 0.5 * d[2]
+    a = np.array([[1.0, wz, -wy], [-wz, 1.0, wx], [wy, -wx, 1.0]])  # I - W/2
+    b = np.array([[1.0, -wz, wy], [wz, 1.0, -wx], [-wy, wx, 1.0]])  # I + W/2
+    adj = np.array([
+        [a[1, 1] * a[2, 2] - a[1, 2] * a[2, 1], a[0, 2] * a[2, 1] - a[0, 1] * a[2, 2], a[0, 1] * a[1, 2] - a[0, 2] * a[1, 1]],
+        [a[1, 2] * a[2, 0] - a[1, 0] * a[2, 2], a[0, 0] * a[2, 2] - a[0, 2] * a[2, 0], a[0, 2] * a[1, 0] - a[0, 0] * a[1, 2]],
+        [a[1, 0] * a[2, 1] - a[1, 1] * a[2, 0], a[0, 1] * a[2, 0] - a[0, 0] * a[2, 1], a[0, 0] * a[1, 1] - a[0, 1] * a[1, 0]],
+    ])
+    det = (a[0, 0] * adj[0, 0] + a[0, 1] * adj[1, 0]) + a[0, 2] * adj[2, 0]
+    q = _mat3(adj / det, b)
+    tn = np.array([(t[i] + d[3] * b1[i]) + d[4] * b2[i] for i in range(3)])
+    tn = tn / np.sqrt((tn[0] * tn[0] + tn[1] * tn[1]) + tn[2] * tn[2])
+    return _mat3(r, q), tn
+
+
+def _signed_sampson(e: np.ndarray, x1: np.ndarray, x2: np.ndarray) -> np.ndarray:
+    a, b = x1[:, 0], x1[:, 1]
+    c, d = x2[:, 0], x2[:, 1]
+    l2x = (e[0, 0] * a + e[0, 1] * b) + e[0, 2]
+    l2y = (e[1, 0] * a + e[1, 1] * b) + e[1, 2]
+    l2z = (e[2, 0] * a + e[2, 1] * b) + e[2, 2]
+    l1x = (e[0, 0] * c + e[1, 0] * d) + e[2, 0]
+    l1y = (e[0, 1] * c + e[1, 1] * d) + e[2, 1]
+    r = (c * l2x + d * l2y) + l2z
+    den = ((l2x * l2x + l2y * l2y) + l1x * l1x) + l1y * l1y
+    return r / np.sqrt(den)
+
+
+def _solve5(h: np.ndarray, g: np.ndarray) -> np.ndarray:
+    """h d = -g by Gaussian elimination with row pivoting (first maximum)."""
+    a = np.concatenate([h, -g[:, None]], axis=1)
+    for c in range(5):
+        pr = c
+        for i in range(c + 1, 5):
+            if abs(a[i, c]) > abs(a[pr, c]):
+                pr = i
+        a[[c, pr]] = a[[pr, c]]
+        for j in range(5, c - 1, -1):
+            a[c, j] = a[c, j] / a[c, c]
+        for i in range(5):
+            if i != c:
+                f = a[i, c]
+                for j in range(c, 6):
+                    a[i, j] = a[i, j] - f * a[c, j]
+    return a[:, 5].copy()
+
+
+def msac_cost(e: np.ndarray, x1: np.ndarray, x2: np.ndarray, thr2: float) -> float:
+    with np.errstate(all="ignore"):
+        err = sampson_sq(e, x1, x2)
+        return float(np.cumsum(np.where(err < thr2, err, thr2))[-1])
+
+
+def polish_pose(r: np.ndarray, t: np.ndarray, x1: np.ndarray, x2: np.ndarray, mask: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """POLISH_ITERS Gauss-Newton steps on sum over the inliers of the (signed) Sampson distance squared, in the five
+    parameters (rotation vector through the Cayley map, two tangent directions of the unit translation), forward-difference
+    Jacobian."""
+    with np.errstate(all="ignore"):
+        for _ in range(POLISH_ITERS):
+            b1, b2 = _tangent_basis(t)
+            r0 = _signed_sampson(_essential_from_pose(r, t), x1, x2)
+            cols = []
+            for k in range(5):
+                d = np.zeros(5)
+                d[k] = POLISH_STEP
+                rk, tk = _perturb_pose(r, t, b1, b2, d)
+                cols.append((_signed_sampson(_essential_from_pose(rk, tk), x1, x2) - r0) / POLISH_STEP)
+            contrib = []
+            for a in range(5):
+                for b in range(a, 5):
+                    contrib.append(cols[a] * cols[b])
+            for a in range(5):
+                contrib.append(cols[a] * r0)
+            c = np.where(mask[:, None], np.stack(contrib, axis=1), 0.0)
+            tot = _reduce_like_the_device(c)
+            h = np.zeros((5, 5))
+            n = 0
+            for a in range(5):
+                for b in range(a, 5):
+                    h[a, b] = h[b, a] = tot[n]
+                    n += 1
+            g = tot[15:20]
+            for a in range(5):
+                h[a, a] = h[a, a] + 1.0e-12 * (1.0 + h[a, a])
+            r, t = _perturb_pose(r, t, b1, b2, _solve5(h, g))
+    return r, t
+
+
 def verify(
     coords_i1: np.ndarray,
     coords_i2: np.ndarray,
@@ -648,5 +779,14 @@ def verify(
         failure["hypotheses"] = res["hypotheses"]
         return failure
     r, t, good = recover_pose(essential, x1[mask], x2[mask])
+    polished = False
+    if use_intrinsics_in_verification:
+        # final polish of the pose on the winner's inliers; kept only if the MSAC cost over ALL matches goes down
+        thr2 = (estimation_threshold_px / fx) * (estimation_threshold_px / fx)
+        r2, t2 = polish_pose(r, t, x1, x2, mask)
+        e2 = _essential_from_pose(r2, t2)
+        if msac_cost(e2, x1, x2, thr2) < res["cost"]:
+            with np.errstate(all="ignore"):
+                r, t, essential, mask, polished = r2, t2, e2, sampson_sq(e2, x1, x2) < thr2, True
     return {"R": r, "t": t, "v_corr_idxs": match_indices[mask], "inlier_ratio": float(mask.mean()), "E": essential,
-            "F": res.get("F"), "mask": mask, "hypotheses": res["hypotheses"], "cheirality": good, "winner": res["winner"]}
+            "F": res.get("F"), "mask": mask, "hypotheses": res["hypotheses"], "cheirality": good, "winner": res["winner"], "polished": polished}

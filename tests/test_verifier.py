@@ -174,6 +174,26 @@ def test_noise_free_winner_equals_the_eight_point_solution():
     assert np.abs(r - rot).max() < 1e-8 and np.abs(tt - t).max() < 1e-8
 
 
+def test_polish_lowers_the_cost_and_the_pose_error():
+    """Six Gauss-Newton steps on the winner's inliers: the MSAC cost over all matches never goes up (the polished pose is only
+    kept when it goes down), the rotation stays a rotation, and over a dozen noisy scenes the pose error shrinks."""
+    before, after = [], []
+    for seed in range(12):
+        s, n1, n2 = _normalised_scene(250, 0.4, 0.7, seed=seed)
+        thr = 2.0 / s["intrinsics"][0]
+        res = vo.ransac_essential(n1, n2, thr, seed)
+        r, t, _ = vo.recover_pose(res["E"], n1[res["mask"]], n2[res["mask"]])
+        r2, t2 = vo.polish_pose(r, t, n1, n2, res["mask"])
+        assert abs(np.linalg.det(r2) - 1) < 1e-12 and np.abs(r2 @ r2.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.norm(t2) - 1) < 1e-12
+        assert vo.msac_cost(vo._essential_from_pose(r2, t2), n1, n2, thr * thr) < res["cost"]
+        before.append((_angle(r, s["i2Ri1"]), np.degrees(np.arccos(np.clip(t @ s["i2Ui1"], -1, 1)))))
+        after.append((_angle(r2, s["i2Ri1"]), np.degrees(np.arccos(np.clip(t2 @ s["i2Ui1"], -1, 1)))))
+        full = vo.verify(s["coordinates_i1"], s["coordinates_i2"], s["match_indices"], s["intrinsics"], s["intrinsics"], 2.0, seed=seed)
+        assert full["polished"] and np.abs(full["R"] - r2).max() < 1e-12  # verify() keeps the polished pose
+    before, after = np.median(before, axis=0), np.median(after, axis=0)
+    assert after[0] < 0.6 * before[0] and after[1] < before[1], (before, after)  # measured: 0.26 -> 0.10 and 0.57 -> 0.50 degrees
+
+
 def test_reference_contract_suite_on_the_oracle():
     """two-plane scene: pose within 2 degrees and every match verified (test_verifier_base.py:80-99); fewer than six
     matches / empty input: the failure tuple (:117-135, opencv_verifier_base.py:71-80)."""
