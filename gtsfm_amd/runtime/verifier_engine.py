@@ -14,6 +14,7 @@ import torch
 from gtsfm_amd.runtime import lib as _lib
 from gtsfm_amd.runtime.superpoint_engine import require_gpu
 
+_NUMPY_DTYPE = {torch.int32: np.int32, torch.int64: np.int64, torch.float64: np.float64}
 STATS_FIELDS = ("inliers", "hypotheses", "winner_hypothesis", "winner_root", "good_r1_t", "good_r2_t", "good_r1_mt", "good_r2_mt")
 
 
@@ -34,7 +35,7 @@ class VerifierEngine:
     def _dev(self, a, dtype) -> torch.Tensor:
         if isinstance(a, torch.Tensor):
             return a.to(device=self.device, dtype=dtype).contiguous()
-        return torch.from_numpy(np.ascontiguousarray(np.asarray(a)).astype(np.dtype(str(dtype).replace("torch.", "")), copy=False)).to(self.device)
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=_NUMPY_DTYPE[dtype])).to(self.device)
 
     def verify_batch(
         self,
@@ -53,8 +54,8 @@ class VerifierEngine:
         kp_off2[p]; match_idx [M,2] int32 (device) rows relative to those offsets, pair p owning match_off[p]:match_off[p+1];
         intrinsics [P,8] = (fx, fy, cx, cy) of i1 then i2; match_count [P] int32 (device, optional): only the first
         match_count[p] rows of pair p's slice are matches (capacity layout of ``compact_matches``). ``use_intrinsics=False``:
-        fundamental-matrix estimation on pixel coordinates (adds "F" [P,3,3]; E = K2^T F K1). Returns device tensors: E [P,3,3], R [P,3,3], t [P,3] (NaN when a
-        pair has no model), mask [M] uint8, stats [P,8] int32 (``STATS_FIELDS``). Enqueued on the current stream."""
+        fundamental-matrix estimation on pixel coordinates (adds "F" [P,3,3]; E = K2^T F K1). Returns device tensors: E [P,3,3],
+        R [P,3,3], t [P,3] (NaN when a pair has no model), mask [M] uint8, stats [P,8] int32 (``STATS_FIELDS``). Enqueued on the current stream."""
         num_pairs = len(kp_off1)
         assert len(kp_off2) == num_pairs and len(match_off) == num_pairs + 1
         assert kp_xy.is_cuda and kp_xy.dtype == torch.float32 and kp_xy.is_contiguous()
