@@ -60,6 +60,51 @@ class BatchedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
     def generate_correspondences(
         self, client: Any, images: List[Any], visibility_graph: List[Tuple[int, int]]
     ) -> Tuple[List[Keypoints], Dict[Tuple[int, int], np.ndarray]]:
+        keypoints_list, putative, _ = self._detect_and_match(client, images, visibility_graph)
+        return keypoints_list, putative
+
+    def generate_correspondences_and_verify(
+        self, client: Any, images: List[Any], visibility_graph: List[Tuple[int, int]], camera_intrinsics: List[Any], verifier: Any
+    ) -> Tuple[List[Keypoints], Dict[Tuple[int, int], np.ndarray], Dict[Tuple[int, int], Tuple[Any, Any, np.ndarray, float]]]:
+        """``generate_correspondences`` followed by the verifier stage of ``TwoViewEstimator.run_2view``
+        (``gtsfm/two_view_estimator.py:391-397``) for every edge, with keypoints and matches staying in HBM between the stages.
+        ``verifier``: a ``gtsfm_amd.frontend.verifier.ransac.Ransac`` (threshold and estimation mode are read from it);
+        ``camera_intrinsics``: one calibration per image. Returns the keypoints, the putative correspondences and, per edge, the
+        verifier's return tuple ``(i2Ri1, i2Ui1, v_corr_idxs, inlier_ratio_est_model)``; edge (i1, i2) draws its samples from the
+        seed ``i1 << 32 | i2``. Calibrations with lens distortion or skew fall back to the per-pair plugin call for their edges."""
+        from gtsfm_amd.common.calibration import pinhole_parameters
+        from gtsfm_amd.frontend.verifier.ransac import Ransac, _to_pose_types
+
+        if not isinstance(verifier, Ransac):
+            raise TypeError("generate_correspondences_and_verify needs gtsfm_amd's Ransac verifier")
+        keypoints_list, putative, state = self._detect_and_match(client, images, visibility_graph)
+        params = [pinhole_parameters(c) for c in camera_intrinsics]
+        use_intrinsics = bool(verifier._use_intrinsics_in_verification)
+        verified: Dict[Tuple[int, int], Tuple[Any, Any, np.ndarray, float]] = {}
+        on_device = [r for r in state["results"]]
+        host_pairs = set()
+        if use_intrinsics and not all(p[4] for p in params):  # distortion / skew: the calibration's own calibrate(), per pair on the host
+            host_pairs = {pair for r in on_device for pair in r["pairs"] if not (params[pair[0]][4] and params[pair[1]][4])}
+        if on_device:
+            intr = np.array([p[:4] for p in params], dtype=np.float64)
+            ver = state["pipe"].verify(state["feats"], on_device, intr, float(verifier._estimation_threshold_px), use_intrinsics=use_intrinsics)
+            for pair, res in state["pipe"].verified_to_numpy(ver).items():
+                if pair in host_pairs:
+                    continue
+                dtype = putative[pair].dtype
+                if res["R"] is None:
+                    verified[pair] = verifier._failure_result
+                else:
+                    rot, direction = _to_pose_types(res["R"], res["t"])
+                    verified[pair] = (rot, direction, res["v_corr_idxs"].astype(dtype), res["inlier_ratio"])
+        for pair in putative:
+            if pair not in verified:  # empty keypoint sets, or a calibration the device path does not model
+                i1, i2 = pair
+                per_pair = Ransac(use_intrinsics, verifier._estimation_threshold_px, seed=(i1 << 32) | i2)
+                verified[pair] = per_pair.verify(keypoints_list[i1], keypoints_list[i2], putative[pair], camera_intrinsics[i1], camera_intrinsics[i2])
+        return keypoints_list, putative, {p: verified[p] for p in putative}
+
+    def _detect_and_match(self, client: Any, images: List[Any], visibility_graph: List[Tuple[int, int]]):
         import torch
 
         from gtsfm_amd.runtime.image_prep import ImagePrep
@@ -89,9 +134,10 @@ class BatchedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
                 kp, d = det.detect_and_describe(im)
                 order = np.lexsort((kp.coordinates[:, 0], kp.coordinates[:, 1])) if len(kp) else np.zeros(0, dtype=np.int64)
                 c = len(order)
-                xy[i, :c] = torch.from_numpy(np.ascontiguousarray(kp.coordinates[order], dtype=np.float32)).to(device)
-                sc[i, :c] = torch.from_numpy(np.ascontiguousarray(kp.responses[order], dtype=np.float32)).to(device)
-                de[i, :c] = torch.from_numpy(np.ascontiguousarray(d[order], dtype=np.float32)).to(device)
+                if c:  # a mask may remove every keypoint (responses are None then)
+                    xy[i, :c] = torch.from_numpy(np.ascontiguousarray(kp.coordinates[order], dtype=np.float32)).to(device)
+                    sc[i, :c] = torch.from_numpy(np.ascontiguousarray(kp.responses[order], dtype=np.float32)).to(device)
+                    de[i, :c] = torch.from_numpy(np.ascontiguousarray(d[order], dtype=np.float32)).to(device)
                 counts[i] = c
             else:
                 by_shape.setdefault(shapes[i], []).append(i)
@@ -130,7 +176,8 @@ class BatchedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         kwargs = (
             {"sinkhorn_iterations": matcher._config["sinkhorn_iterations"], "match_threshold": DEFAULT_MATCH_THRESHOLD} if is_sg else {}
         )
-        result = pipe.matches_to_numpy(pipe.match(feats, todo, shapes, counts=counts, **kwargs), dtype=dtype) if todo else {}
+        results = pipe.match(feats, todo, shapes, counts=counts, **kwargs) if todo else []
+        result = pipe.matches_to_numpy(results, dtype=dtype)
         for p in empty:
             result[p] = np.zeros((0, 2), dtype=dtype)
-        return keypoints_list, {p: result[p] for p in pairs}
+        return keypoints_list, {p: result[p] for p in pairs}, {"pipe": pipe, "feats": feats, "results": results}

@@ -236,3 +236,52 @@ def test_pipeline_detect_match_verify_stays_on_the_device_and_equals_the_oracle(
             np.testing.assert_allclose(got[(i, j)]["t"], ref["t"], atol=1e-9)
             assert got[(i, j)]["inlier_ratio"] == ref["inlier_ratio"]
     assert some >= 3
+
+
+def test_generator_detect_match_verify_equals_per_pair_plugin_calls(gpu_device, tmp_path):
+    """BatchedDetDescCorrespondenceGenerator.generate_correspondences_and_verify (detect -> match -> verify for all edges,
+    device-resident) against what TwoViewEstimator would do edge by edge: the verifier plugin on the generator's keypoints and
+    putative matches (same seed per edge). One image has no keypoints (fully masked), one calibration has skew (host fallback)."""
+    from gtsfm_amd.common.calibration import PinholeIntrinsics
+    from gtsfm_amd.common.image import Image
+    from gtsfm_amd.frontend.correspondence_generator.batched_det_desc_correspondence_generator import BatchedDetDescCorrespondenceGenerator
+    from gtsfm_amd.frontend.detector_descriptor.superpoint import SuperPointDetectorDescriptor
+    from gtsfm_amd.frontend.matcher.lightglue_matcher import LightGlueMatcher
+    from gtsfm_amd.frontend.verifier.ransac import Ransac
+
+    torch.save(synthetic.synthetic_superpoint_state_dict(), str(tmp_path / "sp.pth"))
+    torch.save(synthetic.synthetic_lightglue_state_dict(num_layers=3), str(tmp_path / "lg.pth"))
+    views = synthetic.synthetic_overlapping_views(4, 256, 320, seed=9)
+    images = [Image(value_array=v) for v in views] + [Image(value_array=views[0].copy(), mask=np.zeros((256, 320), dtype=np.uint8))]  # fully masked
+
+    class Skewed(PinholeIntrinsics):
+        def K(self):  # noqa: N802
+            k = super().K()
+            k[0, 1] = 0.5
+            return k
+
+        def calibrate(self, uv):
+            uv = np.asarray(uv, dtype=np.float64).reshape(2)
+            y = (uv[1] - self.v0) / self.fy
+            return np.array([(uv[0] - self.u0 - 0.5 * y) / self.fx, y])
+
+    cams = [PinholeIntrinsics(400.0 + 5 * i, 160.0, 128.0) for i in range(5)]
+    cams[3] = Skewed(410.0, 160.0, 128.0)
+    gen = BatchedDetDescCorrespondenceGenerator(
+        LightGlueMatcher("superpoint", weights_path=tmp_path / "lg.pth"), SuperPointDetectorDescriptor(max_keypoints=600, weights_path=tmp_path / "sp.pth"),
+        pair_batch=2)
+    edges = [(0, 1), (0, 2), (1, 2), (2, 3), (1, 3), (0, 4)]
+    kps, putative, verified = gen.generate_correspondences_and_verify(None, images, edges, cams, Ransac(True, 1.0))
+    assert list(verified) == edges and len(kps[4]) == 0 and verified[(0, 4)][0] is None and verified[(0, 4)][2].size == 0
+    models = 0
+    for i, j in edges:
+        ref = Ransac(True, 1.0, seed=(i << 32) | j).verify(kps[i], kps[j], putative[(i, j)], cams[i], cams[j])
+        got = verified[(i, j)]
+        np.testing.assert_array_equal(got[2], ref[2])
+        assert got[3] == ref[3] and (got[0] is None) == (ref[0] is None)
+        if ref[0] is not None:
+            models += 1
+            np.testing.assert_array_equal(np.asarray(got[0]), np.asarray(ref[0]))
+            np.testing.assert_array_equal(np.asarray(got[1]), np.asarray(ref[1]))
+            assert set(map(tuple, got[2].tolist())) <= set(map(tuple, putative[(i, j)].tolist()))
+    assert models >= 3
