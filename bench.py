@@ -623,6 +623,8 @@ def main() -> None:
                 result["secondary"] = secondary_rates(args, detector, matcher, device, h, w, mk)
                 if getattr(pipe, "last_shared_images", 0):
                     result["secondary"]["headline_per_pair_first_layer"] = unshared_rate(args, detector, matcher, images, pairs, shapes, mk)
+                if args.matcher == "lightglue":
+                    result["secondary"]["lightglue_adaptive_depth"] = adaptive_depth_rate(args, detector, device, images, pairs, shapes)
                 result["secondary"]["verifier_stage"] = verifier_rate(pipe, feats, res, h, w, ms_per_step, device, not args.no_cpu_baseline)
             if world == 1 and not args.no_cpu_baseline:  # rank 0 at N = 1 only
                 first = all_pairs[0] if all_pairs else (0, min(1, len(views_np) - 1))
@@ -725,6 +727,36 @@ def unshared_rate(args, detector, matcher, images, pairs, shapes, mk):
     ms = (time.perf_counter() - t0) / steps * 1e3
     return {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
             "pairs_per_step": len(pairs), "workload": "the headline workload with --share-first-layer 0 (first matcher block once per pair side)"}
+
+
+def adaptive_depth_rate(args, detector, device, images, pairs, shapes):
+    """The headline workload with token-confidence heads that DO fire (the headline's seeded heads never reach the exit
+    threshold, so it pays all 9 layers for every pair -- the worst case). LightGlue's adaptive depth and width run on the device
+    (``lg_stop_check`` / ``lg_prune_*``): pairs leave the batch at different layers inside one launch sequence. Not the headline:
+    a different weight set (``conf_bias`` 1, ``conf_gain`` 4: same recipe as the early-stop parity tests; the synthetic views are
+    alike, so every pair leaves at the same layer -- real image pairs spread over layers 3 to 9), reported with the layers it ran."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+
+    matcher = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(conf_bias=1.0, conf_gain=4.0), device)
+    pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams,
+                            use_graphs=bool(args.graphs), share_first_layer=bool(args.share_first_layer))
+    steps, warmup = 2, 1
+    for _ in range(warmup):
+        res = pipe.match(pipe.detect(images), pairs, shapes)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = pipe.match(pipe.detect(images), pairs, shapes)
+    torch.cuda.synchronize(device)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    layers = torch.cat([r["stop"] for r in res]).float()
+    kept = torch.cat([r["kept"] for r in res]).float()
+    nm = int(sum(int((r["matches"] > -1).sum()) for r in res)) // 2
+    return {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+            "pairs_per_step": len(pairs), "matcher_layers_run": {"mean": round(float(layers.mean()), 2), "min": int(layers.min()), "max": int(layers.max())},
+            "keypoints_alive_at_assignment": round(float(kept.mean()), 1), "matches_per_pair": round(nm / max(1, len(pairs)), 1),
+            "workload": "the headline workload with synthetic token-confidence heads that fire (conf_bias 1, conf_gain 4): adaptive depth / width on the device"}
 
 
 def secondary_rates(args, detector, matcher, device, h, w, mk):
