@@ -277,10 +277,10 @@ extern "C" int gtsfm_sp_select_topk(const float* kp_score_dev, const float* kp_x
         if (rc_ != GTSFM_OK) return rc_; \
     } while (0)
 
-extern "C" int gtsfm_sp_forward(const float* wts, const void* image_dev, int image_is_u8, int B, int H, int W, float thr, int nms_radius,
-                                int border, int capacity, int top_k, void* workspace_dev, size_t workspace_bytes, int32_t* kp_count_dev,
-                                int32_t* kp_count_raw_dev, float* kp_xy_dev, float* kp_score_dev, float* desc_dev,
-                                float* dense_scores_dev, float* nms_scores_dev, void* stream_) {
+static int sp_forward_impl(const float* wts, const void* image_dev, int image_is_u8, int B, int H, int W, float thr, int nms_radius,
+                           int border, int capacity, int top_k, void* workspace_dev, size_t workspace_bytes, int32_t* kp_count_dev,
+                           int32_t* kp_count_raw_dev, float* kp_xy_dev, float* kp_score_dev, float* desc_dev,
+                           float* dense_scores_dev, float* nms_scores_dev, const uint8_t* valid_mask_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GTSFM_CHECK_ARG(wts && image_dev && workspace_dev && kp_count_dev && kp_xy_dev && kp_score_dev && desc_dev, "sp_forward: null pointer");
     GTSFM_CHECK_ARG(B > 0 && H > 0 && W > 0 && capacity > 0, "sp_forward: bad shape (batch %d, %d x %d, capacity %d)", B, H, W, capacity);
@@ -363,6 +363,9 @@ extern "C" int gtsfm_sp_forward(const float* wts, const void* image_dev, int ima
     }
     SP_TRY(launch_softmax_d2s(logits, 65, B, Hc, Wc, scores, stream));
     SP_TRY(launch_simple_nms(scores, B, H8, W8, nms_radius, mask, supp, ss, nms, stream));
+    // Keypoints.filter_by_mask (gtsfm/common/keypoints.py:112-127) ahead of the top-k, as the wrapper orders them
+    // (gtsfm/frontend/detector_descriptor/superpoint.py:76-91): a keypoint at pixel (x, y) survives iff mask[y][x] == 1
+    if (valid_mask_dev) SP_TRY(launch_apply_keypoint_mask(nms, B, H8, W8, valid_mask_dev, H, W, stream));
     if (top_k <= 0) {
         SP_TRY(launch_extract_keypoints(nms, B, H8, W8, thr, border, capacity, rows, rows + (size_t)B * H8, kp_count_dev, count_raw,
                                         kp_xy_dev, kp_score_dev, stream));
@@ -378,4 +381,21 @@ extern "C" int gtsfm_sp_forward(const float* wts, const void* image_dev, int ima
         SP_TRY(launch_sample_descriptors(dense, 256, B, Hc, Wc, kp_xy_dev, kp_count_dev, top_k, desc_dev, stream));
     }
     return GTSFM_OK;
+}
+
+extern "C" int gtsfm_sp_forward(const float* wts, const void* image_dev, int image_is_u8, int B, int H, int W, float thr, int nms_radius,
+                                int border, int capacity, int top_k, void* workspace_dev, size_t workspace_bytes, int32_t* kp_count_dev,
+                                int32_t* kp_count_raw_dev, float* kp_xy_dev, float* kp_score_dev, float* desc_dev,
+                                float* dense_scores_dev, float* nms_scores_dev, void* stream_) {
+    return sp_forward_impl(wts, image_dev, image_is_u8, B, H, W, thr, nms_radius, border, capacity, top_k, workspace_dev, workspace_bytes, kp_count_dev,
+                           kp_count_raw_dev, kp_xy_dev, kp_score_dev, desc_dev, dense_scores_dev, nms_scores_dev, nullptr, stream_);
+}
+
+extern "C" int gtsfm_sp_forward_masked(const float* wts, const void* image_dev, int image_is_u8, int B, int H, int W, float thr, int nms_radius,
+                                       int border, int capacity, int top_k, void* workspace_dev, size_t workspace_bytes, int32_t* kp_count_dev,
+                                       int32_t* kp_count_raw_dev, float* kp_xy_dev, float* kp_score_dev, float* desc_dev,
+                                       float* dense_scores_dev, float* nms_scores_dev, const uint8_t* valid_mask_dev, void* stream_) {
+    GTSFM_CHECK_ARG(!valid_mask_dev || thr > 0.f, "sp_forward_masked: a mask needs a positive keypoint threshold");
+    return sp_forward_impl(wts, image_dev, image_is_u8, B, H, W, thr, nms_radius, border, capacity, top_k, workspace_dev, workspace_bytes, kp_count_dev,
+                           kp_count_raw_dev, kp_xy_dev, kp_score_dev, desc_dev, dense_scores_dev, nms_scores_dev, valid_mask_dev, stream_);
 }

@@ -187,6 +187,19 @@ __device__ __forceinline__ bool kp_valid(float s, int y, int x, int H, int W, fl
     return (s > thr) && (y >= border) && (y < H - border) && (x >= border) && (x < W - border);
 }
 
+__global__ __launch_bounds__(256) void kp_apply_mask_kernel(float* __restrict__ nms, int H, int W, const uint8_t* __restrict__ valid, int img_h, int img_w) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= W) return;
+    if (valid[((size_t)b * img_h + y) * img_w + x] != 1) nms[((size_t)b * H + y) * W + x] = 0.f;  // below any positive threshold
+}
+
+int launch_apply_keypoint_mask(float* nms, int B, int H, int W, const uint8_t* valid_mask, int img_h, int img_w, hipStream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return GTSFM_OK;
+    hipLaunchKernelGGL(kp_apply_mask_kernel, dim3(ceil_div(W, 256), H, B), dim3(256), 0, stream, nms, H, W, valid_mask, img_h, img_w);
+    GTSFM_CHECK_LAUNCH("kp_apply_mask_kernel");
+    return GTSFM_OK;
+}
+
 __global__ __launch_bounds__(64) void kp_count_rows_kernel(const float* __restrict__ nms, int H, int W, float thr, int border,
                                                            int* __restrict__ rowcnt) {
     const int y = blockIdx.x, b = blockIdx.y;

@@ -126,21 +126,12 @@ class BatchedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         de = torch.zeros((n, k, 256), dtype=torch.float32, device=device)
         counts = np.zeros(n, dtype=np.int64)
 
-        # images with a mask go through the plugin (mask filtering precedes top-k and runs on the host); the others are
-        # detected in equally-sized batches with the top-k taken on the device
+        # equally-sized images are detected in batches with the top-k taken on the device; image masks
+        # (Keypoints.filter_by_mask ahead of get_top_k, gtsfm/frontend/detector_descriptor/superpoint.py:76-91) ride along as a
+        # uint8 batch and are applied on the device between the NMS and the keypoint extraction
         by_shape: Dict[Tuple[int, int], List[int]] = {}
-        for i, im in enumerate(imgs):
-            if im.mask is not None:
-                kp, d = det.detect_and_describe(im)
-                order = np.lexsort((kp.coordinates[:, 0], kp.coordinates[:, 1])) if len(kp) else np.zeros(0, dtype=np.int64)
-                c = len(order)
-                if c:  # a mask may remove every keypoint (responses are None then)
-                    xy[i, :c] = torch.from_numpy(np.ascontiguousarray(kp.coordinates[order], dtype=np.float32)).to(device)
-                    sc[i, :c] = torch.from_numpy(np.ascontiguousarray(kp.responses[order], dtype=np.float32)).to(device)
-                    de[i, :c] = torch.from_numpy(np.ascontiguousarray(d[order], dtype=np.float32)).to(device)
-                counts[i] = c
-            else:
-                by_shape.setdefault(shapes[i], []).append(i)
+        for i in range(n):
+            by_shape.setdefault(shapes[i], []).append(i)
         for (h, w), idxs in by_shape.items():
             for b0 in range(0, len(idxs), self._image_batch):
                 sel = idxs[b0 : b0 + self._image_batch]
@@ -155,7 +146,12 @@ class BatchedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
                     if gray.dtype != np.uint8:
                         gray = gray.astype(np.float32) / 255.0
                     batch = torch.from_numpy(gray).to(device)
-                out = det._model.forward(batch, top_k=k)
+                masks = None
+                if any(imgs[i].mask is not None for i in sel):
+                    masks = torch.from_numpy(np.ascontiguousarray(np.stack(
+                        [np.ones((h, w), dtype=np.uint8) if imgs[i].mask is None else (np.asarray(imgs[i].mask) == 1).astype(np.uint8) for i in sel]
+                    ))).to(device)
+                out = det._model.forward(batch, top_k=k, valid_masks=masks)
                 ii = torch.tensor(sel, dtype=torch.long, device=device)
                 xy[ii], sc[ii], de[ii] = out["xy"], out["scores"], out["descriptors"]
                 counts[sel] = out["count"].cpu().numpy()

@@ -93,8 +93,10 @@ class SuperPointEngine:
         remove_borders: int = DEFAULT_REMOVE_BORDERS,
         return_score_maps: bool = False,
         top_k: int = 0,
+        valid_masks: Optional[torch.Tensor] = None,
     ) -> Dict[str, torch.Tensor]:
-        """images: device tensor [B,H,W], uint8 or float32 in [0,1]. Returns device tensors:
+        """images: device tensor [B,H,W], uint8 or float32 in [0,1]; valid_masks (optional): device uint8 [B,H,W], 1 = valid --
+        keypoints on other pixels are dropped before the top-k (``Keypoints.filter_by_mask``). Returns device tensors:
         count [B] int32, count_raw [B] int32, xy [B,cap,2], scores [B,cap], descriptors [B,cap,256]."""
         assert images.dim() == 3 and images.is_cuda and images.is_contiguous()
         assert images.dtype in (torch.uint8, torch.float32)
@@ -114,13 +116,15 @@ class SuperPointEngine:
             dense = torch.empty((b, h8, w8), dtype=torch.float32, device=dev)
             nms = torch.empty((b, h8, w8), dtype=torch.float32, device=dev)
         ws = self._workspace(b, h, w)
-        rc = self._lib.gtsfm_sp_forward(
+        if valid_masks is not None:
+            assert valid_masks.shape == images.shape and valid_masks.dtype == torch.uint8 and valid_masks.is_cuda and valid_masks.is_contiguous()
+        rc = self._lib.gtsfm_sp_forward_masked(
             self.weights.data_ptr(), images.data_ptr(), int(images.dtype == torch.uint8), b, h, w,
             float(keypoint_threshold), int(nms_radius), int(remove_borders), cap, int(top_k), ws.data_ptr(), ws.numel(),
             count.data_ptr(), count_raw.data_ptr(), xy.data_ptr(), scores.data_ptr(), desc.data_ptr(),
-            _lib.ptr(dense), _lib.ptr(nms), torch.cuda.current_stream(dev).cuda_stream,
+            _lib.ptr(dense), _lib.ptr(nms), _lib.ptr(valid_masks), torch.cuda.current_stream(dev).cuda_stream,
         )
-        _lib.check(rc, "gtsfm_sp_forward")
+        _lib.check(rc, "gtsfm_sp_forward_masked")
         out = {"count": count, "count_raw": count_raw, "xy": xy, "scores": scores, "descriptors": desc}
         if return_score_maps:
             out["dense_scores"], out["nms_scores"] = dense, nms

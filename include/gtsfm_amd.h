@@ -116,6 +116,16 @@ int gtsfm_sp_forward(const float* packed_weights_dev, const void* image_dev, int
                      float* kp_xy_dev, float* kp_score_dev, float* desc_dev, float* dense_scores_dev,
                      float* nms_scores_dev, void* stream);
 
+/* The same with the image masks GTSfM attaches to images (gtsfm/common/image.py `mask`): valid_mask_dev [batch][height][width]
+ * uint8, 1 = valid (NULL = no mask). A keypoint at pixel (x, y) is kept iff valid_mask[y][x] == 1 -- Keypoints.filter_by_mask,
+ * gtsfm/common/keypoints.py:112-127 -- applied BEFORE the top-k, as gtsfm/frontend/detector_descriptor/superpoint.py:76-91
+ * orders them. (With a mask the nms_scores_dev tap shows the masked scores; keypoint_threshold must be positive.) */
+int gtsfm_sp_forward_masked(const float* packed_weights_dev, const void* image_dev, int image_is_u8, int batch, int height,
+                            int width, float keypoint_threshold, int nms_radius, int remove_borders, int capacity, int top_k,
+                            void* workspace_dev, size_t workspace_bytes, int32_t* kp_count_dev, int32_t* kp_count_raw_dev,
+                            float* kp_xy_dev, float* kp_score_dev, float* desc_dev, float* dense_scores_dev,
+                            float* nms_scores_dev, const uint8_t* valid_mask_dev, void* stream);
+
 /* The individual SuperPoint stages (same kernels gtsfm_sp_forward launches), for stage-wise parity tests. */
 
 /* softmax over 65 logits per cell, drop dustbin, depth-to-space 8x8.                           replaces SP:163-166

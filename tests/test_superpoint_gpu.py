@@ -497,3 +497,40 @@ def test_end_to_end_matches_golden_config2_shape(engine):
     np.testing.assert_array_equal(xy.astype(np.int32), g["keypoints"])
     np.testing.assert_allclose(sc, g["scores"], rtol=0, atol=SCORE_TOL)
     np.testing.assert_allclose(de[:256], g["descriptors_head"], rtol=0, atol=DESC_TOL)
+
+
+def test_device_mask_equals_filter_by_mask_then_top_k(gpu_device):
+    """gtsfm_sp_forward_masked: the image mask applied on the device ahead of the top-k against the wrapper's host sequence
+    (Keypoints.filter_by_mask, then get_top_k; gtsfm/frontend/detector_descriptor/superpoint.py:76-91) on the unmasked output."""
+    from gtsfm_amd.common.keypoints import Keypoints
+    from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+
+    eng = SuperPointEngine(synthetic.synthetic_superpoint_state_dict(), gpu_device)
+    imgs = np.stack([synthetic.synthetic_gray_image(200, 264, s) for s in (5, 6, 7)])
+    masks = np.zeros((3, 200, 264), dtype=np.uint8)
+    masks[0, 20:150, 30:200] = 1
+    masks[1] = 1                      # everything valid
+    masks[2, ::2, :] = 1              # every other row; values other than 1 are invalid as in the reference
+    masks[2, 1::2, :] = 255
+    x = torch.from_numpy(imgs).to(gpu_device)
+    m = torch.from_numpy(masks).to(gpu_device)
+    plain = eng.forward(x)
+    masked = eng.forward(x, valid_masks=m)
+    top = eng.forward(x, valid_masks=m, top_k=150)
+    for b in range(3):
+        c = int(plain["count"][b])
+        xy = plain["xy"][b, :c].cpu().numpy()
+        sc = plain["scores"][b, :c].cpu().numpy()
+        de = plain["descriptors"][b, :c].cpu().numpy()
+        kept, idx = Keypoints(coordinates=xy, responses=sc).filter_by_mask(masks[b])
+        cm = int(masked["count"][b])
+        assert cm == len(kept) and (b != 1 or cm == c) and cm > 0
+        np.testing.assert_array_equal(masked["xy"][b, :cm].cpu().numpy(), kept.coordinates)
+        np.testing.assert_array_equal(masked["scores"][b, :cm].cpu().numpy(), kept.responses)
+        np.testing.assert_array_equal(masked["descriptors"][b, :cm].cpu().numpy(), de[idx])
+        # top-k of the masked set, detection order (no score ties in these images)
+        order = np.sort(synthetic.topk_detection_order(kept.responses, 150))
+        ct = int(top["count"][b])
+        assert ct == len(order)
+        np.testing.assert_array_equal(top["xy"][b, :ct].cpu().numpy(), kept.coordinates[order])
+        np.testing.assert_array_equal(top["descriptors"][b, :ct].cpu().numpy(), de[idx][order])
