@@ -140,7 +140,7 @@ extern "C" int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* 
     int row = 0, in_row = 0, tile = 0, max_n1 = 0;
     long long zoff = 0, poff = 0;
     for (int p = 0; p < npairs; ++p) max_n1 = max_n1 > n1[p] ? max_n1 : n1[p];
-    const int R = sweep_rows_per_block(max_n1 + ext);
+    const int R = sweep_partial_rows(max_n1, ext);
     for (int p = 0; p < npairs; ++p) {
         GTSFM_CHECK_ARG(n0[p] > 0 && n1[p] > 0, "match_build_desc: pair %d has an empty keypoint set", p);
         const int ns[2] = {n0[p], n1[p]};
@@ -208,7 +208,7 @@ BatchDims batch_dims(int P, const int32_t* n0, const int32_t* n1, int ext) {
     BatchDims d = {P, 0, 0, 0, 0, 0, 0, 0};
     int mx1 = 0;
     for (int p = 0; p < P; ++p) mx1 = mx1 > n1[p] ? mx1 : n1[p];
-    const int R = sweep_rows_per_block(mx1 + ext);
+    const int R = sweep_partial_rows(mx1, ext);
     for (int p = 0; p < P; ++p) {
         d.T += n0[p] + n1[p];
         d.max_n0 = d.max_n0 > n0[p] ? d.max_n0 : n0[p];
@@ -495,7 +495,7 @@ LgDims lg_dims(int P, const int32_t* n0, const int32_t* n1) {
     LgDims d = {P, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int mx1 = 0;
     for (int p = 0; p < P; ++p) mx1 = mx1 > n1[p] ? mx1 : n1[p];
-    const int R = sweep_rows_per_block(mx1);
+    const int R = sweep_partial_rows(mx1, 0);
     for (int p = 0; p < P; ++p) {
         d.T += n0[p] + n1[p];
         d.Tp += cap128(n0[p]) + cap128(n1[p]);

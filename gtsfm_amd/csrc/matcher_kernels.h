@@ -59,7 +59,7 @@ int launch_layernorm_gelu(float* x, int ld, const SeqDesc* seqs, const int* coun
                           const float* beta, hipStream_t stream);
 int launch_rowdot(const float* x, int ld, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* w, float b, int act,
                   float* out, hipStream_t stream);
-// Score-matrix sweeps (sweep_kernels.hip): register-resident rows for up to 2048 columns, LDS-staged rows beyond
+// Score-matrix sweeps (sweep_kernels.hip): register-resident rows (a wave per row up to 2048 columns, a workgroup per row up to 10240), LDS-staged rows beyond
 int launch_sinkhorn(const SweepArgs& a, float bin_score, int iters, hipStream_t stream);
 int launch_double_softmax_lse(const SweepArgs& a, hipStream_t stream);
 int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogit, float threshold, float* max0, int* idx0, int* idx1,
@@ -73,4 +73,6 @@ int launch_sg_fill_bins(const SweepArgs& a, float bin_score, hipStream_t stream)
 int launch_mutual_matches(const SweepArgs& a, float threshold, const float* max0, const int* idx0, const int* idx1, int* matches,
                           float* mscores, hipStream_t stream);
 int launch_materialize_assignment(const SweepArgs& a, int superglue, const float* zlogit, float* out, hipStream_t stream);
-int sweep_rows_per_block(int max_cols);  // rows of the score matrix one workgroup of the row sweep owns
+int sweep_rows_per_block(int max_cols);  // rows of the score matrix one workgroup of the LDS-staged row sweep owns
+// rows behind one block of column partials for a batch whose widest pair has max_n columns (+ ext dustbin column): sizes `partials`
+int sweep_partial_rows(int max_n, int ext);

@@ -20,15 +20,24 @@
 // The extraction sweep reads Z once more and produces the row arg-maxima (wave reduction) and the column arg-maxima
 // (per-lane running best over the wave's rows, combined across waves / row blocks), replacing round 1's two separate
 // sweeps (best_rows + best_cols = 0.93 ms per 32-pair chunk at N = 2048).
-// Score matrices wider than 2048 columns (GTSfM's 5000-keypoint cap) take the LDS-staged kernels of
-// matcher_kernels.hip. Built with -ffp-contract=off.
+// Score matrices wider than 2048 columns (GTSfM's 5000-keypoint cap, deep_front_end.yaml:29) do not fit one wave's
+// registers (20 float4 per lane x 4 buffers). They take the *_wide_kernel forms below: the 4 (or 8) waves of a
+// workgroup SHARE a row -- wave w owns the 256-column chunks w, w + NW, w + 2 NW, ... of every one of the block's 32 rows,
+// so its column statistics are complete without any cross-wave step, and a row costs ONE barrier: every wave publishes
+// the (max, sum) of its slice relative to its OWN maximum, and all waves combine the NW pairs in a fixed order
+// (exp(t - max) = exp(t - max_w) exp(max_w - max)). 5120 columns with 4 waves (round 3), 10240 with 8; beyond that the
+// LDS-staged kernels of matcher_kernels.hip. Which kernel a pair takes depends only on ITS OWN column count -- a batch wider
+// than 2048 launches every tier and the blocks of the other tiers' pairs return at once -- so results do not depend on the
+// batch a pair travels in. Built with -ffp-contract=off.
 
 #include <stdlib.h>
 
 #include "matcher_kernels.h"
 
 #define SW_ROWS 32        // rows per workgroup: 4 waves x 8 rows (wave w owns rows r0 + w, r0 + w + 4, ...)
-#define SW_MAX_COLS 2048  // widest register-resident row
+#define SW_MAX_COLS 2048  // widest row one wave holds in registers
+#define SW_WIDE4_COLS 5120   // widest row the 4 waves of a workgroup hold together (5 chunks of 256 columns per wave)
+#define SW_WIDE8_COLS 10240  // ... 8 waves
 
 constexpr float SW_LOG2E = 1.44269504088896340736f;
 constexpr float SW_FLT_MIN = 1.17549435e-38f;
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 2 : 3) void sinkhorn_rows_kernel(co
     const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
     const int rows = m + 1;
     const int r0 = blockIdx.x * SW_ROWS;
-    if (r0 >= rows) return;
+    if (r0 >= rows || n > SW_MAX_COLS) return;  // wider pairs: sinkhorn_rows_wide_kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ld = pd.ld;
     const float* Z = zbuf + pd.z_off;
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void lg_rows_kernel(const float* __restrict
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
     const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
     const int r0 = blockIdx.x * SW_ROWS;
-    if (r0 >= m) return;
+    if (r0 >= m || n > SW_MAX_COLS) return;  // wider pairs: lg_rows_wide_kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ld = pd.ld;
     const float* Z = zbuf + pd.z_off;
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(con
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
     const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
     const int r0 = blockIdx.x * SW_ROWS;
-    if (r0 >= m) return;
+    if (r0 >= m || n > SW_MAX_COLS) return;  // wider pairs: extract_rows_wide_kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ld = pd.ld;
     const float* Z = zbuf + pd.z_off;
@@ -456,16 +465,358 @@ __global__ __launch_bounds__(256) void extract_cols_kernel(const PairDesc* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Rows wider than 2048 columns: the NW waves of a workgroup share a row (see the header). Wave w, chunk c of its registers
+// <-> columns 256 (w + NW c) + 4 lane .. + 3: the mapping does not depend on NCH (unused chunks are masked), so a pair's
+// result does not depend on the widest pair of its batch. A pair belongs to the tier NW = 4 when 2048 < n <= 5120 and to
+// NW = 8 when 5120 < n <= 10240.
+// ---------------------------------------------------------------------------------------------------------------
+
+template <int NW>
+__device__ __forceinline__ bool sw_wide_tier(int n) {
+    return NW == 4 ? (n > SW_MAX_COLS && n <= SW_WIDE4_COLS) : (n > SW_WIDE4_COLS && n <= SW_WIDE8_COLS);
+}
+
+template <int NW, int NCH>
+__device__ __forceinline__ void sw_load_slice(const float* __restrict__ zr, int n, int wave, int lane, f32x4 (&dst)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 256 * (wave + NW * c) + 4 * lane;
+        if (col < n) dst[c] = *reinterpret_cast<const f32x4*>(zr + col);
+    }
+}
+
+template <int NW, int NCH>
+__global__ __launch_bounds__(64 * NW) void sinkhorn_rows_wide_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+                                                                     const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
+                                                                     float* __restrict__ rowvec, const float* __restrict__ colvec,
+                                                                     float* __restrict__ partials, float alpha, int pair0) {
+    __shared__ float xm[2][NW], xs[2][NW];  // per-wave (max, sum) of the row in flight, double-buffered by row parity
+    const int p = pair0 + blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int rows = m + 1;
+    const int r0 = blockIdx.x * SW_ROWS;
+    if (r0 >= rows || !sw_wide_tier<NW>(n)) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ld = pd.ld;
+    const float* Z = zbuf + pd.z_off;
+    const int vec0 = vec_off(s0, 2 * p), vec1 = vec_off(s1, 2 * p + 1);
+    const float NEG = neg_inf();
+    const float mn = (float)m + (float)n;
+    const float norm = -logf(mn);
+    const float inv_mn = 1.0f / mn;
+    f32x4 v[NCH], acc[NCH], za[NCH], zb[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 256 * (wave + NW * c) + 4 * lane;
+        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < n) v[c] = *reinterpret_cast<const f32x4*>(colvec + vec1 + col);
+        acc[c] = za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float t_bin = alpha + colvec[vec1 + n];  // dustbin column: Z[i][n] = bin_score for every row
+    float acc_bin = 0.f;                           // kept by every wave (same value)
+
+    auto load = [&](int i, f32x4(&dst)[NCH]) {
+        if (i < m) {
+            sw_load_slice<NW, NCH>(Z + (size_t)i * ld, n, wave, lane, dst);
+        } else {  // dustbin row: Z[m][j] = bin_score
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) dst[c] = f32x4{alpha, alpha, alpha, alpha};
+        }
+    };
+    auto process = [&](int i, f32x4(&zz)[NCH], int slot) {
+        float mw = NEG;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = 256 * (wave + NW * c) + 4 * lane;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = (col + e < n) ? zz[c][e] + v[c][e] : NEG;
+                zz[c][e] = t;
+                mw = fmaxf(mw, t);
+            }
+        }
+        mw = wave_max(mw);
+        const bool has = mw != NEG;         // false: none of this wave's columns exist (n is far below the tier's width)
+        const float mref = has ? mw : 0.f;  // the slice's exponentials are taken relative to its own maximum
+        float sw = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ev = sw_exp2((zz[c][e] - mref) * SW_LOG2E);  // exp2(-inf) = 0 for the masked columns
+                zz[c][e] = ev;
+                sw += ev;
+            }
+        }
+        sw = wave_sum(sw);
+        if (lane == 0) xm[slot][wave] = mw, xs[slot][wave] = sw;
+        __syncthreads();
+        float mx = t_bin;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mx = fmaxf(mx, xm[slot][w]);
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += xs[slot][w] * sw_exp2((xm[slot][w] - mx) * SW_LOG2E);  // empty slice: 0 * exp2(-inf) = 0
+        const float e_bin = sw_exp2((t_bin - mx) * SW_LOG2E);
+        s += e_bin;
+        const float lse = logf(s) + mx;
+        const float log_mu = (i < m) ? norm : logf((float)n) + norm;
+        if (threadIdx.x == 0) rowvec[vec0 + i] = log_mu - lse;  // u_i (superglue.py:145)
+        // exp(u_i + max_i) = mu_i / s_i; this wave's exponentials additionally carry exp(max_w - max_i)
+        const float wrow = ((i < m) ? inv_mn : (float)n * inv_mn) / s;
+        const float wgt = has ? sw_exp2((mw - mx) * SW_LOG2E) * wrow : 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[c][e] = fmaf(zz[c][e], wgt, acc[c][e]);
+        }
+        acc_bin = fmaf(e_bin, wrow, acc_bin);
+    };
+
+    const int rend = (r0 + SW_ROWS < rows) ? r0 + SW_ROWS : rows;
+    int i = r0;
+    load(i, za);
+#pragma unroll 1
+    for (; i < rend; i += 2) {  // uniform for the workgroup: every wave walks the same rows
+        if (i + 1 < rend) load(i + 1, zb);
+        process(i, za, 0);
+        if (i + 1 >= rend) break;
+        if (i + 2 < rend) load(i + 2, za);
+        process(i + 1, zb, 1);
+    }
+
+    // column partials of the block's 32 rows: a wave's columns are its own, no combination step
+    float* part = partials + pd.part_off + (size_t)blockIdx.x * ld;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 256 * (wave + NW * c) + 4 * lane;
+        if (col >= n) continue;
+        f32x4 sum = acc[c];
+        const int d = n - col;  // the dustbin column sits inside this float4 when d < 4
+        if (d == 1) sum.y = acc_bin;
+        if (d == 2) sum.z = acc_bin;
+        if (d == 3) sum.w = acc_bin;
+        *reinterpret_cast<f32x4*>(part + col) = sum;  // col < n, col % 4 == 0 -> col + 3 < ld
+    }
+    if (threadIdx.x == 0 && (n & 3) == 0) part[n] = acc_bin;  // ... or opens a float4 of its own
+}
+
+template <int NW, int NCH>
+__global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+                                                               const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
+                                                               float* __restrict__ rowvec, float* __restrict__ partials) {
+    __shared__ float xm[2][NW], xs[2][NW];
+    const int p = blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int r0 = blockIdx.x * SW_ROWS;
+    if (r0 >= m || !sw_wide_tier<NW>(n)) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ld = pd.ld;
+    const float* Z = zbuf + pd.z_off;
+    const int vec0 = vec_off(s0, 2 * p);
+    const float NEG = neg_inf();
+    f32x4 cm[NCH], cs[NCH], za[NCH], zb[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        cm[c] = f32x4{NEG, NEG, NEG, NEG};
+        cs[c] = za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto process = [&](int i, f32x4(&zz)[NCH], int slot) {
+        float mw = NEG;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = 256 * (wave + NW * c) + 4 * lane;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = (col + e < n) ? zz[c][e] : NEG;
+                zz[c][e] = t;
+                mw = fmaxf(mw, t);
+            }
+        }
+        mw = wave_max(mw);
+        const float mref = (mw != NEG) ? mw : 0.f;
+        float sw = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = zz[c][e];
+                sw += sw_exp2((t - mref) * SW_LOG2E);
+                // online column statistics: the masked columns (t = -inf) keep (max, sum) = (-inf, 0)
+                const float nm = fmaxf(cm[c][e], t);
+                const float keep = (nm == NEG) ? 0.f : sw_exp2((cm[c][e] - nm) * SW_LOG2E);
+                const float add = (nm == NEG) ? 0.f : sw_exp2((t - nm) * SW_LOG2E);
+                cs[c][e] = cs[c][e] * keep + add;
+                cm[c][e] = nm;
+            }
+        }
+        sw = wave_sum(sw);
+        if (lane == 0) xm[slot][wave] = mw, xs[slot][wave] = sw;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float mx = xm[slot][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) mx = fmaxf(mx, xm[slot][w]);
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += xs[slot][w] * sw_exp2((xm[slot][w] - mx) * SW_LOG2E);
+            rowvec[vec0 + i] = logf(s) + mx;
+        }
+    };
+    const int rend = (r0 + SW_ROWS < m) ? r0 + SW_ROWS : m;
+    int i = r0;
+    sw_load_slice<NW, NCH>(Z + (size_t)i * ld, n, wave, lane, za);
+#pragma unroll 1
+    for (; i < rend; i += 2) {
+        if (i + 1 < rend) sw_load_slice<NW, NCH>(Z + (size_t)(i + 1) * ld, n, wave, lane, zb);
+        process(i, za, 0);
+        if (i + 1 >= rend) break;
+        if (i + 2 < rend) sw_load_slice<NW, NCH>(Z + (size_t)(i + 2) * ld, n, wave, lane, za);
+        process(i + 1, zb, 1);
+    }
+    // block partial per column: plane 0 = max, plane 1 = sum of exp(. - max), at part_off + block * 2 ld
+    float* part = partials + pd.part_off + (size_t)blockIdx.x * 2 * ld;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 256 * (wave + NW * c) + 4 * lane;
+        if (col >= n) continue;
+        *reinterpret_cast<f32x4*>(part + col) = cm[c];  // col < n, col % 4 == 0 -> col + 3 < ld (columns >= n are never read)
+        *reinterpret_cast<f32x4*>(part + ld + col) = cs[c];
+    }
+}
+
+template <bool SG, int NW, int NCH>
+__global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+                                                                    const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
+                                                                    const float* __restrict__ rowvec, const float* __restrict__ colvec,
+                                                                    const float* __restrict__ zlogit, float* __restrict__ max0,
+                                                                    int* __restrict__ idx0, float* __restrict__ partials) {
+    __shared__ float xv[2][NW];
+    __shared__ int xi[2][NW];
+    const int p = blockIdx.y;
+    const PairDesc pd = pairs[p];
+    const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
+    const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
+    const int r0 = blockIdx.x * SW_ROWS;
+    if (r0 >= m || !sw_wide_tier<NW>(n)) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ld = pd.ld;
+    const float* Z = zbuf + pd.z_off;
+    const int vec0 = vec_off(s0, 2 * p), vec1 = vec_off(s1, 2 * p + 1);
+    const float NEG = neg_inf();
+    const float norm = SG ? -logf((float)m + (float)n) : 0.f;
+    f32x4 bj[NCH], cj[NCH], cbv[NCH], za[NCH], zb[NCH];
+    int cbi[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 256 * (wave + NW * c) + 4 * lane;
+        bj[c] = cj[c] = za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cbv[c] = f32x4{NEG, NEG, NEG, NEG};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cbi[c][e] = SW_NO_INDEX;
+            if (col + e < n) {
+                bj[c][e] = colvec[vec1 + col + e];
+                if (!SG) cj[c][e] = logsigmoid(zlogit[s1.row_off + col + e]);
+            }
+        }
+    }
+    auto process = [&](int i, const f32x4(&zz)[NCH], int slot) {
+        const float a_i = rowvec[vec0 + i];
+        const float c_i = SG ? 0.f : logsigmoid(zlogit[s0.row_off + i]);
+        float best = NEG;
+        int bidx = SW_NO_INDEX;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = 256 * (wave + NW * c) + 4 * lane;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (col + e < n) {
+                    const float val = assign_value<SG>(zz[c][e], a_i, bj[c][e], norm, c_i, cj[c][e]);
+                    if (val > best) {  // columns ascend within a lane: the first maximum wins
+                        best = val;
+                        bidx = col + e;
+                    }
+                    if (val > cbv[c][e]) {  // rows ascend
+                        cbv[c][e] = val;
+                        cbi[c][e] = i;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int oj = __shfl_xor(bidx, off, 64);
+            if (ob > best || (ob == best && oj < bidx)) {
+                best = ob;
+                bidx = oj;
+            }
+        }
+        if (lane == 0) xv[slot][wave] = best, xi[slot][wave] = bidx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float bv = xv[slot][0];
+            int bi = xi[slot][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const float ov = xv[slot][w];
+                const int oi = xi[slot][w];
+                if (ov > bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            max0[s0.row_off + i] = bv;
+            idx0[s0.row_off + i] = (bi == SW_NO_INDEX) ? 0 : bi;  // all-NaN row: stay in range
+        }
+    };
+    const int rend = (r0 + SW_ROWS < m) ? r0 + SW_ROWS : m;
+    int i = r0;
+    sw_load_slice<NW, NCH>(Z + (size_t)i * ld, n, wave, lane, za);
+#pragma unroll 1
+    for (; i < rend; i += 2) {
+        if (i + 1 < rend) sw_load_slice<NW, NCH>(Z + (size_t)(i + 1) * ld, n, wave, lane, zb);
+        process(i, za, 0);
+        if (i + 1 >= rend) break;
+        if (i + 2 < rend) sw_load_slice<NW, NCH>(Z + (size_t)(i + 2) * ld, n, wave, lane, za);
+        process(i + 1, zb, 1);
+    }
+    // block partial per column: plane 0 = best value, plane 1 = its row (as int bits), at part_off + block * 2 ld
+    float* part = partials + pd.part_off + (size_t)blockIdx.x * 2 * ld;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 256 * (wave + NW * c) + 4 * lane;
+        if (col >= n) continue;
+        *reinterpret_cast<f32x4*>(part + col) = cbv[c];
+        *reinterpret_cast<int4*>(reinterpret_cast<int*>(part) + ld + col) = int4{cbi[c][0], cbi[c][1], cbi[c][2], cbi[c][3]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------------------------------------------
 
 // GTSFM_SWEEP=lds forces the LDS-staged kernels for every width (A/B measurements)
 static bool use_register_rows(int max_n) {
     static const char* which = getenv("GTSFM_SWEEP");
-    return max_n <= SW_MAX_COLS && !(which && which[0] == 'l');
+    return max_n <= SW_WIDE8_COLS && !(which && which[0] == 'l');
 }
 
+// Rows of the score matrix behind one block of column partials (sizes the partials buffer: matcher_api.hip)
+int sweep_partial_rows(int max_n, int ext) { return use_register_rows(max_n) ? SW_ROWS : sweep_rows_per_block(max_n + ext); }
+
 static int chunks_for(int max_n) { return max_n <= 256 ? 1 : max_n <= 512 ? 2 : max_n <= 1024 ? 4 : 8; }
+// register chunks per wave of the wide tiers: the batch's widest pair of the tier decides (3 .. 5)
+static int wide_chunks_for(int max_n, int nw) {
+    const int cap = nw == 4 ? SW_WIDE4_COLS : SW_WIDE8_COLS;
+    const int nch = ceil_div(max_n < cap ? max_n : cap, 256 * nw);
+    return nch < 3 ? 3 : nch;
+}
 
 #define SW_DISPATCH(nch, LAUNCH)    \
     switch (nch) {                  \
@@ -473,6 +824,22 @@ static int chunks_for(int max_n) { return max_n <= 256 ? 1 : max_n <= 512 ? 2 : 
         case 2: { LAUNCH(2); break; } \
         case 4: { LAUNCH(4); break; } \
         default: { LAUNCH(8); break; } \
+    }
+#define SW_DISPATCH_WIDE(nw, nch, LAUNCH)          \
+    {                                              \
+        if ((nw) == 4) {                           \
+            switch (nch) {                         \
+                case 3: { LAUNCH(4, 3); break; }   \
+                case 4: { LAUNCH(4, 4); break; }   \
+                default: { LAUNCH(4, 5); break; }  \
+            }                                      \
+        } else {                                   \
+            switch (nch) {                         \
+                case 3: { LAUNCH(8, 3); break; }   \
+                case 4: { LAUNCH(8, 4); break; }   \
+                default: { LAUNCH(8, 5); break; }  \
+            }                                      \
+        }                                          \
     }
 
 int launch_sinkhorn(const SweepArgs& a, float bin_score, int iters, hipStream_t stream) {
@@ -500,6 +867,12 @@ int launch_sinkhorn(const SweepArgs& a, float bin_score, int iters, hipStream_t 
 #define SW_LAUNCH_SINKHORN(N)                                                                                                          \
     hipLaunchKernelGGL((sinkhorn_rows_kernel<N>), grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, \
                        a.partials, bin_score, pair0)
+#define SW_LAUNCH_SINKHORN_WIDE(NW, N)                                                                                                  \
+    hipLaunchKernelGGL((sinkhorn_rows_wide_kernel<NW, N>), grid_rows, dim3(64 * NW), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, \
+                       a.colvec, a.partials, bin_score, pair0)
+            // every tier the batch can hold; the blocks of pairs of another tier return at once
+            if (a.max_n > SW_WIDE4_COLS) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_SINKHORN_WIDE)
+            if (a.max_n > SW_MAX_COLS) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_SINKHORN_WIDE)
             SW_DISPATCH(nch, SW_LAUNCH_SINKHORN)
             hipLaunchKernelGGL(sinkhorn_cols_kernel, grid_cols, dim3(256), 0, stream, a.pairs, a.seqs, a.counts, a.partials, a.colvec, pair0);
         }
@@ -514,6 +887,10 @@ int launch_double_softmax_lse(const SweepArgs& a, hipStream_t stream) {
     const dim3 grid_rows(ceil_div(a.max_m, SW_ROWS), a.npairs), grid_cols(ceil_div(a.max_n, 256), a.npairs);
 #define SW_LAUNCH_LG(N) \
     hipLaunchKernelGGL((lg_rows_kernel<N>), grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.partials)
+#define SW_LAUNCH_LG_WIDE(NW, N) \
+    hipLaunchKernelGGL((lg_rows_wide_kernel<NW, N>), grid_rows, dim3(64 * NW), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.partials)
+    if (a.max_n > SW_WIDE4_COLS) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_LG_WIDE)
+    if (a.max_n > SW_MAX_COLS) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_LG_WIDE)
     SW_DISPATCH(chunks_for(a.max_n), SW_LAUNCH_LG)
     hipLaunchKernelGGL(lg_cols_kernel, grid_cols, dim3(256), 0, stream, a.pairs, a.seqs, a.counts, a.partials, a.colvec);
     GTSFM_CHECK_LAUNCH("lg_rows/cols_kernel");
@@ -531,9 +908,19 @@ int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogi
 #define SW_LAUNCH_EXTRACT_LG(N)                                                                                                          \
     hipLaunchKernelGGL((extract_rows_kernel<false, N>), grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, \
                        zlogit, max0, idx0, a.partials)
+#define SW_LAUNCH_EXTRACT_SG_WIDE(NW, N)                                                                                                  \
+    hipLaunchKernelGGL((extract_rows_wide_kernel<true, NW, N>), grid_rows, dim3(64 * NW), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, \
+                       a.colvec, zlogit, max0, idx0, a.partials)
+#define SW_LAUNCH_EXTRACT_LG_WIDE(NW, N)                                                                                                   \
+    hipLaunchKernelGGL((extract_rows_wide_kernel<false, NW, N>), grid_rows, dim3(64 * NW), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, \
+                       a.colvec, zlogit, max0, idx0, a.partials)
     if (superglue) {
+        if (a.max_n > SW_WIDE4_COLS) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_EXTRACT_SG_WIDE)
+        if (a.max_n > SW_MAX_COLS) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_EXTRACT_SG_WIDE)
         SW_DISPATCH(chunks_for(a.max_n), SW_LAUNCH_EXTRACT_SG)
     } else {
+        if (a.max_n > SW_WIDE4_COLS) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_EXTRACT_LG_WIDE)
+        if (a.max_n > SW_MAX_COLS) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_EXTRACT_LG_WIDE)
         SW_DISPATCH(chunks_for(a.max_n), SW_LAUNCH_EXTRACT_LG)
     }
     hipLaunchKernelGGL(extract_cols_kernel, grid_cols, dim3(256), 0, stream, a.pairs, a.seqs, a.counts, a.partials, idx1);

@@ -176,11 +176,15 @@ def test_superglue_sinkhorn_iteration_counts(sg_engine, sg_sd, iters):
 
 
 @pytest.mark.parametrize("shapes,iters", [([(257, 300), (1, 5), (300, 255), (64, 1)], 20), ([(2048, 2048), (2047, 1500)], 100),
-                                           ([(700, 513)], 1), ([(2100, 2300)], 20)],
-                         ids=["ragged_small", "n2048_it100", "one_iteration", "wider_than_2048_lds_path"])
+                                           ([(700, 513)], 1), ([(2100, 2300)], 20), ([(1500, 5000), (33, 2049), (40, 3072), (300, 200)], 20),
+                                           ([(64, 5120), (31, 5121), (40, 2048), (65, 7000)], 5), ([(40, 10240), (20, 10241)], 3)],
+                         ids=["ragged_small", "n2048_it100", "one_iteration", "wider_than_2048", "cap5000_mixed_tiers", "eight_wave_tier",
+                              "lds_path_beyond_10240"])
 def test_sinkhorn_standalone_vs_oracle(lib, gpu_device, shapes, iters):
     """The sweep kernels on their own (gtsfm_sinkhorn_f32) against superglue.py:150-170 as restated by the oracle: ragged
-    batches, widths on both sides of the 256-column register chunks, the LDS-staged path beyond 2048 columns."""
+    batches, widths on both sides of the 256-column register chunks, the workgroup-per-row tiers beyond 2048 columns (4 waves
+    to 5120, 8 waves to 10240; GTSfM's cap of 5000 keypoints sits in the first), tier boundaries, batches that mix tiers, the
+    LDS-staged path beyond 10240 columns."""
     from gtsfm_amd.runtime import lib as L
 
     rng = np.random.default_rng(5)
@@ -208,6 +212,38 @@ def test_sinkhorn_standalone_vs_oracle(lib, gpu_device, shapes, iters):
         norm = -np.log(np.float32(mm + nn))
         got = couplings + u[p, : mm + 1, None] + v[p, None, : nn + 1] - norm
         np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4)
+
+
+def test_sinkhorn_batch_composition_does_not_change_a_pair(lib, gpu_device):
+    """Which sweep kernel a pair takes depends on its own width only: a pair alone, next to a wider pair (which adds the
+    workgroup-per-row launches and more register chunks per wave) and next to a narrower one gives the same u, v bit for bit."""
+    from gtsfm_amd.runtime import lib as L
+
+    rng = np.random.default_rng(9)
+
+    def run(shapes, scores):
+        m = np.array([s[0] for s in shapes], dtype=np.int32)
+        n = np.array([s[1] for s in shapes], dtype=np.int32)
+        flat = []
+        for (mm, nn), sc in zip(shapes, scores):
+            z = np.zeros((mm + 1, (nn + 1 + 3) // 4 * 4), dtype=np.float32)
+            z[:mm, :nn] = sc
+            flat.append(z.reshape(-1))
+        z_dev = T(np.concatenate(flat)).to(gpu_device)
+        ws = torch.empty(int(lib.gtsfm_sinkhorn_workspace_bytes(len(shapes), m.ctypes.data, n.ctypes.data)), dtype=torch.uint8, device=gpu_device)
+        u = torch.zeros((len(shapes), int(m.max()) + 1), device=gpu_device)
+        v = torch.zeros((len(shapes), int(n.max()) + 1), device=gpu_device)
+        L.check(lib.gtsfm_sinkhorn_f32(z_dev.data_ptr(), len(shapes), m.ctypes.data, n.ctypes.data, 1.0, 7, ws.data_ptr(), ws.numel(),
+                                       u.data_ptr(), v.data_ptr(), _stream()), "sinkhorn")
+        return u.cpu().numpy(), v.cpu().numpy()
+
+    shapes = [(90, 700), (70, 2600), (50, 4100), (40, 6000)]
+    scores = [(rng.standard_normal(s) * 6.0).astype(np.float32) for s in shapes]
+    u_all, v_all = run(shapes, scores)
+    for q, (mm, nn) in enumerate(shapes):
+        u1, v1 = run([shapes[q]], [scores[q]])
+        np.testing.assert_array_equal(u_all[q, : mm + 1], u1[0, : mm + 1])
+        np.testing.assert_array_equal(v_all[q, : nn + 1], v1[0, : nn + 1])
 
 
 def test_superglue_plugin_contract(gpu_device, sg_sd, tmp_path):
@@ -321,6 +357,53 @@ def test_lightglue_batch_mixed_depths(gpu_device):
         np.testing.assert_array_equal(ms[row : row + a], single["matching_scores0"])
         row += a + b
     assert stops == singles
+
+
+@pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
+def test_batch_mixing_sweep_tiers_equals_single_pairs(gpu_device, matcher):
+    """Score matrices of one batch on both sides of the 2048-column limit of the wave-per-row sweeps: the wide pairs take the
+    workgroup-per-row kernels, the narrow ones the wave-per-row kernels, inside the same launch sequence; every pair equals its
+    stand-alone result bit for bit, and the wide ones equal the oracle."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+
+    specs = [(300, 2600, 51), (2600, 300, 52), (120, 100, 53), (2050, 2049, 54)]
+    feats = [synthetic.synthetic_pair_features(a, b, (768, 1024), (768, 1024), seed=sdd) for a, b, sdd in specs]
+    kp = T(np.concatenate([np.concatenate([f[0], f[3]]) for f in feats])).to(gpu_device)
+    sc = T(np.concatenate([np.concatenate([f[1], f[4]]) for f in feats])).to(gpu_device)
+    de = T(np.concatenate([np.concatenate([f[2], f[5]]) for f in feats])).to(gpu_device)
+    n0, n1 = [s[0] for s in specs], [s[1] for s in specs]
+    hw = [[768, 1024, 768, 1024]] * len(specs)
+    if matcher == "superglue":
+        sd = synthetic.synthetic_superglue_state_dict(num_layers=2)
+        eng = ME.SuperGlueEngine(sd, gpu_device)
+        out = eng.match_batch(kp, sc, de, n0, n1, hw, sinkhorn_iterations=20)
+        single = lambda f: eng.match_pair(f[0], f[1], f[2], f[3], f[4], f[5], (768, 1024), (768, 1024), sinkhorn_iterations=20)  # noqa: E731
+    else:
+        sd = synthetic.synthetic_lightglue_state_dict(num_layers=2, match_bias=-2.0, match_gain=30.0)
+        eng = ME.LightGlueEngine(sd, gpu_device)
+        out = eng.match_batch(kp, de, n0, n1, hw, pruning_threshold=None)
+        single = lambda f: eng.match_pair(f[0], f[2], f[3], f[5], (768, 1024), (768, 1024), pruning_threshold=None)  # noqa: E731
+    m, ms = out["matches"].cpu().numpy(), out["mscores"].cpu().numpy()
+    row = 0
+    for q, ((a, b, _), f) in enumerate(zip(specs, feats)):
+        one = single(f)
+        np.testing.assert_array_equal(m[row : row + a], one["matches0"])
+        np.testing.assert_array_equal(m[row + a : row + a + b], one["matches1"])
+        np.testing.assert_array_equal(ms[row : row + a], one["matching_scores0"])
+        np.testing.assert_array_equal(ms[row + a : row + a + b], one["matching_scores1"])
+        row += a + b
+        if q < 2:
+            with torch.no_grad():
+                if matcher == "superglue":
+                    ora = sgo.superglue_forward(sd, T(f[0])[None], T(f[3])[None], T(f[1])[None], T(f[4])[None], T(f[2]).T[None].contiguous(),
+                                                T(f[5]).T[None].contiguous(), (768, 1024), (768, 1024), sinkhorn_iterations=20)
+                else:
+                    ora = lgo.lightglue_forward(sd, T(f[0])[None], T(f[3])[None], T(f[2])[None], T(f[5])[None], (768, 1024), (768, 1024),
+                                                pruning_threshold=None, return_intermediates=True)
+            np.testing.assert_array_equal(one["matches0"], ora["matches0"][0].numpy())
+            np.testing.assert_array_equal(one["matches1"], ora["matches1"][0].numpy())
+            np.testing.assert_allclose(one["matching_scores0"], ora["matching_scores0"][0].numpy(), rtol=0, atol=SCORE_TOL)
+            assert (one["matches0"] > -1).sum() > 20
 
 
 def test_lightglue_fused_layernorm_epilogue_is_bit_identical(gpu_device, monkeypatch):
