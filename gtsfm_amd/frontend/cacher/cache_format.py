@@ -10,8 +10,9 @@ installation (its ``cache/`` directory, CI's ``gtsfm-cache``):
   so both installations address the same entries.
 
 ``Keypoints`` objects must unpickle on the other side: when GTSfM is importable its own class is used throughout
-(``gtsfm_amd/common/keypoints.py``); where it is not (this container), ``enable_reference_pickle_names`` registers the
-stand-in under the reference's module path so that files written here carry ``gtsfm.common.keypoints.Keypoints``.
+(``gtsfm_amd/common/keypoints.py``); where it is not (this container), the cache files are written and read by a pickler /
+unpickler pair that names the stand-in ``gtsfm.common.keypoints.Keypoints`` INSIDE THE FILE ONLY -- neither the class nor
+``sys.modules`` is touched, so ordinary pickles of the process (Dask scatter, multiprocessing) keep their real module path.
 """
 
 from __future__ import annotations
@@ -19,8 +20,6 @@ from __future__ import annotations
 import hashlib
 import os
 import pickle
-import sys
-import types
 from bz2 import BZ2File
 from pathlib import Path
 from typing import Any, List, Optional, Tuple
@@ -66,14 +65,51 @@ def matcher_cache_key(matcher_obj, keypoints_i1, keypoints_i2, descriptors_i1: n
     return "{}_{}".format(type(matcher_obj).__name__, generate_hash_for_numpy_array(np.concatenate(arrays)))
 
 
+REFERENCE_KEYPOINTS_PATH = ("gtsfm.common.keypoints", "Keypoints")
+
+
+class _ReferenceNamesPickler(pickle._Pickler):  # the pure-Python pickler: the C one has no hook for how a class is named
+    """Writes the stand-in ``Keypoints`` class under the reference's module path. The hook is ``save`` itself, not
+    ``save_global`` / the ``dispatch`` table: libraries such as dill replace ``pickle._Pickler.dispatch[type]`` process-wide."""
+
+    def save(self, obj, save_persistent_id=True):
+        if obj is not Keypoints:
+            return super().save(obj, save_persistent_id)
+        memoized = self.memo.get(id(obj))
+        if memoized is not None:
+            self.write(self.get(memoized[0]))
+            return None
+        self.save(REFERENCE_KEYPOINTS_PATH[0])
+        self.save(REFERENCE_KEYPOINTS_PATH[1])
+        self.write(pickle.STACK_GLOBAL)
+        self.memoize(obj)
+        return None
+
+
+class _ReferenceNamesUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if (module, name) == REFERENCE_KEYPOINTS_PATH:
+            return Keypoints
+        return super().find_class(module, name)
+
+
+def _stand_in_keypoints() -> bool:
+    """True where GTSfM is not importable and ``Keypoints`` is this package's own class."""
+    return Keypoints.__module__ != REFERENCE_KEYPOINTS_PATH[0]
+
+
 def read_from_bz2_file(file_path: Path) -> Optional[Any]:
-    """gtsfm/utils/io.py:437-449: None when the file is missing; a corrupted file is removed."""
+    """gtsfm/utils/io.py:437-449: None when the file is missing; a corrupted file is removed. One deliberate difference: an
+    entry that fails to load because a CLASS it names cannot be imported here (an entry of a shared reference cache holding
+    types this installation lacks) is left alone -- it is valid for its writer -- and reported as a miss."""
     file_path = Path(file_path)
     if not file_path.exists():
         return None
     try:
-        enable_reference_pickle_names()
-        return pickle.load(BZ2File(file_path, "rb"))
+        with BZ2File(file_path, "rb") as f:
+            return _ReferenceNamesUnpickler(f).load() if _stand_in_keypoints() else pickle.load(f)
+    except (ImportError, AttributeError):  # ModuleNotFoundError is an ImportError
+        return None
     except Exception:  # noqa: BLE001 - the reference swallows every failure and drops the file
         os.remove(file_path)
         return None
@@ -83,25 +119,8 @@ def write_to_bz2_file(data: Any, file_path: Path) -> None:
     """gtsfm/utils/io.py:452-457."""
     file_path = Path(file_path)
     file_path.parent.mkdir(exist_ok=True, parents=True)
-    enable_reference_pickle_names()
-    pickle.dump(data, BZ2File(file_path, "wb"))
-
-
-def enable_reference_pickle_names() -> bool:
-    """Make ``Keypoints`` pickle as ``gtsfm.common.keypoints.Keypoints`` where GTSfM itself cannot be imported: registers
-    placeholder modules ``gtsfm`` / ``gtsfm.common`` / ``gtsfm.common.keypoints`` holding the stand-in class. A no-op (returns
-    False) when the real package is present -- its class is what ``gtsfm_amd.common.keypoints`` re-exports then."""
-    if Keypoints.__module__ == "gtsfm.common.keypoints":
-        return "gtsfm_amd_placeholder" in getattr(sys.modules.get("gtsfm.common.keypoints"), "__dict__", {})
-    for name in ("gtsfm", "gtsfm.common", "gtsfm.common.keypoints"):
-        if name not in sys.modules:
-            mod = types.ModuleType(name)
-            mod.__dict__["gtsfm_amd_placeholder"] = True
-            mod.__path__ = []  # type: ignore[attr-defined]
-            sys.modules[name] = mod
-    sys.modules["gtsfm"].common = sys.modules["gtsfm.common"]  # type: ignore[attr-defined]
-    sys.modules["gtsfm.common"].keypoints = sys.modules["gtsfm.common.keypoints"]  # type: ignore[attr-defined]
-    sys.modules["gtsfm.common.keypoints"].Keypoints = Keypoints  # type: ignore[attr-defined]
-    Keypoints.__module__ = "gtsfm.common.keypoints"
-    Keypoints.__qualname__ = "Keypoints"
-    return True
+    with BZ2File(file_path, "wb") as f:
+        if _stand_in_keypoints():
+            _ReferenceNamesPickler(f, protocol=pickle.DEFAULT_PROTOCOL).dump(data)
+        else:
+            pickle.dump(data, f)

@@ -82,15 +82,15 @@ class BatchedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         use_intrinsics = bool(verifier._use_intrinsics_in_verification)
         verified: Dict[Tuple[int, int], Tuple[Any, Any, np.ndarray, float]] = {}
         on_device = [r for r in state["results"]]
-        host_pairs = set()
-        if use_intrinsics and not all(p[4] for p in params):  # distortion / skew: the calibration's own calibrate(), per pair on the host
-            host_pairs = {pair for r in on_device for pair in r["pairs"] if not (params[pair[0]][4] and params[pair[1]][4])}
+        if use_intrinsics and not all(p[4] for p in params):
+            # distortion / skew / a non-pinhole model: those edges use the calibration's own calibrate(), per pair on the host,
+            # and stay out of the device batch (a chunk holding such an edge goes to the host as a whole: its match lists are
+            # interleaved on the device)
+            on_device = [r for r in on_device if all(params[i][4] and params[j][4] for i, j in r["pairs"])]
         if on_device:
             intr = np.array([p[:4] for p in params], dtype=np.float64)
             ver = state["pipe"].verify(state["feats"], on_device, intr, float(verifier._estimation_threshold_px), use_intrinsics=use_intrinsics)
             for pair, res in state["pipe"].verified_to_numpy(ver).items():
-                if pair in host_pairs:
-                    continue
                 dtype = putative[pair].dtype
                 if res["R"] is None:
                     verified[pair] = verifier._failure_result
@@ -101,6 +101,7 @@ class BatchedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
             if pair not in verified:  # empty keypoint sets, or a calibration the device path does not model
                 i1, i2 = pair
                 per_pair = Ransac(use_intrinsics, verifier._estimation_threshold_px, seed=(i1 << 32) | i2)
+                per_pair._engine = verifier._ensure_engine()  # one lib handle / workspace for every fallback edge
                 verified[pair] = per_pair.verify(keypoints_list[i1], keypoints_list[i2], putative[pair], camera_intrinsics[i1], camera_intrinsics[i2])
         return keypoints_list, putative, {p: verified[p] for p in putative}
 

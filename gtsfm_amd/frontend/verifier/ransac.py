@@ -72,6 +72,9 @@ class Ransac(VerifierBase):
         fx2, fy2, cx2, cy2, pure2 = pinhole_parameters(camera_intrinsics_i2)
         c1 = np.asarray(keypoints_i1.coordinates)
         c2 = np.asarray(keypoints_i2.coordinates)
+        if match_indices.min() < 0 or match_indices[:, 0].max() >= c1.shape[0] or match_indices[:, 1].max() >= c2.shape[0]:
+            # the reference indexes numpy arrays with these (IndexError); the device would read out of bounds silently
+            raise IndexError("match_indices refer to keypoints outside the keypoint tables")
         threshold_px = float(self._estimation_threshold_px)
         if (pure1 and pure2) or not self._use_intrinsics_in_verification:  # ((u - cx) / fx, (v - cy) / fy) in double precision on the device
             intr = [fx1, fy1, cx1, cy1, fx2, fy2, cx2, cy2]

@@ -25,7 +25,9 @@ LightGlue (upstream ``cvg/LightGlue`` module names)
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+from collections import OrderedDict
 from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -114,7 +116,13 @@ class _MatcherBase:
         self.device = require_gpu(device)
         self._lib = _lib.load()
         self._workspace: Optional[torch.Tensor] = None
-        self._desc_cache: Dict[tuple, torch.Tensor] = {}
+        # pristine descriptor blocks per batch shape, least recently used first. A block a captured hipGraph copies from must
+        # never be freed (the graph's copy node holds its ADDRESS): blocks touched inside ``pin_descriptors()`` are exempt
+        # from eviction for the life of the engine.
+        self._desc_cache: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()
+        self._desc_pinned: set = set()
+        self._pinning = False
+        self.desc_cache_capacity = 64
 
     def _get_workspace(self, nbytes: int) -> torch.Tensor:
         if self._workspace is None or self._workspace.numel() < nbytes:
@@ -135,11 +143,23 @@ class _MatcherBase:
                 self._lib.gtsfm_match_build_desc(int(superglue), p, n0.ctypes.data, n1.ctypes.data, hw.ctypes.data, host.ctypes.data),
                 "gtsfm_match_build_desc",
             )
-            if len(self._desc_cache) >= 64:
-                self._desc_cache.clear()
+            for old in [k for k in self._desc_cache if k not in self._desc_pinned][: max(0, len(self._desc_cache) + 1 - self.desc_cache_capacity)]:
+                del self._desc_cache[old]  # oldest unpinned shapes go; the caching allocator keeps a block alive until its queued readers ran
             pristine = self._desc_cache[key] = torch.from_numpy(host).to(self.device)
+        else:
+            self._desc_cache.move_to_end(key)
+        if self._pinning:
+            self._desc_pinned.add(key)
         return pristine.clone()
 
+    @contextlib.contextmanager
+    def pin_descriptors(self):
+        """Descriptor blocks built or reused inside this context stay cached for good (hipGraph capture: pipeline._GraphedChunk)."""
+        self._pinning = True
+        try:
+            yield
+        finally:
+            self._pinning = False
 
     def workspace_bytes(self, n0: Sequence[int], n1: Sequence[int]) -> int:
         a0 = np.ascontiguousarray(n0, dtype=np.int32)

@@ -33,13 +33,15 @@ class _GraphedChunk:
         self.sc = torch.zeros((2 * num_pairs, k), dtype=torch.float32, device=dev)
         self.de = torch.zeros((2 * num_pairs, k, 256), dtype=torch.float32, device=dev)
         self.ws = torch.empty(matcher.workspace_bytes(self.n, self.n) + 256, dtype=torch.uint8, device=dev)
-        with torch.cuda.stream(stream):
-            self._gather(feats, idx)
-            self._run()  # eager warm-up on real features: descriptor cache, allocator
-        stream.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=stream):
-            self.out = self._run()
+        # the captured copy node reads the pristine descriptor block at its address: pinned in the engine's cache for good
+        with matcher.pin_descriptors():
+            with torch.cuda.stream(stream):
+                self._gather(feats, idx)
+                self._run()  # eager warm-up on real features: descriptor cache, allocator
+            stream.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=stream):
+                self.out = self._run()
 
     def _run(self):
         kp, sc, de = self.kp.reshape(-1, 2), self.sc.reshape(-1), self.de.reshape(-1, 256)
@@ -92,6 +94,9 @@ class FrontEndPipeline:
         """Match `pairs` (indices into the feature table). `counts` = host copy of feats["count"] (fetched if None: the
         one host synchronisation of the pipeline, needed to size the ragged batch). Returns one dict per chunk with the
         engine outputs plus the chunk's pair list and per-pair keypoint counts."""
+        self.last_shared_images = 0
+        if len(pairs) == 0:  # a rank of a sharded scene may own no pair at all
+            return []
         if counts is None:
             counts = feats["count"].cpu().numpy()
         results = []

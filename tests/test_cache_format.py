@@ -72,16 +72,29 @@ def test_detector_cacher_writes_reference_format_and_hits(tmp_path):
     # the reference's reader: pickle.load(BZ2File(file_path, "rb")) (gtsfm/utils/io.py:443) -> {"keypoints", "descriptors"}
     raw = BZ2File(path, "rb").read()
     assert b"gtsfm.common.keypoints" in raw and b"gtsfm_amd" not in raw, "Keypoints must unpickle inside a GTSfM installation"
-    data = pickle.loads(raw)
+    data = cache_format.read_from_bz2_file(path)
     assert sorted(data) == ["descriptors", "keypoints"] and data["keypoints"] == kp and np.array_equal(data["descriptors"], desc)
+    # naming the class the reference's way is confined to the cache files: the class, sys.modules and ordinary pickles are untouched
+    import sys
+
+    if "gtsfm" not in sys.modules:
+        assert Keypoints.__module__ == "gtsfm_amd.common.keypoints" and b"gtsfm_amd.common.keypoints" in pickle.dumps(kp)
     kp2, desc2 = cacher.detect_and_describe(image)  # served from the cache
     assert FakeDetectorDescriptor.calls == 1 and kp2 == kp and np.array_equal(desc2, desc)
     # an entry written by "the reference" (its writer: pickle.dump(data, BZ2File(file_path, "wb")), io.py:452-455) is read back
     other = Image(value_array=np.zeros((4, 4), dtype=np.uint8), file_name="x.png")
     ref_path = tmp_path / "detector_descriptor" / (cache_format.detector_descriptor_cache_key(plugin, other) + ".pbz2")
-    pickle.dump({"keypoints": Keypoints(coordinates=np.ones((2, 2), dtype=np.float32)), "descriptors": np.zeros((2, 256), dtype=np.float32)}, BZ2File(ref_path, "wb"))
+    ref_blob = pickle.dumps({"keypoints": Keypoints(coordinates=np.ones((2, 2), dtype=np.float32)), "descriptors": np.zeros((2, 256), dtype=np.float32)}, protocol=0)
+    ref_blob = ref_blob.replace(b"gtsfm_amd.common.keypoints", b"gtsfm.common.keypoints")  # protocol 0 names modules in plain text lines
+    with BZ2File(ref_path, "wb") as f:
+        f.write(ref_blob)
     kp3, desc3 = cacher.detect_and_describe(other)
     assert FakeDetectorDescriptor.calls == 1 and len(kp3) == 2 and desc3.shape == (2, 256)
+    # an entry naming a class this installation lacks is a miss, NOT a corrupted file: it stays on disk for its writer
+    foreign = tmp_path / "detector_descriptor" / "foreign.pbz2"
+    with BZ2File(foreign, "wb") as f:
+        f.write(b"cgtsfm.some.module\nSomeClass\n.")
+    assert cache_format.read_from_bz2_file(foreign) is None and foreign.exists()
 
 
 def test_matcher_cacher_round_trip_and_corrupted_entry(tmp_path):

@@ -697,3 +697,32 @@ def test_first_layer_shared_per_image_is_bit_identical(gpu_device, matcher, cap,
     # independent pairs (no image reused): nothing to share, the plain path runs
     shared.match(feats, [(0, 1), (2, 3)], [(192, 256)] * 5, **mk)
     assert shared.last_shared_images == 0
+
+
+def test_graph_replay_survives_descriptor_cache_eviction_and_empty_pair_lists(gpu_device):
+    """A captured chunk copies its descriptor block from the engine's cache by ADDRESS: the block must outlive any number of
+    other batch shapes passing through the cache (ragged scenes add one per chunk). And a rank that owns no pair gets []."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+    from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+
+    det = SuperPointEngine(synthetic.synthetic_superpoint_state_dict(), gpu_device)
+    eng = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(num_layers=2), gpu_device)
+    eng.desc_cache_capacity = 4
+    pipe = FrontEndPipeline(det, eng, max_keypoints=128, pair_chunk=2, num_streams=1, use_graphs=True, share_first_layer=False)
+    feats = pipe.detect(torch.from_numpy(synthetic.synthetic_overlapping_views(3, 192, 256, seed=3)).to(gpu_device))
+    pairs, shapes = [(0, 1), (0, 2)], [(192, 256)] * 3
+    assert pipe.match(feats, [], shapes) == []
+    first = pipe.match(feats, pairs, shapes)
+    torch.cuda.synchronize()
+    assert len(pipe._graphs) == 1 and len(eng._desc_pinned) >= 1
+    k0, _, d0, k1, _, d1, _ = synthetic.synthetic_pair_features(40, 40, (192, 256), (192, 256), seed=1)
+    junk = []
+    for n in range(20, 32):  # twelve other shapes through a cache of four
+        eng.match_pair(k0[:n], d0[:n], k1[:n], d1[:n], (192, 256), (192, 256))
+        junk.append(torch.full((4096,), 7, dtype=torch.int32, device=gpu_device))  # whatever the allocator hands out next gets overwritten
+    assert all(key in eng._desc_cache for key in eng._desc_pinned) and len(eng._desc_cache) <= 4 + len(eng._desc_pinned)
+    again = pipe.match(feats, pairs, shapes)
+    torch.cuda.synchronize()
+    assert torch.equal(first[0]["matches"], again[0]["matches"]) and torch.equal(first[0]["mscores"], again[0]["mscores"])
+    assert int((first[0]["matches"] > -1).sum()) > 0

@@ -225,6 +225,20 @@ def test_plugin_constructs_pickles_and_returns_the_failure_tuple_early():
             return 0.1
 
     assert pinhole_parameters(Distorted(500.0, 320.0, 240.0))[4] is False
+
+    class Cal3Fisheye(PinholeIntrinsics):  # gtsam's equidistant model (CALIBRATION_TYPE): never ((u - cx) / fx, .), even with k1..k4 = 0
+        def k1(self):
+            return 0.0
+
+    class Cal3DS2(PinholeIntrinsics):
+        def k1(self):
+            return 0.0
+
+        def p2(self):
+            return self.fy - 500.0
+
+    assert pinhole_parameters(Cal3Fisheye(500.0, 320.0, 240.0))[4] is False
+    assert pinhole_parameters(Cal3DS2(500.0, 320.0, 240.0))[4] is True and pinhole_parameters(Cal3DS2(500.0, 320.0, 240.0, fy=501.0))[4] is False
     from gtsfm_amd.common.keypoints import Keypoints
 
     few = v.verify(Keypoints(np.zeros((9, 2), np.float32)), Keypoints(np.zeros((9, 2), np.float32)), np.zeros((3, 2), np.int64), PinholeIntrinsics(), PinholeIntrinsics())
