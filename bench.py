@@ -383,6 +383,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the per-kernel roofline micro-launches (for rocprofv3 --kernel-trace runs whose stats should hold the workload's launches only)")
+    ap.add_argument("--dump-matches", type=int, default=0, help="1: add match_digest (SHA-1 over the last step's (K,2) match arrays in pair order) to the line")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help='"nccl" = RCCL; "gloo" only with --plumbing-only')
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no GPU work: random features / matches stand in for the kernels so that the launcher, partitioning, collectives "
@@ -635,6 +636,21 @@ def main() -> None:
             },
             "tflops": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2),
         }
+        if args.dump_matches:
+            import hashlib
+
+            per_pair = gathered if gathered is not None else (matches_to_numpy(res) if res else {})
+            digest = hashlib.sha1()
+            for pair in sorted(per_pair):
+                digest.update(np.asarray(pair, dtype=np.int64).tobytes())
+                digest.update(np.ascontiguousarray(per_pair[pair], dtype=np.int64).tobytes())
+            result["match_digest"] = digest.hexdigest()
+        if dist is not None:
+            result["distributed"] = {
+                "backend": dist.get_backend(), "world_size": world,
+                "collectives": ["broadcast (packed weights)", "barrier", "all_reduce MAX (step time)"]
+                               + (["all_gather_into_tensor (feature table)", "all_gather (ragged match lists)"] if scene else []),
+            }
         if kept_frac < 1.0:
             result["tflops_note"] = (f"upper bound: counted at full width N = {args.keypoints} in every layer; point pruning left "
                                      f"{kept_frac:.3f} of the keypoints alive at the final assignment")

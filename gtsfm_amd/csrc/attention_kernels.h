@@ -23,7 +23,17 @@ struct AttnParams {
     const int* counts;            // device
     float scale;                  // softmax(scale * q k^T)
     int heads;
-    int qtiles, nproblems;        // filled by the launcher
+    // split schedule (one workgroup per query tile AND key segment + a combine kernel; bit-identical to the fused schedule):
+    int max_k;                     // most keys of any problem (0: max_q); sizes the segment dimension of the split grid
+    float* split_workspace;        // device, attention_split_floats(...) floats; nullptr: fused schedule only
+    size_t split_workspace_floats;
+    size_t part_rows;              // rows of the q / out arrays (a segment's partial O is [part_rows][heads * 64])
+    int force_split;               // 0: by launch geometry, 1: always (if more than one segment fits), -1: never
+    int qtiles, nproblems, nseg;   // filled by the launcher
+    float* part_o;                 // "
+    float* part_ml;                // "
 };
 
+// Floats of split workspace the launch (nproblems, heads, max_q, max_k) over `rows` token rows will use; 0 = it runs fused.
+size_t attention_split_floats(int nproblems, int heads, int max_q, int max_k, size_t rows);
 int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t stream);

@@ -6,11 +6,25 @@
 // "head = fast axis" layout is removed by permuting the projection weights at load time).
 //
 // Tiling (head_dim = 64): workgroup = 4 waves = 128 queries of one head of one problem; each wave owns 32 queries and
-// walks the keys in tiles of 64 staged through LDS (K as [key][d], V transposed as [d][key], row stride 68 floats).
+// walks the keys in tiles of 64 that travel global -> LDS by DMA (global_load_lds) into an XOR-swizzled unpadded image.
 // The score tile is computed TRANSPOSED, S^T[key][q] = K Q^T, so that a query is a lane: the softmax row reductions
 // are in-register (+ one cross-half shuffle), and the exponentiated accumulator registers are directly the B operand
-// of the second product O^T[d][q] += V^T[d][key] P^T[key][q] -- no LDS round trip for P, no layout shuffles.
-// Per 64-key tile and wave: 64 + 64 v_mfma_f32_32x32x2_f32.
+// of the second product O^T[d][q] += V^T[d][key] P^T[key][q] -- no LDS round trip for P, no layout shuffles. A second
+// score tile lives in registers so that the softmax of tile t runs in the shadow of the S MFMAs of tile t + 1 inside
+// one wave. Per 64-key tile and wave: 64 + 64 v_mfma_f32_32x32x2_f32. Derivation, LDS-bank argument and the round-1 /
+// round-2 measurements (register-staged predecessor, double-buffered K/V, ...): tools/experimental/attention_dma.hip, DESIGN.md.
+//
+// Key SEGMENTS (round 3). The keys of a problem are cut into segments of AT_SEG_TILES tiles (1024 keys). Every segment runs
+// the online softmax from a FRESH state (O = 0, l = 0, reference maximum from its first tile) and the segments' (O, m, l) are
+// merged in ascending order with one fixed formula (at_merge). Two schedules execute exactly this arithmetic:
+//   fused  (attention_dma_kernel<false>): a workgroup walks all segments of its 128 queries; the running merged O sits in a
+//          32 KiB LDS slab between segments (thread-private slots: no barrier) -- the batched workloads, where problems x
+//          heads x query tiles already fill the chip;
+//   split  (attention_dma_kernel<true> + attention_combine_kernel): one workgroup per (query tile, segment) writes its
+//          unnormalised (O, m, l) to a workspace, a small second kernel merges them -- single pairs (the per-call plugin API:
+//          one pair at N = 2048 is 128 workgroups unsplit on a chip that holds 512).
+// Same operations in the same order on the same values: the two schedules are BIT-IDENTICAL (tests/test_matchers_gpu.py),
+// so which one runs is a pure launch-geometry decision and batched == single-pair results stay bit-exact.
 
 #include <stdlib.h>
 
@@ -18,236 +32,14 @@
 #include "mfma_tiles.h"
 
 #define AT_KT 64       // keys per tile
-#define AT_QW 32       // queries per wave
 #define AT_QB 128      // queries per workgroup
-#define AT_ROW 68      // LDS row stride (floats)
-#define AT_TILE (AT_KT * AT_ROW)
 #define AT_REBASE 8.0f  // rebase the softmax reference when the running maximum moved by more than this (base-2 units)
-
-// Developer timeline (tools/trace_attention.hip builds this file with -DGTSFM_TRACE; the product build has none of it):
-// per wave, shader-clock cycles summed over all key tiles for each segment of the tile loop. The stamps sit where the
-// LDS queue is empty anyway (s_memtime returns through lgkmcnt) and are fenced against instruction motion.
-#ifdef GTSFM_TRACE
-__device__ unsigned long long* g_attn_trace;  // [workgroup][wave][8]: S issue, softmax, PV issue, barrier 1, store + barrier 2, total, hw id, tiles
-#define TRACE_DECL unsigned t_prev = (unsigned)__builtin_amdgcn_s_memtime(); const unsigned t_begin = t_prev; unsigned seg[5] = {0, 0, 0, 0, 0};
-#define TRACE_SEG(k)                                                  \
-    {                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                            \
-        const unsigned t_now = (unsigned)__builtin_amdgcn_s_memtime(); \
-        seg[k] += t_now - t_prev;                                     \
-        t_prev = t_now;                                               \
-        __builtin_amdgcn_sched_barrier(0);                            \
-    }
-#else
-#define TRACE_DECL
-#define TRACE_SEG(k)
+#ifndef AT_SEG_TILES
+#define AT_SEG_TILES 16  // key tiles per segment
 #endif
 
-__global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnParams p) {
-    // LDS: one K tile and one V tile ([key][d], row stride 68; 34 KiB -> three workgroups per CU, which keeps the matrix
-    // pipe fed better than two workgroups with double-buffered tiles: 83 % vs 80 % of peak). While the waves work on
-    // tile t, tile t+1 travels global -> registers (issued before the MFMAs) and is written to LDS after them, between
-    // two barriers: no exposed global latency.
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Ks = lds;
-    float* Vs = lds + AT_TILE;
-    // XCD-aware block order (speed only): workgroups are dispatched round-robin over the 8 XCDs, each with a private
-    // L2. All query tiles of one (problem, head) share the same K / V, so they are given linear ids that are congruent
-    // mod 8 -> same XCD -> K / V are fetched into ONE L2 instead of eight.
-    const int b = blockIdx.x;
-    const int groups = p.heads * p.nproblems;
-    const int k_in_xcd = b >> 3;
-    const int g = (k_in_xcd / p.qtiles) * 8 + (b & 7);
-    if (g >= groups) return;
-    const int h = g % p.heads;
-    const AttnProblem pr = p.problems[g / p.heads];
-    const int nq = p.counts[pr.q_cnt_idx], nk = p.counts[pr.k_cnt_idx];
-    const int q0 = (k_in_xcd % p.qtiles) * AT_QB;
-    if (q0 >= nq) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, kh = lane >> 5;
-    const int qrow = q0 + wave * AT_QW + j;
-    const bool qvalid = qrow < nq;
-
-    // Q fragment (B operand of S^T = K Q^T): lane (q = j, kh) holds Q[q][8t + 4kh .. +3], t = 0..7
-    f32x4 qreg[8];
-    {
-        const float* qp = p.q + (size_t)(pr.q_off + (qvalid ? qrow : 0)) * p.ldq + h * 64 + kh * 4;
-        // softmax runs in the base-2 domain (exp(x) = exp2(x log2 e), one v_exp_f32 per element); the factor
-        // scale * log2(e) is folded into Q once instead of into every score
-        const float scale2 = p.scale * 1.44269504088896340736f;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(qp + t * 8);
-            if (!qvalid) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            qreg[t] = v * scale2;
-        }
-    }
-    f32x16 o0, o1;  // O^T: rows d 0..31 / 32..63, column q
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    float m = 0.f, l = 0.f;  // m: lazy reference maximum (set by the first tile)
-
-    const float* kbase = p.k + (size_t)pr.k_off * p.ldk + h * 64;
-    const float* vbase = p.v + (size_t)pr.k_off * p.ldv + h * 64;
-
-    // staging: thread t moves float4 #(t + 256 i), i = 0..3, of the K tile and of the V tile (64 rows x 16 float4 each)
-    const int srow = tid >> 4, sq = tid & 15;
-    f32x4 kst[4], vst[4];
-    auto stage_load = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = k0 + srow + 16 * i;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (key < nk) {
-                kv = *reinterpret_cast<const f32x4*>(kbase + (size_t)key * p.ldk + sq * 4);
-                vv = *reinterpret_cast<const f32x4*>(vbase + (size_t)key * p.ldv + sq * 4);
-            }
-            kst[i] = kv, vst[i] = vv;
-        }
-    };
-    auto stage_store = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&Ks[(srow + 16 * i) * AT_ROW + sq * 4]) = kst[i];
-            *reinterpret_cast<f32x4*>(&Vs[(srow + 16 * i) * AT_ROW + sq * 4]) = vst[i];
-        }
-    };
-
-    const int ntiles = (nk + AT_KT - 1) / AT_KT;
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-    TRACE_DECL
-    for (int t = 0; t < ntiles; ++t) {
-        const int k0 = t * AT_KT;
-        const float* Kt = Ks;
-        const float* Vt = Vs;
-        if (t + 1 < ntiles) stage_load(k0 + AT_KT);
-
-        // S^T = K Q^T  (two 32-key tiles). The accumulators start at -m (m = reference maximum of this query, see
-        // below), so the MFMA chain delivers s - m directly and the softmax needs no subtraction pass.
-        f32x16 s0, s1;
-        const float neg_m = -m;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = neg_m;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Kt[j * AT_ROW + u * 8 + kh * 4]);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Kt[(32 + j) * AT_ROW + u * 8 + kh * 4]);
-            mt_step(s0, s1, a0, a1, qreg[u]);
-        }
-        TRACE_SEG(0)
-        // Everything between the two MFMA phases is latency-bound VALU / LDS / barrier work that crawls when the other
-        // two waves of the SIMD win the issue arbitration with their MFMAs; while it lasts this wave offers the matrix
-        // pipe nothing. Run it at raised priority so the wave is back to feeding the pipe as soon as possible.
-        __builtin_amdgcn_s_setprio(3);
-        // mask (last tile only)
-        if (k0 + AT_KT > nk) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (key >= nk) s0[r] = -__builtin_inff();
-                if (key + 32 >= nk) s1[r] = -__builtin_inff();
-            }
-        }
-        // Online softmax with a LAZY reference maximum (per query = per lane; the two lane halves hold different keys of
-        // the same query): m follows the running maximum only when that has moved by more than AT_REBASE (base-2 units),
-        // so exp2(s - m) <= 2^AT_REBASE stays far from overflow while most tiles skip the rebase (subtract + rescale of O
-        // and l) entirely. The VALU work of a tile -- which crawls while the other waves of the SIMD keep the matrix
-        // pipe busy -- drops from ~180 to ~90 instructions. out = O / l does not depend on the choice of m.
-        float mloc = fmaxf(s0[0], s1[0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));  // finite on every tile: key k0 is always valid
-        const bool rebase = (t == 0) || (mloc > AT_REBASE);
-        if (__any(rebase)) {  // wave-uniform
-            const float d = rebase ? mloc : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s0[r] -= d;
-                s1[r] -= d;
-            }
-            if (t > 0) {  // (first tile: O = l = 0 and m = 0)
-                const float alpha = __builtin_amdgcn_exp2f(-d);
-                l *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    o0[r] *= alpha;
-                    o1[r] *= alpha;
-                }
-            }
-            m += d;
-        }
-        float lsum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r]);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r]);
-            lsum += s0[r] + s1[r];
-        }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l += lsum;
-        __builtin_amdgcn_s_setprio(0);
-        TRACE_SEG(1)
-        // O^T += V^T P^T. Accumulator register r of S^T tile T holds key 32T + (r&3) + 8(r>>2) + 4kh, so it IS the B
-        // operand of k-step r; the A operand V^T[d = lane][key] is a conflict-free row read of the row-major V tile.
-#pragma unroll
-        for (int T = 0; T < 2; ++T) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int key = 32 * T + 8 * g + 4 * kh;
-                f32x4 a0, a1, b;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a0[e] = Vt[(key + e) * AT_ROW + j];
-                    a1[e] = Vt[(key + e) * AT_ROW + 32 + j];
-                    b[e] = T ? s1[4 * g + e] : s0[4 * g + e];
-                }
-                mt_step(o0, o1, a0, a1, b);
-            }
-        }
-        TRACE_SEG(2)
-        if (t + 1 < ntiles) {
-            __builtin_amdgcn_s_setprio(3);
-            __syncthreads();
-            TRACE_SEG(3)
-            stage_store(0);
-            __syncthreads();
-            __builtin_amdgcn_s_setprio(0);
-            TRACE_SEG(4)
-        }
-    }
-#ifdef GTSFM_TRACE
-    if (lane == 0 && g_attn_trace) {
-        unsigned long long* o = g_attn_trace + ((size_t)blockIdx.x * 4 + wave) * 8;
-        for (int k = 0; k < 5; ++k) o[k] = seg[k];
-        o[5] = (unsigned)__builtin_amdgcn_s_memtime() - t_begin;
-        o[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
-        o[7] = ntiles;
-    }
-#endif
-
-    if (!qvalid) return;
-    const float inv = (l > 0.f) ? 1.0f / l : 0.f;
-    float* op = p.out + (size_t)(pr.q_off + qrow) * p.ldo + h * 64 + kh * 4;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 v0 = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
-        const f32x4 v1 = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
-        *reinterpret_cast<f32x4*>(op + 8 * g) = v0;
-        *reinterpret_cast<f32x4*>(op + 32 + 8 * g) = v1;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Default kernel since round 2 (GTSFM_ATTENTION=mfma selects the one above): K / V tiles by LDS-DMA into an XOR-swizzled unpadded image and a second
-// score tile in the freed registers, so that the softmax of tile t runs in the shadow of the S MFMAs of tile t + 1
-// inside one wave. Derivation, LDS-bank argument and round-1 status: tools/experimental/attention_dma.hip.
-// ---------------------------------------------------------------------------------------------------------------
 #define ATD_TILE_FLOATS (AT_KT * 64)
+#define ATD_OC_FLOATS (34 * 256)  // merged state between segments: 32 accumulator registers + (m, l), x 256 threads
 #ifndef ATD_WGS_PER_CU
 #define ATD_WGS_PER_CU 2
 #endif
@@ -263,30 +55,60 @@ __device__ __forceinline__ void mfma8(f32x16& acc0, f32x16& acc1, const f32x4 a0
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
 }
 
+// THE merge of two softmax partial states over disjoint key sets, (O, m, l) <- (O, m, l) (+) (Os, ms, ls): m are reference
+// exponents (base 2), O = sum 2^(s - m) v, l = sum 2^(s - m). Both the fused kernel and the combine kernel of the split
+// schedule call exactly this (explicitly rounded products and sum: no contraction can tell them apart).
+struct AtMergeWeights {
+    float a, b, m;
+};
+__device__ __forceinline__ AtMergeWeights at_merge_weights(float m, float ms) {
+    AtMergeWeights w;
+    w.m = fmaxf(m, ms);
+    w.a = __builtin_amdgcn_exp2f(m - w.m);   // one of the two is exp2(0) = 1 exactly
+    w.b = __builtin_amdgcn_exp2f(ms - w.m);
+    return w;
+}
+__device__ __forceinline__ float at_merge(float acc, float seg, const AtMergeWeights& w) {
+    return __fadd_rn(__fmul_rn(acc, w.a), __fmul_rn(seg, w.b));
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Ks = lds;                // [64 keys][64 floats], swizzled
+    float* Ks = lds;                    // [64 keys][64 floats], swizzled
     float* Vs = lds + ATD_TILE_FLOATS;  // same
-    // XCD-aware block order as in attention_mfma_kernel
+    float* Oc = lds + 2 * ATD_TILE_FLOATS;  // fused schedule only: this thread's merged O of the segments done so far
+    // XCD-aware block order (speed only): workgroups are dispatched round-robin over the 8 XCDs, each with a private L2. All
+    // query tiles (and segments) of one (problem, head) share the same K / V, so they get linear ids that are congruent
+    // mod 8 -> same XCD -> K / V are fetched into ONE L2 instead of eight.
     const int b = blockIdx.x;
     const int groups = p.heads * p.nproblems;
     const int k_in_xcd = b >> 3;
-    const int g = (k_in_xcd / p.qtiles) * 8 + (b & 7);
+    const int per_group = SPLIT ? p.qtiles * p.nseg : p.qtiles;
+    const int g = (k_in_xcd / per_group) * 8 + (b & 7);
     if (g >= groups) return;
+    const int within = k_in_xcd % per_group;  // split: segment-major, the query tiles of one segment run side by side
+    const int seg_of_wg = SPLIT ? within / p.qtiles : 0;
     const int h = g % p.heads;
     const AttnProblem pr = p.problems[g / p.heads];
     const int nq = p.counts[pr.q_cnt_idx], nk = p.counts[pr.k_cnt_idx];
-    const int q0 = (k_in_xcd % p.qtiles) * AT_QB;
+    const int q0 = (SPLIT ? within % p.qtiles : within) * AT_QB;
     if (q0 >= nq) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, kh = lane >> 5;
     const int qrow = q0 + wave * 32 + j;
     const bool qvalid = qrow < nq;
+    const int ntiles = (nk + AT_KT - 1) / AT_KT;
+    const int t_begin = SPLIT ? seg_of_wg * AT_SEG_TILES : 0;
+    const int t_end = SPLIT ? (ntiles < t_begin + AT_SEG_TILES ? ntiles : t_begin + AT_SEG_TILES) : ntiles;
+    if (SPLIT && t_begin >= ntiles) return;  // this problem has fewer segments than the widest of the launch (or no keys: combine writes zeros)
 
-    f32x4 qreg[8];  // Q fragment, pre-scaled by scale * log2(e) (base-2 softmax)
+    f32x4 qreg[8];  // Q fragment (B operand of S^T = K Q^T): lane (q = j, kh) holds Q[q][8t + 4kh .. +3], pre-scaled by scale * log2(e)
     {
         const float* qp = p.q + (size_t)(pr.q_off + (qvalid ? qrow : 0)) * p.ldq + h * 64 + kh * 4;
+        // softmax runs in the base-2 domain (exp(x) = exp2(x log2 e), one v_exp_f32 per element); the factor
+        // scale * log2(e) is folded into Q once instead of into every score
         const float scale2 = p.scale * 1.44269504088896340736f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -297,8 +119,7 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
     }
     const float* kbase = p.k + (size_t)pr.k_off * p.ldk + h * 64;
     const float* vbase = p.v + (size_t)pr.k_off * p.ldv + h * 64;
-    const int ntiles = (nk + AT_KT - 1) / AT_KT;
-    if (nk <= 0) {  // no keys: the output rows are zero (as attention_mfma_kernel); uniform for the workgroup
+    if (!SPLIT && nk <= 0) {  // no keys: the output rows are zero; uniform for the workgroup
         if (qvalid) {
             float* op = p.out + (size_t)(pr.q_off + qrow) * p.ldo + h * 64 + kh * 32;
             for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(op + 4 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -307,15 +128,18 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
     }
 
     // DMA of one 64 x 64 tile: 16 instructions per workgroup, 4 per wave; instruction i of wave w covers rows
-    // 16 w + 4 i .. + 3; lane l writes position l % 16 of row (l / 16) and fetches chunk (l % 16) ^ (row & 15)
+    // 16 i + 4 w .. + 3; lane l writes position l % 16 of row (l / 16) and fetches chunk (l % 16) ^ (row & 15). With this row
+    // assignment row & 15 = 4 w + l / 16 is the same for a lane's four instructions: ONE swizzled column offset per lane
+    // (round 2 had rows 16 w + 4 i: four 64-bit address registers pairs per tensor, the kernel sits at the register ceiling)
     const int drow = lane >> 4, dpos = lane & 15;
+    const int dma_col = (dpos ^ ((4 * wave + drow) & 15)) << 2;
     auto tile_dma = [&](const float* base, int ld, int k0, float* dst) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int rb = 16 * wave + 4 * i, r = rb + drow;
-            int key = k0 + r;
+            const int rb = 16 * i + 4 * wave;
+            int key = k0 + rb + drow;
             key = key < nk ? key : nk - 1;  // clamp: keys beyond nk are masked to -inf (their V rows meet P = 0)
-            __builtin_amdgcn_global_load_lds(base + (size_t)key * ld + ((dpos ^ (r & 15)) << 2), dst + rb * 64, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(base + (size_t)key * ld + dma_col, dst + rb * 64, 16, 0, 0);
         }
     };
     auto kfrag = [&](int row, int u) {  // floats 8 u + 4 kh .. + 3 of key row `row`
@@ -329,35 +153,38 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
         for (int u = 0; u < 8; ++u) mfma8(s0, s1, kfrag(j, u), kfrag(32 + j, u), qreg[u]);
     };
 
-    f32x16 o0, o1;
+    f32x16 o0, o1;  // O^T of the CURRENT segment: rows d 0..31 / 32..63, column q
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    float m = 0.f, l = 0.f;  // lazy reference maximum and running denominator, as in attention_mfma_kernel
-    f32x16 sc0, sc1;         // score tile being soft-maxed
-    f32x16 sn0, sn1;         // score tile being accumulated
+    float m = 0.f, l = 0.f;  // current segment: lazy reference maximum (set by the segment's first tile) and running denominator
+    f32x16 sc0, sc1;           // score tile being soft-maxed
+    f32x16 sn0, sn1;           // score tile being accumulated
 
-    // prologue: K(0) -> S(0); then K(1) and V(0) in flight
-    tile_dma(kbase, p.ldk, 0, Ks);
+    // prologue: K(t_begin) -> S; then the next K tile and V(t_begin) in flight
+    tile_dma(kbase, p.ldk, t_begin * AT_KT, Ks);
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     __syncthreads();
     s_phase(sc0, sc1, 0.f);
-    __syncthreads();  // every wave is done reading K(0)
-    if (ntiles > 1) tile_dma(kbase, p.ldk, AT_KT, Ks);
-    tile_dma(vbase, p.ldv, 0, Vs);
+    __syncthreads();  // every wave is done reading the first K tile
+    if (t_begin + 1 < t_end) tile_dma(kbase, p.ldk, (t_begin + 1) * AT_KT, Ks);
+    tile_dma(vbase, p.ldv, t_begin * AT_KT, Vs);
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
 
     // (A variant with the S MFMAs and the softmax VALU arranged in shared straight-line blocks -- rebase branches moved
     // between two halves of the S phase -- was measured in round 2: 256 registers, 495 vs 499 image-pairs/s in the
     // workload, not kept.)
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
         const int k0 = t * AT_KT;
-        const bool more = t + 1 < ntiles;
+        const int ts = t % AT_SEG_TILES;  // tile index inside its segment (t_begin is a multiple of AT_SEG_TILES)
+        const bool more = t + 1 < t_end;
+        const bool next_fresh = !SPLIT && more && ts == AT_SEG_TILES - 1;  // fused: the next tile opens a new segment
         // ---- phase 1: S(t+1) MFMAs in whose shadow the softmax of tile t runs
         // (the reference maximum used for S(t+1)'s accumulator start is the one BEFORE tile t's possible rebase; the
-        // difference is applied below when that tile is soft-maxed: its own rebase test sees scores relative to the old m)
+        // difference is applied below when that tile is soft-maxed: its own rebase test sees scores relative to the old m.
+        // A tile that opens a segment starts from reference 0, like the very first one.)
         const float m_start = m;
-        if (more) s_phase(sn0, sn1, -m_start);
+        if (more) s_phase(sn0, sn1, next_fresh ? 0.f : -m_start);
         if (k0 + AT_KT > nk) {  // mask (last tile only)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -366,11 +193,15 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
                 if (key + 32 >= nk) sc1[r] = -__builtin_inff();
             }
         }
+        // Online softmax with a LAZY reference maximum (per query = per lane; the two lane halves hold different keys of
+        // the same query): m follows the running maximum only when that has moved by more than AT_REBASE (base-2 units),
+        // so exp2(s - m) <= 2^AT_REBASE stays far from overflow while most tiles skip the rebase (subtract + rescale of O
+        // and l) entirely. out = O / l does not depend on the choice of m.
         float mloc = fmaxf(sc0[0], sc1[0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(sc0[r], sc1[r]));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const bool rebase = (t == 0) || (mloc > AT_REBASE);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));  // finite on every tile: key k0 is always valid
+        const bool rebase = (ts == 0) || (mloc > AT_REBASE);
         float d = 0.f;
         if (__any(rebase)) {  // wave-uniform
             d = rebase ? mloc : 0.f;
@@ -379,7 +210,7 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
                 sc0[r] -= d;
                 sc1[r] -= d;
             }
-            if (t > 0) {
+            if (ts > 0) {  // (a segment's first tile: O = l = 0 and m = 0)
                 const float alpha = __builtin_amdgcn_exp2f(-d);
                 l *= alpha;
 #pragma unroll
@@ -400,7 +231,7 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
         lsum += __shfl_xor(lsum, 32, 64);
         l += lsum;
         // the next tile was accumulated relative to m_start; bring it to the (possibly rebased) reference
-        if (more && __any(d != 0.f)) {
+        if (more && !next_fresh && __any(d != 0.f)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 sn0[r] -= d;
@@ -409,8 +240,9 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);  // own V(t) DMA landed (issued one phase ago)
         __syncthreads();                     // B1: K buffer free, V(t) visible
-        if (t + 2 < ntiles) tile_dma(kbase, p.ldk, k0 + 2 * AT_KT, Ks);
-        // ---- phase 2: O^T += V^T P^T
+        if (t + 2 < t_end) tile_dma(kbase, p.ldk, k0 + 2 * AT_KT, Ks);
+        // ---- phase 2: O^T += V^T P^T. Accumulator register r of S^T tile T holds key 32T + (r&3) + 8(r>>2) + 4kh, so it IS
+        // the B operand of k-step r; the A operand V^T[d = lane][key] is a conflict-free read of the swizzled V tile.
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
 #pragma unroll
@@ -432,8 +264,45 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
             tile_dma(vbase, p.ldv, k0 + AT_KT, Vs);
             sc0 = sn0, sc1 = sn1;
         }
+        // ---- fused schedule, end of a segment: fold (O, m, l) into the merged state. The merged O waits in LDS (each thread
+        // reads and writes only its own 32 slots, so no barrier is involved) while the registers serve the next segment.
+        if (!SPLIT && (next_fresh || (!more && t >= AT_SEG_TILES))) {
+            if (t >= AT_SEG_TILES) {  // not the first segment: merged <- merged (+) this segment
+                const AtMergeWeights w = at_merge_weights(Oc[32 * 256 + tid], m);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o0[r] = at_merge(Oc[r * 256 + tid], o0[r], w);
+                    o1[r] = at_merge(Oc[(16 + r) * 256 + tid], o1[r], w);
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // eight LDS values in flight at a time: the kernel sits at the register ceiling
+                }
+                l = at_merge(Oc[33 * 256 + tid], l, w);
+                m = w.m;
+            }
+            if (more) {  // park the merged state (O, m, l) and start the next segment from a fresh one
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    Oc[r * 256 + tid] = o0[r];
+                    Oc[(16 + r) * 256 + tid] = o1[r];
+                    o0[r] = o1[r] = 0.f;
+                }
+                Oc[32 * 256 + tid] = m;
+                Oc[33 * 256 + tid] = l;
+                m = 0.f, l = 0.f;
+            }
+        }
     }
     if (!qvalid) return;
+    if (SPLIT) {  // this segment's unnormalised state; attention_combine_kernel merges the segments
+        const size_t row = (size_t)seg_of_wg * p.part_rows + pr.q_off + qrow;
+        float* po = p.part_o + row * (p.heads * 64) + h * 64 + kh * 4;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            *reinterpret_cast<f32x4*>(po + 8 * gq) = f32x4{o0[4 * gq], o0[4 * gq + 1], o0[4 * gq + 2], o0[4 * gq + 3]};
+            *reinterpret_cast<f32x4*>(po + 32 + 8 * gq) = f32x4{o1[4 * gq], o1[4 * gq + 1], o1[4 * gq + 2], o1[4 * gq + 3]};
+        }
+        if (kh == 0) *reinterpret_cast<float2*>(p.part_ml + (row * p.heads + h) * 2) = float2{m, l};
+        return;
+    }
     const float inv = (l > 0.f) ? 1.0f / l : 0.f;
     float* op = p.out + (size_t)(pr.q_off + qrow) * p.ldo + h * 64 + kh * 4;
 #pragma unroll
@@ -443,24 +312,82 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
     }
 }
 
+// Split schedule, second kernel: out[q][h] = merge of the segments' (O, m, l) in ascending order / l. One thread per
+// (query, head, float4 of the 64 channels): 4 queries per workgroup.
+__global__ __launch_bounds__(256) void attention_combine_kernel(AttnParams p) {
+    const AttnProblem pr = p.problems[blockIdx.y];
+    const int nq = p.counts[pr.q_cnt_idx], nk = p.counts[pr.k_cnt_idx];
+    const int qrow = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qrow >= nq) return;
+    const int lane = threadIdx.x & 63, h = lane >> 4, c = lane & 15;
+    if (h >= p.heads) return;
+    const int ntiles = (nk + AT_KT - 1) / AT_KT;
+    const int nseg = (ntiles + AT_SEG_TILES - 1) / AT_SEG_TILES;
+    const size_t row = (size_t)pr.q_off + qrow;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    float m = 0.f, l = 0.f;
+    for (int s = 0; s < nseg; ++s) {
+        const size_t prow = (size_t)s * p.part_rows + row;
+        const f32x4 os = *reinterpret_cast<const f32x4*>(p.part_o + prow * (p.heads * 64) + h * 64 + c * 4);
+        const float2 ml = *reinterpret_cast<const float2*>(p.part_ml + (prow * p.heads + h) * 2);
+        if (s == 0) {
+            o = os, m = ml.x, l = ml.y;
+        } else {
+            const AtMergeWeights w = at_merge_weights(m, ml.x);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = at_merge(o[e], os[e], w);
+            l = at_merge(l, ml.y, w);
+            m = w.m;
+        }
+    }
+    const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+    *reinterpret_cast<f32x4*>(p.out + row * p.ldo + h * 64 + c * 4) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+}
+
+static int at_segments(int max_k) { return ceil_div(ceil_div(max_k < 1 ? 1 : max_k, AT_KT), AT_SEG_TILES); }
+
+// The split schedule pays one extra round trip of O through the workspace; it is chosen when the unsplit launch would not fill
+// the chip's workgroup slots (256 CUs x ATD_WGS_PER_CU) twice and the keys span more than one segment. Measured (MI355X,
+// tools/bench_attention.py, fraction of the fp32 MFMA peak, fused -> split): one pair at N = 2048 (128 workgroups) 0.36 -> 0.63,
+// one pair at N = 5000 (320) 0.51 -> 0.70, two pairs at N = 5000 (640) 0.67 -> 0.76, two pairs at N = 2048 (256) 0.71 -> 0.72;
+// 32 pairs at N = 2048 (4096) 0.84 -> 0.81 and 8 pairs at N = 5000 (2560) 0.82 -> 0.79: batches stay fused. The segment
+// structure itself costs the fused schedule 0.2 % (A/B against a build with one unbounded segment).
+static bool at_wants_split(int nproblems, int heads, int max_q, int max_k) {
+    const char* env = getenv("GTSFM_ATTENTION_SPLIT");  // "0": never, "1": whenever there is more than one segment (read per launch: tests toggle it)
+    if (at_segments(max_k) < 2 || (env && env[0] == '0')) return false;
+    if (env && env[0] == '1') return true;
+    return (long long)nproblems * heads * ceil_div(max_q, AT_QB) < 2 * 256 * ATD_WGS_PER_CU;
+}
+
+size_t attention_split_floats(int nproblems, int heads, int max_q, int max_k, size_t rows) {
+    if (nproblems <= 0 || !at_wants_split(nproblems, heads, max_q, max_k)) return 0;
+    return (size_t)at_segments(max_k) * rows * ((size_t)heads * 64 + (size_t)heads * 2);
+}
 
 int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t stream) {
     GTSFM_CHECK_ARG(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, "attention: leading dimensions must be multiples of 4");
-    GTSFM_CHECK_ARG(p.heads > 0, "attention: heads must be positive");
+    GTSFM_CHECK_ARG(p.heads > 0 && p.heads <= 4, "attention: 1 to 4 heads");
     if (nproblems <= 0 || max_q <= 0) return GTSFM_OK;
     AttnParams q = p;
     q.qtiles = ceil_div(max_q, AT_QB);
     q.nproblems = nproblems;
     const int groups = p.heads * nproblems;
-    dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles);
-    // Default since round 2: the LDS-DMA kernel. In isolation both reach 84-85 % of the fp32 MFMA peak at N = 2048; inside
-    // the detect+match workload (two streams) the DMA kernel is 1.2 % faster end to end (501 vs 495 image-pairs/s, A/B run twice,
-    // profiles/r02_attention_ab.txt). GTSFM_ATTENTION=mfma selects the register-staged kernel of round 1.
-    static const char* which = getenv("GTSFM_ATTENTION");
-    if (which && which[0] == 'm')
-        hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(256), (size_t)2 * AT_TILE * sizeof(float), stream, q);
-    else
-        hipLaunchKernelGGL(attention_dma_kernel, grid, dim3(256), (size_t)2 * ATD_TILE_FLOATS * sizeof(float), stream, q);
+    const int max_k = p.max_k > 0 ? p.max_k : max_q;
+    const bool split = p.split_workspace != nullptr && (p.force_split > 0 || (p.force_split == 0 && at_wants_split(nproblems, p.heads, max_q, max_k)));
+    if (split) {
+        q.nseg = at_segments(max_k);
+        const size_t need = (size_t)q.nseg * p.part_rows * ((size_t)p.heads * 64 + (size_t)p.heads * 2);
+        GTSFM_CHECK_ARG(p.part_rows > 0 && p.split_workspace_floats >= need, "attention: split workspace too small (%zu < %zu floats)", p.split_workspace_floats, need);
+        q.part_o = p.split_workspace;
+        q.part_ml = p.split_workspace + (size_t)q.nseg * p.part_rows * p.heads * 64;
+        dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles * q.nseg);
+        hipLaunchKernelGGL((attention_dma_kernel<true>), grid, dim3(256), (size_t)2 * ATD_TILE_FLOATS * sizeof(float), stream, q);
+        hipLaunchKernelGGL(attention_combine_kernel, dim3(ceil_div(max_q, 4), nproblems), dim3(256), 0, stream, q);
+    } else {
+        q.nseg = 1;
+        dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles);
+        hipLaunchKernelGGL((attention_dma_kernel<false>), grid, dim3(256), (size_t)(2 * ATD_TILE_FLOATS + ATD_OC_FLOATS) * sizeof(float), stream, q);
+    }
     GTSFM_CHECK_LAUNCH("attention kernel");
     return GTSFM_OK;
 }

@@ -186,10 +186,25 @@ extern "C" int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* 
 extern "C" int gtsfm_attention_f32(const float* q_dev, int ldq, const float* k_dev, int ldk, const float* v_dev, int ldv, float* out_dev,
                                    int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems, int max_q, int heads,
                                    float scale, void* stream) {
+    return gtsfm_attention_split_f32(q_dev, ldq, k_dev, ldk, v_dev, ldv, out_dev, ldo, problems_dev, counts_dev, nproblems, max_q, max_q, heads, scale, -1,
+                                     0, nullptr, 0, stream);
+}
+
+extern "C" size_t gtsfm_attention_split_workspace_bytes(int max_k, int heads, size_t rows) {
+    // the split schedule holds one unnormalised O row + (m, l) per head, per key segment and token row
+    const int nseg = (((max_k < 1 ? 1 : max_k) + 63) / 64 + 15) / 16;
+    return (size_t)nseg * rows * ((size_t)heads * 64 + (size_t)heads * 2) * sizeof(float);
+}
+
+extern "C" int gtsfm_attention_split_f32(const float* q_dev, int ldq, const float* k_dev, int ldk, const float* v_dev, int ldv, float* out_dev,
+                                         int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems, int max_q, int max_k,
+                                         int heads, float scale, int mode, size_t rows, void* workspace_dev, size_t workspace_bytes, void* stream) {
     GTSFM_CHECK_ARG(q_dev && k_dev && v_dev && out_dev && problems_dev && counts_dev, "attention: null pointer");
-    AttnParams p;
+    GTSFM_CHECK_ARG(mode >= -1 && mode <= 1, "attention: mode is -1 (fused), 0 (by launch geometry) or 1 (split)");
+    AttnParams p = {};
     p.q = q_dev, p.ldq = ldq, p.k = k_dev, p.ldk = ldk, p.v = v_dev, p.ldv = ldv, p.out = out_dev, p.ldo = ldo;
     p.problems = (const AttnProblem*)problems_dev, p.counts = counts_dev, p.scale = scale, p.heads = heads;
+    p.max_k = max_k, p.force_split = mode, p.split_workspace = (float*)workspace_dev, p.split_workspace_floats = workspace_bytes / sizeof(float), p.part_rows = rows;
     return launch_attention(p, nproblems, max_q, (hipStream_t)stream);
 }
 
@@ -224,7 +239,7 @@ BatchDims batch_dims(int P, const int32_t* n0, const int32_t* n1, int ext) {
 }
 
 struct SgWorkspace {
-    size_t enc_in, ka, kb, x, qkv, mlp, md, pack, z, part, uv_row, uv_col, max0, idx0, idx1, total;
+    size_t enc_in, ka, kb, x, qkv, mlp, md, pack, z, part, uv_row, uv_col, max0, idx0, idx1, attn, attn_floats, total;
 };
 
 SgWorkspace sg_workspace_layout(const BatchDims& d) {
@@ -251,6 +266,8 @@ SgWorkspace sg_workspace_layout(const BatchDims& d) {
     w.max0 = take(T);
     w.idx0 = take(T);
     w.idx1 = take(T);
+    w.attn_floats = attention_split_floats(2 * d.P, 4, d.max_n, d.max_n, T);  // 0 unless the batch is small enough for the split schedule
+    w.attn = take(w.attn_floats);
     w.total = o;
     return w;
 }
@@ -338,10 +355,11 @@ static int sg_forward_phased(const float* wts, int num_layers, float bin_score, 
     // attentional GNN (superglue.py:122-138): alternating self / cross layers, both images per launch
     for (int l = (phase == 2 ? 1 : 0); l < (phase == 1 ? 1 : num_layers); ++l) {
         TRY(gemm(X, 512, 256, 768, QKV, 768, 0, nullptr, 0, 0));
-        AttnParams ap;
+        AttnParams ap = {};
         // the attention output lands in the second half of cat([x, .]); attn.merge is folded into mlp.0 at load time
         ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = X + 256, ap.ldo = 512;
         ap.problems = (l % 2 == 0) ? self_p : cross_p, ap.counts = counts, ap.scale = 0.125f, ap.heads = 4;
+        ap.max_k = d.max_n, ap.split_workspace = (float*)(wsp + ws.attn), ap.split_workspace_floats = ws.attn_floats, ap.part_rows = T;
         TRY(launch_attention(ap, 2 * npairs, d.max_n, stream));
         TRY(gemm(X, 512, 512, 512, MLP, 512, 0, nullptr, 0, 1));       // mlp.0 (+BN, merge folded) + ReLU
         TRY(gemm(MLP, 512, 512, 256, X, 512, 0, X, 512, 0));           // mlp.3, desc += delta
@@ -514,7 +532,7 @@ LgDims lg_dims(int P, const int32_t* n0, const int32_t* n1) {
 
 struct LgWorkspace {
     size_t xa, xb, qkv, mlp, md, enca, encb, inda, indb, indf, conf, mval, z_logit, pos, pack, z, part, uv_row, uv_col, max0, idx0, idx1,
-        m_int, ms_int, total;
+        m_int, ms_int, attn, attn_floats, total;
 };
 
 LgWorkspace lg_workspace_layout(const LgDims& d) {
@@ -532,6 +550,8 @@ LgWorkspace lg_workspace_layout(const LgDims& d) {
     w.pack = take(d.pack_floats), w.z = take(d.z_floats), w.part = take(d.part_floats);
     w.uv_row = take(T + 16 * d.P + 8), w.uv_col = take(T + 16 * d.P + 8);
     w.max0 = take(T), w.idx0 = take(T), w.idx1 = take(T), w.m_int = take(T), w.ms_int = take(T);
+    w.attn_floats = attention_split_floats(2 * d.P, 4, d.max_n, d.max_n, T);  // 0 unless the batch is small enough for the split schedule
+    w.attn = take(w.attn_floats);
     w.total = o;
     return w;
 }
@@ -648,10 +668,11 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
     TRY(launch_lg_posenc(kpts_dev, seqs, live, nseq, d.max_n, Wr, enc, stream));
 
     for (int l = 0; l < num_layers; ++l) {
-        AttnParams ap;
+        AttnParams ap = {};
         // the attention context lands in the second half of cat([x, .]); out_proj / to_out are folded into ffn.0 at load time
         ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = X + 256, ap.ldo = 512;
         ap.counts = live, ap.scale = 0.125f, ap.heads = 4;
+        ap.max_k = d.max_n, ap.split_workspace = (float*)(wsp + ws.attn), ap.split_workspace_floats = ws.attn_floats, ap.part_rows = d.Tp;
         if (l == 0 && phase == 2) {  // the first self block was run per image (phase 1): step over its weights
             const float *w, *b, *raw;
             cur.linear(768, 256, &w, &b, &raw), cur.linear(512, 512, &w, &b, &raw);

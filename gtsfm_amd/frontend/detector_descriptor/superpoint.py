@@ -69,12 +69,14 @@ class SuperPointDetectorDescriptor(DetectorDescriptorBase):
         gray = rgb_to_gray_u8(image.value_array)
         if gray.dtype != np.uint8:  # the reference computes astype(float32) / 255.0 whatever the input dtype
             gray = gray.astype(np.float32) / 255.0
-        xy, responses, descriptors = self._model.detect(np.ascontiguousarray(gray))
+        xy, responses, fetch_descriptors = self._model.detect_lazy(np.ascontiguousarray(gray))
         detections = Keypoints(xy, scales=None, responses=responses)
 
-        # selection on the host with the reference's own Keypoints methods -> identical ordering and ties
+        # selection on the host with the reference's own Keypoints methods -> identical ordering and ties; the descriptor rows
+        # of the survivors are gathered on the device and only those cross PCIe
+        keep = np.arange(len(detections))
         if image.mask is not None:
             detections, inside = detections.filter_by_mask(image.mask)
-            descriptors = descriptors[inside]
+            keep = keep[inside]
         detections, strongest = detections.get_top_k(self.max_keypoints)
-        return detections, descriptors[strongest]
+        return detections, fetch_descriptors(keep[strongest])

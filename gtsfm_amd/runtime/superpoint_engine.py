@@ -130,6 +130,49 @@ class SuperPointEngine:
             out["dense_scores"], out["nms_scores"] = dense, nms
         return out
 
+    def _pinned(self, name: str, shape, dtype) -> torch.Tensor:
+        """A page-locked host buffer that lives as long as the engine (grown geometrically): the per-call plugin API moves an image
+        in and keypoints / descriptors out on every call, and must not depend on how fast the host maps fresh pageable memory."""
+        pool = self.__dict__.setdefault("_pinned_pool", {})
+        need = int(np.prod(shape))
+        buf = pool.get(name)
+        if buf is None or buf.numel() < need or buf.dtype != dtype:
+            buf = pool[name] = torch.empty(max(need, int(1.5 * (0 if buf is None else buf.numel()))), dtype=dtype, pin_memory=True)
+        return buf[:need].view(*shape)
+
+    def detect_lazy(self, gray: np.ndarray, **kwargs):
+        """Single host image -> (coordinates [K,2], scores [K], fetch): the keypoint list in the model's row-major order on the
+        host, the descriptors still on the device; ``fetch(indices)`` returns descriptor rows ``indices`` as a fresh [len,256] numpy
+        array. The plugin selects on the host with the reference's own ``Keypoints`` methods and downloads only what it keeps
+        (5000 of ~8000 rows at GTSfM's cap)."""
+        assert gray.ndim == 2
+        stage = self._pinned("image", gray.shape, torch.uint8 if gray.dtype == np.uint8 else torch.float32)
+        stage.numpy()[...] = gray
+        img = stage.to(self.device, non_blocking=True)[None]
+        out = self.forward(img, **kwargs)
+        k_raw = int(out["count_raw"][0].item())  # synchronises: the staged image has been consumed
+        if k_raw > out["xy"].shape[1]:  # ties can exceed the NMS packing bound; rerun with an exact capacity
+            out = self.forward(img, **dict(kwargs, capacity=k_raw))
+        k = int(out["count"][0].item())
+        small = self._pinned("xy_scores", (k, 3), torch.float32)
+        small[:, :2].copy_(out["xy"][0, :k], non_blocking=True)
+        small[:, 2].copy_(out["scores"][0, :k], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        host = small.numpy()
+        desc = out["descriptors"][0]
+
+        def fetch(indices: np.ndarray) -> np.ndarray:
+            indices = np.asarray(indices, dtype=np.int64)
+            rows = self._pinned("descriptors", (len(indices), 256), torch.float32)
+            if len(indices):
+                idx = self._pinned("indices", (len(indices),), torch.int64)
+                idx.numpy()[...] = indices
+                rows.copy_(desc.index_select(0, idx.to(self.device, non_blocking=True)), non_blocking=True)
+                torch.cuda.current_stream(self.device).synchronize()
+            return rows.numpy().copy()
+
+        return host[:, :2].copy(), host[:, 2].copy(), fetch
+
     def detect(self, gray: np.ndarray, **kwargs):
         """Single host image (H,W) uint8 or float32 -> numpy (coordinates [K,2] f32 (x,y), scores [K], descriptors
         [K,256]) in the model's row-major order, i.e. what superpoint.py:198-202 returns before the GTSfM wrapper's

@@ -176,6 +176,17 @@ int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* n0_host, co
 int gtsfm_attention_f32(const float* q_dev, int ldq, const float* k_dev, int ldk, const float* v_dev, int ldv,
                         float* out_dev, int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems,
                         int max_q, int heads, float scale, void* stream);
+/* The same attention with its two SCHEDULES selectable (results are bit-identical): mode -1 = fused (one workgroup walks all keys of
+ * its 128 queries; what gtsfm_attention_f32 runs), 1 = split (one workgroup per query tile and 1024-key segment writes an
+ * unnormalised partial (O, m, l) to the workspace, a second kernel merges the segments in ascending order -- fills the chip for a
+ * single pair, the per-call plugin API), 0 = chosen from the launch geometry as the matchers do. max_k: upper bound of the key
+ * counts; rows: rows of the q / out arrays; workspace_dev: gtsfm_attention_split_workspace_bytes(max_k, heads, rows) bytes
+ * (may be NULL for mode -1). */
+size_t gtsfm_attention_split_workspace_bytes(int max_k, int heads, size_t rows);
+int gtsfm_attention_split_f32(const float* q_dev, int ldq, const float* k_dev, int ldk, const float* v_dev, int ldv,
+                              float* out_dev, int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems,
+                              int max_q, int max_k, int heads, float scale, int mode, size_t rows, void* workspace_dev,
+                              size_t workspace_bytes, void* stream);
 
 /* ---- input step in front of SuperPoint (uint8, OpenCV's 8-bit fixed-point arithmetic) ----
  * RGB(A) -> gray.          replaces gtsfm/utils/images.py:15-42 (cv.cvtColor COLOR_RGB2GRAY / COLOR_RGBA2GRAY), called from

@@ -1,0 +1,41 @@
+"""Two ranks of the front-end's collectives on ONE device (tests/test_rccl_gpu.py launches this under torch.distributed.run).
+Exit code 77 = RCCL refuses two ranks on one GPU (it normally does: "Duplicate GPU detected"); 0 = the collectives ran and agree."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from gtsfm_amd import parallel  # noqa: E402
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda:0")
+try:
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    probe = torch.full((4,), float(rank), device=dev)
+    dist.all_reduce(probe)
+    torch.cuda.synchronize()
+except Exception as e:  # noqa: BLE001
+    print(f"rank {rank}: RCCL refused two ranks on one device: {str(e)[:200]}", flush=True)
+    os._exit(77)
+blob = torch.arange(1000, dtype=torch.float32, device=dev) if rank == 0 else None
+got = parallel.broadcast_packed_weights(blob, 1000, dev)
+assert torch.equal(got.cpu(), torch.arange(1000, dtype=torch.float32))
+n, k = 5, 16
+mine = parallel.partition_images(n, rank, world)
+local = {"count": torch.tensor([k - i for i in mine], dtype=torch.int32, device=dev), "xy": torch.stack([torch.full((k, 2), float(i), device=dev) for i in mine]),
+         "scores": torch.stack([torch.full((k,), float(i), device=dev) for i in mine]), "descriptors": torch.stack([torch.full((k, 256), float(i), device=dev) for i in mine])}
+table = parallel.all_gather_feature_table(local, n)
+for i in range(n):
+    row = parallel.table_index(i, n, world)
+    assert int(table["count"][row]) == k - i and float(table["descriptors"][row, 3, 7]) == float(i)
+pairs = parallel.partition_pairs_2d(parallel.exhaustive_pairs(n), rank, world)
+gathered = parallel.gather_matches({p: np.full((p[0] + p[1], 2), p[0], dtype=np.int64) for p in pairs}, dev)
+assert sorted(gathered) == parallel.exhaustive_pairs(n) and all(v.shape == (p[0] + p[1], 2) for p, v in gathered.items())
+dist.barrier()
+dist.destroy_process_group()
+print(f"rank {rank}: rccl_two_ranks OK", flush=True)

@@ -95,6 +95,53 @@ def test_attention_ragged_batch(lib, gpu_device):
     assert float((out_all[:100].cpu() - ref0).abs().max()) < 2e-5
 
 
+def test_attention_split_schedule_is_bit_identical_to_fused(lib, gpu_device):
+    """Keys are processed in 1024-key segments, each from a fresh online-softmax state, merged in ascending order by one formula.
+    The fused schedule (a workgroup walks all segments; what batches run) and the split schedule (one workgroup per segment + a
+    combine kernel; what a single pair runs to fill the chip) must agree BIT FOR BIT: 1, 2, 3 and 5 segments, a last segment of
+    one key, ragged problems in one launch, a problem without keys, late dominant keys (reference maximum moves across segments).
+    Both are also held to the fp32 reference."""
+    counts = [300, 1024, 1025, 2048, 2500, 5000, 0, 70]
+    caps = [384, 1024, 1152, 2048, 2560, 5120, 128, 128]
+    offs = np.concatenate([[0], np.cumsum(caps)])[:-1]
+    total = int(sum(caps))
+    gen = torch.Generator().manual_seed(3)
+    qkv = torch.randn((total, 768), generator=gen)
+    qkv[:, :512] *= 1.5
+    qkv[offs[5] + 4990, 256:320] = qkv[offs[5] : offs[5] + 5000, :64].mean(0) * 40  # head 0 of the 5000-key set: a key of the LAST segment dominates
+    qkv[offs[3] + 3, 256 + 64 : 256 + 128] = qkv[offs[3] : offs[3] + 2048, 64:128].mean(0) * 40  # head 1 of the 2048-key set: one of the FIRST segment
+    # (queries, keys): self problems of every size, cross problems between different segment counts, no keys, few queries x many keys
+    problems = [(0, 0), (1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (7, 6), (7, 5), (4, 2), (2, 4)]
+    d = qkv.to(gpu_device)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=gpu_device)
+    ws = torch.empty(int(lib.gtsfm_attention_split_workspace_bytes(max(counts), 4, total)), dtype=torch.uint8, device=gpu_device)
+
+    def run(sel, mode):
+        prob = torch.tensor([[offs[a], a, offs[b], b] for a, b in sel], dtype=torch.int32, device=gpu_device)
+        out = torch.full((total, 256), float("nan"), device=gpu_device)
+        rc = lib.gtsfm_attention_split_f32(d.data_ptr(), 768, d.data_ptr() + 256 * 4, 768, d.data_ptr() + 512 * 4, 768, out.data_ptr(), 256, prob.data_ptr(),
+                                           cnt.data_ptr(), len(sel), max(counts[a] for a, _ in sel), max(counts), 4, 0.125, mode, total, ws.data_ptr(), ws.numel(),
+                                           _stream())
+        assert rc == 0, lib.gtsfm_last_error()
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    for sel in ([problems[0], problems[3], problems[5]], [problems[1], problems[2], problems[4], problems[6]], [problems[7]], [problems[8]], [problems[9]]):
+        fused, split = run(sel, -1), run(sel, 1)
+        for a, b in sel:
+            rows = slice(offs[a], offs[a] + counts[a])
+            assert torch.equal(fused[rows], split[rows]), (a, b)
+            if counts[b] == 0:
+                assert float(fused[rows].abs().max()) == 0.0
+                continue
+            ref = _ref_attention(qkv[rows, :256], qkv[offs[b] : offs[b] + counts[b], 256:512], qkv[offs[b] : offs[b] + counts[b], 512:], 0.125)
+            assert float((fused[rows] - ref).abs().max()) < 3e-5
+        touched = torch.zeros(total, dtype=torch.bool)
+        for a, _ in sel:
+            touched[offs[a] : offs[a] + counts[a]] = True
+        assert torch.isnan(fused[~touched]).all() and torch.isnan(split[~touched]).all()
+
+
 def test_attention_peaked_softmax(lib, gpu_device):
     """Online-softmax rescaling across key tiles: a late key dominates every row (max jumps after several tiles)."""
     nq, nk = 200, 700

@@ -111,3 +111,69 @@ def test_matcher_input_validation_needs_no_gpu(tmp_path):
     r = np.ones(3, dtype=np.float32)
     with pytest.raises(Exception, match="256"):
         sg.match(Keypoints(k, responses=r), Keypoints(k, responses=r), np.zeros((3, 128), np.float32), np.zeros((3, 128), np.float32), (8, 8, 3), (8, 8, 3))
+
+
+def test_same_named_classes_coexist_in_the_reference_registry():
+    """``gtsfm/ui/registry.py:15-45`` keys its global registry on ``__name__``; the plugins here carry the reference's class names on
+    purpose (shared cache namespace, section 8b). With GTSfM importable both ``gtsfm.frontend...SuperPointDetectorDescriptor`` and
+    this package's class are defined under one metaclass: the two classes stay distinct and usable, and the registry (which only the
+    UI's process-graph renderer reads, ``gtsfm/ui/process_graph_generator.py``) holds whichever was defined LAST under the shared
+    name. A fake ``gtsfm.ui`` restating that metaclass stands in for GTSfM (own interpreter: ``sys.modules`` stays clean here)."""
+    import subprocess
+    import sys
+    import textwrap
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parent.parent
+    script = textwrap.dedent("""
+        import abc, sys, types
+        from dataclasses import dataclass
+        from typing import Optional, Tuple
+        for name in ("gtsfm", "gtsfm.ui", "gtsfm.ui.registry", "gtsfm.ui.gtsfm_process"):
+            mod = types.ModuleType(name); mod.__path__ = []; sys.modules[name] = mod
+        class RegistryHolder(type):                                   # gtsfm/ui/registry.py:15-40
+            REGISTRY = {}
+            def __new__(cls, name, bases, attrs):
+                new_cls = type.__new__(cls, name, bases, attrs)
+                cls.REGISTRY[new_cls.__name__] = new_cls
+                return new_cls
+            @classmethod
+            def get_registry(cls):
+                return dict(cls.REGISTRY)
+        class AbstractableRegistryHolder(abc.ABCMeta, RegistryHolder):  # gtsfm/ui/registry.py:43-45
+            pass
+        @dataclass(frozen=True, order=True)
+        class UiMetadata:                                              # gtsfm/ui/gtsfm_process.py:36-52
+            display_name: str
+            input_products: Tuple[str, ...]
+            output_products: Tuple[str, ...]
+            parent_plate: Optional[str] = None
+        class GTSFMProcess(metaclass=AbstractableRegistryHolder):      # gtsfm/ui/gtsfm_process.py:55-65
+            @staticmethod
+            @abc.abstractmethod
+            def get_ui_metadata():
+                ...
+        sys.modules["gtsfm.ui.registry"].RegistryHolder = RegistryHolder
+        sys.modules["gtsfm.ui.registry"].AbstractableRegistryHolder = AbstractableRegistryHolder
+        sys.modules["gtsfm.ui.gtsfm_process"].GTSFMProcess = GTSFMProcess
+        sys.modules["gtsfm.ui.gtsfm_process"].UiMetadata = UiMetadata
+        class SuperPointDetectorDescriptor(GTSFMProcess):              # stands for the reference's class of that name
+            @staticmethod
+            def get_ui_metadata():
+                return UiMetadata("DetectorDescriptor", ("Images",), ("Keypoints", "Descriptors"))
+        reference_cls = SuperPointDetectorDescriptor
+        assert RegistryHolder.get_registry()["SuperPointDetectorDescriptor"] is reference_cls
+        from gtsfm_amd.frontend.detector_descriptor.superpoint import SuperPointDetectorDescriptor as amd_cls
+        from gtsfm_amd.frontend.matcher.lightglue_matcher import LightGlueMatcher
+        from gtsfm_amd.frontend.registry import GTSFMProcess as used
+        assert used is GTSFMProcess, "the plugins must derive from GTSfM's own process base when it is importable"
+        reg = RegistryHolder.get_registry()
+        assert amd_cls is not reference_cls and issubclass(amd_cls, GTSFMProcess) and issubclass(reference_cls, GTSFMProcess)
+        assert reg["SuperPointDetectorDescriptor"] is amd_cls          # last definition wins the NAME ...
+        assert reference_cls.get_ui_metadata().display_name == amd_cls.get_ui_metadata().display_name  # ... the UI node it names is the same either way
+        assert reference_cls().get_ui_metadata().display_name == "DetectorDescriptor"  # the shadowed class still works
+        assert reg["LightGlueMatcher"] is LightGlueMatcher
+        print("registry OK")
+    """)
+    run = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, cwd=str(repo), timeout=300)
+    assert run.returncode == 0 and "registry OK" in run.stdout, (run.stdout, run.stderr[-3000:])
