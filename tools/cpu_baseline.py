@@ -90,7 +90,7 @@ def main() -> None:
                 with torch.no_grad():
                     return model(data)
 
-            reps = args.reps if n <= 2048 else max(2, args.reps // 2)
+            reps = args.reps
             med, ts = timed(run, reps)
             key = f"n{n}_sinkhorn{iters}"
             out["superglue"][key] = {"kind": "reference", "s_per_pair": round(med, 4), "pairs_per_s": round(1.0 / med, 4), "reps": reps,
@@ -101,7 +101,7 @@ def main() -> None:
             with torch.no_grad():
                 return lightglue_oracle.lightglue_forward(lg_sd, T(k0)[None], T(k1)[None], T(d0)[None], T(d1)[None], (h, w), (h, w))
 
-        reps = args.reps if n <= 2048 else max(2, args.reps // 2)
+        reps = args.reps
         med, ts = timed(run_lg, reps)
         out["lightglue"][f"n{n}"] = {"kind": "port", "s_per_pair": round(med, 4), "pairs_per_s": round(1.0 / med, 4), "reps": reps,
                                      "independent_pairs_per_s": round(1.0 / (med + 2 * out["superpoint"]["s_per_image"]), 4), "samples_s": [round(t, 4) for t in ts],

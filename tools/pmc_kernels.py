@@ -1,17 +1,21 @@
 """PMC workload (GPU box, run under rocprofv3 --pmc ...): a few launches of ONE kernel at its workload shape.
-    python tools/pmc_kernels.py attention | gemm K N | sinkhorn | conv"""
+    python tools/pmc_kernels.py attention [N pairs] | gemm ROWS K N | sinkhorn [N pairs] | conv | all"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch, bench
 from gtsfm_amd.runtime import lib as L
 lib = L.load(); dev = torch.device("cuda:0")
-what = sys.argv[1]
-if what == "attention":
-    bench.measure_attention_roofline(lib, dev, 2048, 32, reps=4)
-elif what == "gemm":
-    bench.measure_gemm_roofline(lib, dev, 131072, int(sys.argv[2]), int(sys.argv[3]), reps=4)
-elif what == "sinkhorn":
-    bench.measure_sinkhorn_roofline(lib, dev, 2048, 32, iters=4)
-elif what == "conv":
+what = sys.argv[1] if len(sys.argv) > 1 else "all"
+num = [int(a) for a in sys.argv[2:]]
+if what in ("attention", "all"):
+    bench.measure_attention_roofline(lib, dev, *(num or [5000, 8]), reps=4)
+if what == "gemm":
+    bench.measure_gemm_roofline(lib, dev, *num, reps=4)
+if what == "all":
+    for k, n in ((256, 768), (512, 512), (512, 256)):
+        bench.measure_gemm_roofline(lib, dev, 81920, k, n, reps=4)
+if what in ("sinkhorn", "all"):
+    bench.measure_sinkhorn_roofline(lib, dev, *(num or [5000, 8]), iters=4)
+if what in ("conv", "all"):
     bench.measure_conv_roofline(lib, dev, 8, 1024, 1024, reps=2)
