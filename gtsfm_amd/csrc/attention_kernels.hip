@@ -38,7 +38,27 @@
 #define AT_SEG_TILES 16  // key tiles per segment
 #endif
 
-#define ATD_TILE_FLOATS (AT_KT * 64)
+// Developer timeline (tools/trace_attention.hip builds this file with -DGTSFM_TRACE; the product build has none of it): per wave,
+// shader-clock cycles summed over all key tiles for each segment of the tile loop, stamps fenced against instruction motion.
+#ifdef GTSFM_TRACE
+__device__ unsigned long long* g_attn_trace;  // [workgroup][wave][10]: S issue, softmax, B1, PV issue, B2 + DMA issue, merge, total, tiles, start stamp, end stamp
+#define TRACE_DECL const unsigned long long t_abs0 = __builtin_amdgcn_s_memtime(); unsigned t_prev = (unsigned)t_abs0; const unsigned t_begin_clk = t_prev; unsigned seg[6] = {0, 0, 0, 0, 0, 0};
+#define TRACE_SEG(k)                                                  \
+    {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        const unsigned t_now = (unsigned)__builtin_amdgcn_s_memtime(); \
+        seg[k] += t_now - t_prev;                                     \
+        t_prev = t_now;                                               \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    }
+#else
+#define TRACE_DECL
+#define TRACE_SEG(k)
+#endif
+
+#define ATD_TILE_FLOATS (AT_KT * 64)   // K tile: [64 keys][64 floats], 16-byte chunks XOR-swizzled by key & 15
+#define ATD_VBLOCK_FLOATS 288         // V tile: 16 blocks of 4 key rows (what one DMA instruction writes: 1 KiB) + 128 B of padding each
+#define ATD_VTILE_FLOATS (16 * ATD_VBLOCK_FLOATS)
 #define ATD_OC_FLOATS (34 * 256)  // merged state between segments: 32 accumulator registers + (m, l), x 256 threads
 #ifndef ATD_WGS_PER_CU
 #define ATD_WGS_PER_CU 2
@@ -76,8 +96,8 @@ template <bool SPLIT>
 __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Ks = lds;                    // [64 keys][64 floats], swizzled
-    float* Vs = lds + ATD_TILE_FLOATS;  // same
-    float* Oc = lds + 2 * ATD_TILE_FLOATS;  // fused schedule only: this thread's merged O of the segments done so far
+    float* Vs = lds + ATD_TILE_FLOATS;  // padded 4-row blocks (see velem)
+    float* Oc = lds + ATD_TILE_FLOATS + ATD_VTILE_FLOATS;  // fused schedule only: this thread's merged O of the segments done so far
     // XCD-aware block order (speed only): workgroups are dispatched round-robin over the 8 XCDs, each with a private L2. All
     // query tiles (and segments) of one (problem, head) share the same K / V, so they get linear ids that are congruent
     // mod 8 -> same XCD -> K / V are fetched into ONE L2 instead of eight.
@@ -131,21 +151,29 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
     // 16 i + 4 w .. + 3; lane l writes position l % 16 of row (l / 16) and fetches chunk (l % 16) ^ (row & 15). With this row
     // assignment row & 15 = 4 w + l / 16 is the same for a lane's four instructions: ONE swizzled column offset per lane
     // (round 2 had rows 16 w + 4 i: four 64-bit address registers pairs per tensor, the kernel sits at the register ceiling)
+    //
+    // K: the 16-byte chunks are XOR-swizzled (a lane reads ITS key row at a compile-time column, ds_read_b128: row stride 256 B
+    // would put all lanes on the same banks). V: rows are stored as they come, but every 4-row block (= one DMA instruction)
+    // is followed by 128 bytes of padding. The P V product reads V[key][d = lane] with compile-time keys: lanes 0-31 read 32
+    // consecutive floats of one row, lanes 32-63 the same columns 4 rows (one block + 128 B = 32 banks) further -- conflict-free,
+    // and every address is ONE per-lane base plus an immediate. (Round 2 swizzled V like K: the XOR with key & 15 gave the
+    // compiler 64 distinct per-lane addresses, a quarter of the register file, in a kernel at the 256-register ceiling.)
     const int drow = lane >> 4, dpos = lane & 15;
-    const int dma_col = (dpos ^ ((4 * wave + drow) & 15)) << 2;
-    auto tile_dma = [&](const float* base, int ld, int k0, float* dst) {
+    const int dma_col_k = (dpos ^ ((4 * wave + drow) & 15)) << 2, dma_col_v = dpos << 2;
+    auto tile_dma = [&](const float* base, int ld, int k0, float* dst, bool is_v) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int rb = 16 * i + 4 * wave;
             int key = k0 + rb + drow;
             key = key < nk ? key : nk - 1;  // clamp: keys beyond nk are masked to -inf (their V rows meet P = 0)
-            __builtin_amdgcn_global_load_lds(base + (size_t)key * ld + dma_col, dst + rb * 64, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(base + (size_t)key * ld + (is_v ? dma_col_v : dma_col_k), dst + (is_v ? (rb >> 2) * ATD_VBLOCK_FLOATS : rb * 64), 16, 0, 0);
         }
     };
     auto kfrag = [&](int row, int u) {  // floats 8 u + 4 kh .. + 3 of key row `row`
         return *reinterpret_cast<const f32x4*>(Ks + row * 64 + (((2 * u + kh) ^ (row & 15)) << 2));
     };
-    auto velem = [&](int key, int d) { return Vs[key * 64 + ((((d >> 2) ^ (key & 15)) << 2) | (d & 3))]; };
+    const float* vlane = Vs + kh * ATD_VBLOCK_FLOATS + j;  // this lane's V column; key4 = key - 4 kh is a compile-time constant at every use
+    auto velem = [&](int key4, int dhalf) { return vlane[(key4 >> 2) * ATD_VBLOCK_FLOATS + (key4 & 3) * 64 + dhalf * 32]; };
     auto s_phase = [&](f32x16& s0, f32x16& s1, float neg_m) {  // S^T tile = K Q^T - m (accumulators start at -m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s0[r] = s1[r] = neg_m;
@@ -161,19 +189,20 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
     f32x16 sn0, sn1;           // score tile being accumulated
 
     // prologue: K(t_begin) -> S; then the next K tile and V(t_begin) in flight
-    tile_dma(kbase, p.ldk, t_begin * AT_KT, Ks);
+    tile_dma(kbase, p.ldk, t_begin * AT_KT, Ks, false);
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     __syncthreads();
     s_phase(sc0, sc1, 0.f);
     __syncthreads();  // every wave is done reading the first K tile
-    if (t_begin + 1 < t_end) tile_dma(kbase, p.ldk, (t_begin + 1) * AT_KT, Ks);
-    tile_dma(vbase, p.ldv, t_begin * AT_KT, Vs);
+    if (t_begin + 1 < t_end) tile_dma(kbase, p.ldk, (t_begin + 1) * AT_KT, Ks, false);
+    tile_dma(vbase, p.ldv, t_begin * AT_KT, Vs, true);
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
 
     // (A variant with the S MFMAs and the softmax VALU arranged in shared straight-line blocks -- rebase branches moved
     // between two halves of the S phase -- was measured in round 2: 256 registers, 495 vs 499 image-pairs/s in the
     // workload, not kept.)
+    TRACE_DECL
     for (int t = t_begin; t < t_end; ++t) {
         const int k0 = t * AT_KT;
         const int ts = t % AT_SEG_TILES;  // tile index inside its segment (t_begin is a multiple of AT_SEG_TILES)
@@ -185,6 +214,10 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
         // A tile that opens a segment starts from reference 0, like the very first one.)
         const float m_start = m;
         if (more) s_phase(sn0, sn1, next_fresh ? 0.f : -m_start);
+        TRACE_SEG(0)
+#ifdef AT_SETPRIO
+        __builtin_amdgcn_s_setprio(AT_SETPRIO);
+#endif
         if (k0 + AT_KT > nk) {  // mask (last tile only)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -238,32 +271,39 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
                 sn1[r] -= d;
             }
         }
+#ifdef AT_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        TRACE_SEG(1)
         __builtin_amdgcn_s_waitcnt(0x0f70);  // own V(t) DMA landed (issued one phase ago)
         __syncthreads();                     // B1: K buffer free, V(t) visible
-        if (t + 2 < t_end) tile_dma(kbase, p.ldk, k0 + 2 * AT_KT, Ks);
+        if (t + 2 < t_end) tile_dma(kbase, p.ldk, k0 + 2 * AT_KT, Ks, false);
+        TRACE_SEG(2)
         // ---- phase 2: O^T += V^T P^T. Accumulator register r of S^T tile T holds key 32T + (r&3) + 8(r>>2) + 4kh, so it IS
         // the B operand of k-step r; the A operand V^T[d = lane][key] is a conflict-free read of the swizzled V tile.
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const int key = 32 * T + 8 * gq + 4 * kh;
+                const int key4 = 32 * T + 8 * gq;  // this lane's keys: key4 + 4 kh + e
                 f32x4 a0, a1, bb;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    a0[e] = velem(key + e, j);
-                    a1[e] = velem(key + e, 32 + j);
+                    a0[e] = velem(key4 + e, 0);
+                    a1[e] = velem(key4 + e, 1);
                     bb[e] = T ? sc1[4 * gq + e] : sc0[4 * gq + e];
                 }
                 mfma8(o0, o1, a0, a1, bb);
             }
         }
+        TRACE_SEG(3)
         if (more) {
             __builtin_amdgcn_s_waitcnt(0x0f70);  // own K(t+2) DMA landed
             __syncthreads();                     // B2: V buffer free, K(t+2) visible
-            tile_dma(vbase, p.ldv, k0 + AT_KT, Vs);
+            tile_dma(vbase, p.ldv, k0 + AT_KT, Vs, true);
             sc0 = sn0, sc1 = sn1;
         }
+        TRACE_SEG(4)
         // ---- fused schedule, end of a segment: fold (O, m, l) into the merged state. The merged O waits in LDS (each thread
         // reads and writes only its own 32 slots, so no barrier is involved) while the registers serve the next segment.
         if (!SPLIT && (next_fresh || (!more && t >= AT_SEG_TILES))) {
@@ -289,8 +329,19 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
                 Oc[33 * 256 + tid] = l;
                 m = 0.f, l = 0.f;
             }
+            TRACE_SEG(5)
         }
     }
+#ifdef GTSFM_TRACE
+    if (lane == 0 && g_attn_trace) {
+        unsigned long long* o = g_attn_trace + ((size_t)blockIdx.x * 4 + wave) * 10;
+        for (int k = 0; k < 6; ++k) o[k] = seg[k];
+        const unsigned long long t_abs1 = __builtin_amdgcn_s_memtime();
+        o[6] = (unsigned)t_abs1 - t_begin_clk;
+        o[7] = t_end - t_begin;
+        o[8] = t_abs0, o[9] = t_abs1;
+    }
+#endif
     if (!qvalid) return;
     if (SPLIT) {  // this segment's unnormalised state; attention_combine_kernel merges the segments
         const size_t row = (size_t)seg_of_wg * p.part_rows + pr.q_off + qrow;
@@ -381,12 +432,12 @@ int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t 
         q.part_o = p.split_workspace;
         q.part_ml = p.split_workspace + (size_t)q.nseg * p.part_rows * p.heads * 64;
         dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles * q.nseg);
-        hipLaunchKernelGGL((attention_dma_kernel<true>), grid, dim3(256), (size_t)2 * ATD_TILE_FLOATS * sizeof(float), stream, q);
+        hipLaunchKernelGGL((attention_dma_kernel<true>), grid, dim3(256), (size_t)(ATD_TILE_FLOATS + ATD_VTILE_FLOATS) * sizeof(float), stream, q);
         hipLaunchKernelGGL(attention_combine_kernel, dim3(ceil_div(max_q, 4), nproblems), dim3(256), 0, stream, q);
     } else {
         q.nseg = 1;
         dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles);
-        hipLaunchKernelGGL((attention_dma_kernel<false>), grid, dim3(256), (size_t)(2 * ATD_TILE_FLOATS + ATD_OC_FLOATS) * sizeof(float), stream, q);
+        hipLaunchKernelGGL((attention_dma_kernel<false>), grid, dim3(256), (size_t)(ATD_TILE_FLOATS + ATD_VTILE_FLOATS + ATD_OC_FLOATS) * sizeof(float), stream, q);
     }
     GTSFM_CHECK_LAUNCH("attention kernel");
     return GTSFM_OK;

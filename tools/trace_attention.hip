@@ -1,0 +1,88 @@
+// Developer tool: per-phase cycle budget of attention_dma_kernel at a workload shape (default: 16 sequences x 4 heads, N = 5000).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -DGTSFM_TRACE -Igtsfm_amd/csrc -Iinclude tools/trace_attention.hip -o tools/bin/trace_attention
+#include <cstdarg>
+#include <cstdlib>
+#include <vector>
+#include "../gtsfm_amd/csrc/attention_kernels.hip"
+
+void gtsfm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+}
+
+int main(int argc, char** argv) {
+    const int nseq = argc > 1 ? atoi(argv[1]) : 16, n = argc > 2 ? atoi(argv[2]) : 5000;
+    const int cap = (n + 127) / 128 * 128;
+    const size_t rows = (size_t)nseq * cap;
+    float *qkv, *out;
+    hipMalloc(&qkv, rows * 768 * 4);
+    hipMalloc(&out, rows * 256 * 4);
+    std::vector<float> h(rows * 768);
+    unsigned st = 1;
+    for (auto& v : h) { st = st * 1664525u + 1013904223u; v = ((st >> 8) * (1.0f / 16777216.0f) - 0.5f) * 3.4f; }
+    hipMemcpy(qkv, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    std::vector<int> probs(nseq * 4), counts(nseq, n);
+    for (int s = 0; s < nseq; ++s) probs[4 * s] = s * cap, probs[4 * s + 1] = s, probs[4 * s + 2] = s * cap, probs[4 * s + 3] = s;
+    int *probs_d, *counts_d;
+    hipMalloc(&probs_d, probs.size() * 4); hipMalloc(&counts_d, counts.size() * 4);
+    hipMemcpy(probs_d, probs.data(), probs.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(counts_d, counts.data(), counts.size() * 4, hipMemcpyHostToDevice);
+    AttnParams p = {};
+    p.q = qkv, p.ldq = 768, p.k = qkv + 256, p.ldk = 768, p.v = qkv + 512, p.ldv = 768, p.out = out, p.ldo = 256;
+    p.problems = (const AttnProblem*)probs_d, p.counts = counts_d, p.scale = 0.125f, p.heads = 4, p.max_k = n, p.force_split = -1;
+    const size_t nwg = (size_t)(nseq * 4 + 7) / 8 * 8 * ((n + 127) / 128);
+#ifdef GTSFM_TRACE
+    unsigned long long* trace;
+    hipMalloc(&trace, nwg * 4 * 10 * 8);
+    hipMemset(trace, 0, nwg * 4 * 10 * 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &trace, sizeof(trace));
+#endif
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch_attention(p, nseq, n, 0);
+    hipEventRecord(e0);
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) launch_attention(p, nseq, n, 0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("attention %d seq x %d: %.3f ms per launch, %.1f TFLOP/s (%.3f of 157.3)\n", nseq, n, ms, 1024.0 * n * n * nseq / (ms * 1e-3) / 1e12,
+           1024.0 * n * n * nseq / (ms * 1e-3) / 1e12 / 157.3);
+#ifdef GTSFM_TRACE
+    // one more launch on its own for the clock: cycles between the first start and the last end of the workgroups of one XCD
+    // (the s_memtime counters of different XCDs are not synchronised) against the launch's HIP-event time
+    hipMemset(trace, 0, nwg * 4 * 10 * 8);
+    hipEventRecord(e0);
+    launch_attention(p, nseq, n, 0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms1; hipEventElapsedTime(&ms1, e0, e1);
+    std::vector<unsigned long long> t(nwg * 4 * 10);
+    hipMemcpy(t.data(), trace, t.size() * 8, hipMemcpyDeviceToHost);
+    double sum[8] = {0}; size_t waves = 0;
+    unsigned long long lo[8], hi[8];
+    for (int x = 0; x < 8; ++x) lo[x] = ~0ull, hi[x] = 0;
+    for (size_t w = 0; w < nwg * 4; ++w) {
+        if (t[w * 10 + 7] == 0) continue;
+        ++waves;
+        for (int k = 0; k < 8; ++k) sum[k] += (double)t[w * 10 + k];
+        const int x = (int)((w / 4) & 7);
+        if (t[w * 10 + 8] < lo[x]) lo[x] = t[w * 10 + 8];
+        if (t[w * 10 + 9] > hi[x]) hi[x] = t[w * 10 + 9];
+    }
+    double span = 0;
+    for (int x = 0; x < 8; ++x) span += (double)(hi[x] - lo[x]) / 8;
+    printf("one launch: %.3f ms by HIP events, %.0f shader cycles from first workgroup start to last end (mean over the XCDs) -> %.2f GHz effective clock\n", ms1, span, span / (ms1 * 1e-3) / 1e9);
+    const char* names[6] = {"S(t+1) MFMA issue", "mask + softmax VALU", "vmcnt + barrier 1 + K DMA issue", "PV MFMA issue", "vmcnt + barrier 2 + V DMA issue + sc=sn", "segment merge"};
+    const double tiles = sum[7] / waves;
+    printf("workgroup slots busy: wave lifetime x workgroups / (512 slots x span) = %.3f\n", (sum[6] / waves) * (waves / 4.0) / (512.0 * span));
+    printf("%zu waves, %.1f tiles each; per wave and TILE (shader-clock cycles; two waves share a SIMD's matrix pipe: 2 x 8192 = 16384 when it never idles):\n", waves, tiles);
+    double acc = 0;
+    for (int k = 0; k < 6; ++k) { printf("  %-42s %9.0f\n", names[k], sum[k] / waves / tiles); acc += sum[k] / waves / tiles; }
+    printf("  %-42s %9.0f\n  %-42s %9.0f (prologue + epilogue per wave: %.0f)\n", "sum of the loop", acc, "wave lifetime / tiles", sum[6] / waves / tiles, sum[6] / waves - acc * tiles);
+#endif
+    return 0;
+}
