@@ -25,15 +25,17 @@ struct AttnParams {
     int heads;
     // split schedule (one workgroup per query tile AND key segment + a combine kernel; bit-identical to the fused schedule):
     int max_k;                     // most keys of any problem (0: max_q); sizes the segment dimension of the split grid
-    float* split_workspace;        // device, attention_split_floats(...) floats; nullptr: fused schedule only
-    size_t split_workspace_floats;
+    float* workspace;              // device, attention_workspace_floats(...) floats: the split schedule's partial states, or the fused
+    size_t workspace_floats;       // schedule's parking space for the merged state between key segments; nullptr: fused, parked in LDS
     size_t part_rows;              // rows of the q / out arrays (a segment's partial O is [part_rows][heads * 64])
     int force_split;               // 0: by launch geometry, 1: always (if more than one segment fits), -1: never
     int qtiles, nproblems, nseg;   // filled by the launcher
+    int lds_has_oc;                // "
     float* part_o;                 // "
     float* part_ml;                // "
+    float* park;                   // "
 };
 
-// Floats of split workspace the launch (nproblems, heads, max_q, max_k) over `rows` token rows will use; 0 = it runs fused.
-size_t attention_split_floats(int nproblems, int heads, int max_q, int max_k, size_t rows);
+// Floats of workspace the launch (nproblems, heads, max_q, max_k) over `rows` token rows can use (0 when every problem is one segment).
+size_t attention_workspace_floats(int nproblems, int heads, int max_q, int max_k, size_t rows);
 int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t stream);

@@ -28,6 +28,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "attention_kernels.h"
 #include "mfma_tiles.h"
 
@@ -59,6 +61,18 @@ __device__ unsigned long long* g_attn_trace;  // [workgroup][wave][10]: S issue,
 #define ATD_TILE_FLOATS (AT_KT * 64)   // K tile: [64 keys][64 floats], 16-byte chunks XOR-swizzled by key & 15
 #define ATD_VBLOCK_FLOATS 288         // V tile: 16 blocks of 4 key rows (what one DMA instruction writes: 1 KiB) + 128 B of padding each
 #define ATD_VTILE_FLOATS (16 * ATD_VBLOCK_FLOATS)
+#define ATD_STAGE_FLOATS (ATD_TILE_FLOATS + ATD_VTILE_FLOATS)
+#ifndef ATD_DBUF
+// 1: K / V tiles double-buffered, ONE barrier per key tile, DMA issued a whole tile ahead (256 VGPRs, 68 KiB of LDS per workgroup).
+// Measured round 3 (tools/bench_attention.py, same box, A/B/A): 3.202 / 3.186 / 3.206 ms per launch of 16 sequences at N = 5000 and
+// 2.079 / 2.069 / 2.084 ms for 64 at N = 2048 (double / single / double): no difference -- the cycle budget (tools/trace_attention.hip)
+// shows the one barrier absorbing exactly the wait of the former two (3.4 k cycles per tile) while the tile period stays at
+// 18.1 k cycles against 16.4 k of MFMA work: the waves are not held up by each other's jitter but queue for the matrix pipe, and the
+// rest of the gap to the nominal peak is clock (2.16 GHz under the profiler's counters, profiles/r03_effective_clock.csv).
+// The single-buffered form (198 VGPRs, 34 KiB) therefore stays the default.
+#define ATD_DBUF 0
+#endif
+#define ATD_LDS_TILE_FLOATS ((ATD_DBUF ? 2 : 1) * ATD_STAGE_FLOATS)
 #define ATD_OC_FLOATS (34 * 256)  // merged state between segments: 32 accumulator registers + (m, l), x 256 threads
 #ifndef ATD_WGS_PER_CU
 #define ATD_WGS_PER_CU 2
@@ -95,9 +109,14 @@ __device__ __forceinline__ float at_merge(float acc, float seg, const AtMergeWei
 template <bool SPLIT>
 __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Ks = lds;                    // [64 keys][64 floats], swizzled
-    float* Vs = lds + ATD_TILE_FLOATS;  // padded 4-row blocks (see velem)
-    float* Oc = lds + ATD_TILE_FLOATS + ATD_VTILE_FLOATS;  // fused schedule only: this thread's merged O of the segments done so far
+    // LDS: K tile(s) [64 keys][64 floats] swizzled, then V tile(s) in padded 4-row blocks (see velem); buffer b of K at
+    // Ks + b * ATD_TILE_FLOATS, of V at Vs + b * ATD_VTILE_FLOATS
+    float* Ks = lds;
+    float* Vs = lds + (ATD_DBUF ? 2 : 1) * ATD_TILE_FLOATS;
+    // fused schedule only: this thread's merged (O, m, l) of the segments done so far is parked between segments -- in a
+    // workgroup-private slab of the caller's workspace (L2-resident; written and read once per 1024 keys), or behind the tiles in
+    // LDS when the caller gave none (gtsfm_attention_f32: at the price of one workgroup per CU). Thread-private slots: no barrier.
+    float* Oc = (!SPLIT && p.park) ? p.park + (size_t)blockIdx.x * ATD_OC_FLOATS : lds + ATD_LDS_TILE_FLOATS;
     // XCD-aware block order (speed only): workgroups are dispatched round-robin over the 8 XCDs, each with a private L2. All
     // query tiles (and segments) of one (problem, head) share the same K / V, so they get linear ids that are congruent
     // mod 8 -> same XCD -> K / V are fetched into ONE L2 instead of eight.
@@ -123,6 +142,7 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
     const int t_begin = SPLIT ? seg_of_wg * AT_SEG_TILES : 0;
     const int t_end = SPLIT ? (ntiles < t_begin + AT_SEG_TILES ? ntiles : t_begin + AT_SEG_TILES) : ntiles;
     if (SPLIT && t_begin >= ntiles) return;  // this problem has fewer segments than the widest of the launch (or no keys: combine writes zeros)
+    if (!SPLIT && !p.park && !p.lds_has_oc && ntiles > AT_SEG_TILES) __builtin_trap();  // the host promised one segment and reserved no parking space
 
     f32x4 qreg[8];  // Q fragment (B operand of S^T = K Q^T): lane (q = j, kh) holds Q[q][8t + 4kh .. +3], pre-scaled by scale * log2(e)
     {
@@ -169,55 +189,68 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
             __builtin_amdgcn_global_load_lds(base + (size_t)key * ld + (is_v ? dma_col_v : dma_col_k), dst + (is_v ? (rb >> 2) * ATD_VBLOCK_FLOATS : rb * 64), 16, 0, 0);
         }
     };
-    auto kfrag = [&](int row, int u) {  // floats 8 u + 4 kh .. + 3 of key row `row`
-        return *reinterpret_cast<const f32x4*>(Ks + row * 64 + (((2 * u + kh) ^ (row & 15)) << 2));
+    auto kfrag = [&](int buf, int row, int u) {  // floats 8 u + 4 kh .. + 3 of key row `row` of K buffer `buf` (compile-time buf and u: immediates)
+        return *reinterpret_cast<const f32x4*>(Ks + buf * ATD_TILE_FLOATS + row * 64 + (((2 * u + kh) ^ (row & 15)) << 2));
     };
     const float* vlane = Vs + kh * ATD_VBLOCK_FLOATS + j;  // this lane's V column; key4 = key - 4 kh is a compile-time constant at every use
-    auto velem = [&](int key4, int dhalf) { return vlane[(key4 >> 2) * ATD_VBLOCK_FLOATS + (key4 & 3) * 64 + dhalf * 32]; };
-    auto s_phase = [&](f32x16& s0, f32x16& s1, float neg_m) {  // S^T tile = K Q^T - m (accumulators start at -m)
+    auto velem = [&](int buf, int key4, int dhalf) { return vlane[buf * ATD_VTILE_FLOATS + (key4 >> 2) * ATD_VBLOCK_FLOATS + (key4 & 3) * 64 + dhalf * 32]; };
+    auto s_phase = [&](int buf, f32x16& s0, f32x16& s1, float neg_m) {  // S^T tile = K Q^T - m (accumulators start at -m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s0[r] = s1[r] = neg_m;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) mfma8(s0, s1, kfrag(j, u), kfrag(32 + j, u), qreg[u]);
+        for (int u = 0; u < 8; ++u) mfma8(s0, s1, kfrag(buf, j, u), kfrag(buf, 32 + j, u), qreg[u]);
     };
 
     f32x16 o0, o1;  // O^T of the CURRENT segment: rows d 0..31 / 32..63, column q
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
     float m = 0.f, l = 0.f;  // current segment: lazy reference maximum (set by the segment's first tile) and running denominator
-    f32x16 sc0, sc1;           // score tile being soft-maxed
-    f32x16 sn0, sn1;           // score tile being accumulated
+    f32x16 sa0, sa1, sb0, sb1;  // two score tiles: one being soft-maxed and multiplied with V, one being accumulated (roles alternate per tile)
 
     // prologue: K(t_begin) -> S; then the next K tile and V(t_begin) in flight
     tile_dma(kbase, p.ldk, t_begin * AT_KT, Ks, false);
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     __syncthreads();
-    s_phase(sc0, sc1, 0.f);
-    __syncthreads();  // every wave is done reading the first K tile
-    if (t_begin + 1 < t_end) tile_dma(kbase, p.ldk, (t_begin + 1) * AT_KT, Ks, false);
+    s_phase(0, sa0, sa1, 0.f);
+    if (!ATD_DBUF) __syncthreads();  // single buffer: every wave is done reading the first K tile
+    if (t_begin + 1 < t_end) tile_dma(kbase, p.ldk, (t_begin + 1) * AT_KT, Ks + (ATD_DBUF ? ATD_TILE_FLOATS : 0), false);
     tile_dma(vbase, p.ldv, t_begin * AT_KT, Vs, true);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
+    if (!ATD_DBUF) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    }
 
-    // (A variant with the S MFMAs and the softmax VALU arranged in shared straight-line blocks -- rebase branches moved
-    // between two halves of the S phase -- was measured in round 2: 256 registers, 495 vs 499 image-pairs/s in the
-    // workload, not kept.)
+    // One key tile. PAR (compile time) = parity of the tile inside its segment: with double buffers tile t lives in K / V buffer
+    // PAR, and sc / sn swap roles from tile to tile without a copy (the loop below is unrolled twice).
+    // Double-buffered schedule, ONE barrier per tile, at the top: behind it K(t+1) and V(t) have landed and are visible, and every
+    // wave has finished S(t) [K buffer PAR] and P V(t-1) [V buffer PAR ^ 1] -- exactly the two buffers the DMA of K(t+2) and
+    // V(t+1), issued right behind the barrier, overwrites; they have a whole tile of MFMAs to land. (Round 2's attempt at this
+    // spilled 13 registers inside the loop and lost 15 %; the padded V layout freed 54.)
+    // (A variant with the S MFMAs and the softmax VALU arranged in shared straight-line blocks was measured in round 2: not kept;
+    // raised wave priority over the softmax, round 3: the softmax phase shrinks from 2.9 k to 2.0 k cycles per tile and the
+    // barrier waits grow by as much, tools/trace_attention.hip.)
     TRACE_DECL
-    for (int t = t_begin; t < t_end; ++t) {
+    auto tile_step = [&](auto par_c, f32x16& sc0, f32x16& sc1, f32x16& sn0, f32x16& sn1, const int t) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr int KB = ATD_DBUF ? PAR : 0, KB_NEXT = ATD_DBUF ? PAR ^ 1 : 0, VB = ATD_DBUF ? PAR : 0, VB_NEXT = ATD_DBUF ? PAR ^ 1 : 0;
         const int k0 = t * AT_KT;
         const int ts = t % AT_SEG_TILES;  // tile index inside its segment (t_begin is a multiple of AT_SEG_TILES)
         const bool more = t + 1 < t_end;
         const bool next_fresh = !SPLIT && more && ts == AT_SEG_TILES - 1;  // fused: the next tile opens a new segment
+        if (ATD_DBUF) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // own pieces of K(t+1) and V(t) landed (issued one tile ago)
+            __syncthreads();
+            if (t + 2 < t_end) tile_dma(kbase, p.ldk, k0 + 2 * AT_KT, Ks + KB * ATD_TILE_FLOATS, false);
+            if (more) tile_dma(vbase, p.ldv, k0 + AT_KT, Vs + VB_NEXT * ATD_VTILE_FLOATS, true);
+            TRACE_SEG(2)
+        }
         // ---- phase 1: S(t+1) MFMAs in whose shadow the softmax of tile t runs
         // (the reference maximum used for S(t+1)'s accumulator start is the one BEFORE tile t's possible rebase; the
         // difference is applied below when that tile is soft-maxed: its own rebase test sees scores relative to the old m.
         // A tile that opens a segment starts from reference 0, like the very first one.)
         const float m_start = m;
-        if (more) s_phase(sn0, sn1, next_fresh ? 0.f : -m_start);
+        if (more) s_phase(KB_NEXT, sn0, sn1, next_fresh ? 0.f : -m_start);
         TRACE_SEG(0)
-#ifdef AT_SETPRIO
-        __builtin_amdgcn_s_setprio(AT_SETPRIO);
-#endif
         if (k0 + AT_KT > nk) {  // mask (last tile only)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -271,16 +304,15 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
                 sn1[r] -= d;
             }
         }
-#ifdef AT_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         TRACE_SEG(1)
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // own V(t) DMA landed (issued one phase ago)
-        __syncthreads();                     // B1: K buffer free, V(t) visible
-        if (t + 2 < t_end) tile_dma(kbase, p.ldk, k0 + 2 * AT_KT, Ks, false);
-        TRACE_SEG(2)
+        if (!ATD_DBUF) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // own V(t) DMA landed (issued one phase ago)
+            __syncthreads();                     // B1: K buffer free, V(t) visible
+            if (t + 2 < t_end) tile_dma(kbase, p.ldk, k0 + 2 * AT_KT, Ks, false);
+            TRACE_SEG(2)
+        }
         // ---- phase 2: O^T += V^T P^T. Accumulator register r of S^T tile T holds key 32T + (r&3) + 8(r>>2) + 4kh, so it IS
-        // the B operand of k-step r; the A operand V^T[d = lane][key] is a conflict-free read of the swizzled V tile.
+        // the B operand of k-step r; the A operand V^T[d = lane][key] is a conflict-free read of the padded V tile.
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
 #pragma unroll
@@ -289,23 +321,22 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
                 f32x4 a0, a1, bb;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    a0[e] = velem(key4 + e, 0);
-                    a1[e] = velem(key4 + e, 1);
+                    a0[e] = velem(VB, key4 + e, 0);
+                    a1[e] = velem(VB, key4 + e, 1);
                     bb[e] = T ? sc1[4 * gq + e] : sc0[4 * gq + e];
                 }
                 mfma8(o0, o1, a0, a1, bb);
             }
         }
         TRACE_SEG(3)
-        if (more) {
+        if (!ATD_DBUF && more) {
             __builtin_amdgcn_s_waitcnt(0x0f70);  // own K(t+2) DMA landed
             __syncthreads();                     // B2: V buffer free, K(t+2) visible
             tile_dma(vbase, p.ldv, k0 + AT_KT, Vs, true);
-            sc0 = sn0, sc1 = sn1;
         }
         TRACE_SEG(4)
-        // ---- fused schedule, end of a segment: fold (O, m, l) into the merged state. The merged O waits in LDS (each thread
-        // reads and writes only its own 32 slots, so no barrier is involved) while the registers serve the next segment.
+        // ---- fused schedule, end of a segment: fold (O, m, l) into the merged state, which waits in Oc (each thread reads and
+        // writes only its own 34 slots, so no barrier is involved) while the registers serve the next segment.
         if (!SPLIT && (next_fresh || (!more && t >= AT_SEG_TILES))) {
             if (t >= AT_SEG_TILES) {  // not the first segment: merged <- merged (+) this segment
                 const AtMergeWeights w = at_merge_weights(Oc[32 * 256 + tid], m);
@@ -313,7 +344,6 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
                 for (int r = 0; r < 16; ++r) {
                     o0[r] = at_merge(Oc[r * 256 + tid], o0[r], w);
                     o1[r] = at_merge(Oc[(16 + r) * 256 + tid], o1[r], w);
-                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // eight LDS values in flight at a time: the kernel sits at the register ceiling
                 }
                 l = at_merge(Oc[33 * 256 + tid], l, w);
                 m = w.m;
@@ -330,6 +360,18 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
                 m = 0.f, l = 0.f;
             }
             TRACE_SEG(5)
+        }
+    };
+    if (ATD_DBUF) {
+        for (int t = t_begin; t < t_end; t += 2) {  // t_begin is even (a multiple of AT_SEG_TILES): parity of t = parity inside the segment
+            tile_step(std::integral_constant<int, 0>{}, sa0, sa1, sb0, sb1, t);
+            if (t + 1 >= t_end) break;
+            tile_step(std::integral_constant<int, 1>{}, sb0, sb1, sa0, sa1, t + 1);
+        }
+    } else {
+        for (int t = t_begin; t < t_end; ++t) {  // (unrolled twice to spare the 32 moves the loop needs 9 registers more than it has)
+            tile_step(std::integral_constant<int, 0>{}, sa0, sa1, sb0, sb1, t);
+            sa0 = sb0, sa1 = sb1;
         }
     }
 #ifdef GTSFM_TRACE
@@ -410,9 +452,14 @@ static bool at_wants_split(int nproblems, int heads, int max_q, int max_k) {
     return (long long)nproblems * heads * ceil_div(max_q, AT_QB) < 2 * 256 * ATD_WGS_PER_CU;
 }
 
-size_t attention_split_floats(int nproblems, int heads, int max_q, int max_k, size_t rows) {
-    if (nproblems <= 0 || !at_wants_split(nproblems, heads, max_q, max_k)) return 0;
-    return (size_t)at_segments(max_k) * rows * ((size_t)heads * 64 + (size_t)heads * 2);
+static int at_fused_grid(int nproblems, int heads, int max_q) { return ceil_div(heads * nproblems, 8) * 8 * ceil_div(max_q, AT_QB); }
+
+size_t attention_workspace_floats(int nproblems, int heads, int max_q, int max_k, size_t rows) {
+    if (nproblems <= 0 || at_segments(max_k) < 2) return 0;  // one segment: neither schedule needs memory
+    const size_t split = (size_t)at_segments(max_k) * rows * ((size_t)heads * 64 + (size_t)heads * 2);
+    const size_t park = (size_t)at_fused_grid(nproblems, heads, max_q) * ATD_OC_FLOATS;
+    // the schedule is picked per launch (and can be forced): hold enough for whichever the launch geometry picks
+    return at_wants_split(nproblems, heads, max_q, max_k) ? (split > park ? split : park) : park;
 }
 
 int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t stream) {
@@ -422,22 +469,31 @@ int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t 
     AttnParams q = p;
     q.qtiles = ceil_div(max_q, AT_QB);
     q.nproblems = nproblems;
+    q.park = nullptr, q.lds_has_oc = 0;
     const int groups = p.heads * nproblems;
     const int max_k = p.max_k > 0 ? p.max_k : max_q;
-    const bool split = p.split_workspace != nullptr && (p.force_split > 0 || (p.force_split == 0 && at_wants_split(nproblems, p.heads, max_q, max_k)));
+    const size_t tile_bytes = (size_t)ATD_LDS_TILE_FLOATS * sizeof(float);
+    const bool split = p.workspace != nullptr && (p.force_split > 0 || (p.force_split == 0 && at_wants_split(nproblems, p.heads, max_q, max_k)));
     if (split) {
         q.nseg = at_segments(max_k);
         const size_t need = (size_t)q.nseg * p.part_rows * ((size_t)p.heads * 64 + (size_t)p.heads * 2);
-        GTSFM_CHECK_ARG(p.part_rows > 0 && p.split_workspace_floats >= need, "attention: split workspace too small (%zu < %zu floats)", p.split_workspace_floats, need);
-        q.part_o = p.split_workspace;
-        q.part_ml = p.split_workspace + (size_t)q.nseg * p.part_rows * p.heads * 64;
+        GTSFM_CHECK_ARG(p.part_rows > 0 && p.workspace_floats >= need, "attention: workspace too small for the split schedule (%zu < %zu floats)", p.workspace_floats, need);
+        q.part_o = p.workspace;
+        q.part_ml = p.workspace + (size_t)q.nseg * p.part_rows * p.heads * 64;
         dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles * q.nseg);
-        hipLaunchKernelGGL((attention_dma_kernel<true>), grid, dim3(256), (size_t)(ATD_TILE_FLOATS + ATD_VTILE_FLOATS) * sizeof(float), stream, q);
+        hipLaunchKernelGGL((attention_dma_kernel<true>), grid, dim3(256), tile_bytes, stream, q);
         hipLaunchKernelGGL(attention_combine_kernel, dim3(ceil_div(max_q, 4), nproblems), dim3(256), 0, stream, q);
     } else {
         q.nseg = 1;
-        dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles);
-        hipLaunchKernelGGL((attention_dma_kernel<false>), grid, dim3(256), (size_t)(ATD_TILE_FLOATS + ATD_VTILE_FLOATS + ATD_OC_FLOATS) * sizeof(float), stream, q);
+        dim3 grid(at_fused_grid(nproblems, p.heads, max_q));
+        size_t lds_bytes = tile_bytes;
+        if (p.workspace && p.workspace_floats >= (size_t)grid.x * ATD_OC_FLOATS) {
+            q.park = p.workspace;  // merged state between segments in the workspace: two workgroups per CU
+        } else if (p.max_k <= 0 || at_segments(max_k) > 1) {
+            q.lds_has_oc = 1;      // ... in LDS behind the tiles (callers without a workspace)
+            lds_bytes += (size_t)ATD_OC_FLOATS * sizeof(float);
+        }                          // else: the caller vouches for one segment (the kernel traps if a problem has more)
+        hipLaunchKernelGGL((attention_dma_kernel<false>), grid, dim3(256), lds_bytes, stream, q);
     }
     GTSFM_CHECK_LAUNCH("attention kernel");
     return GTSFM_OK;

@@ -186,14 +186,18 @@ extern "C" int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* 
 extern "C" int gtsfm_attention_f32(const float* q_dev, int ldq, const float* k_dev, int ldk, const float* v_dev, int ldv, float* out_dev,
                                    int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems, int max_q, int heads,
                                    float scale, void* stream) {
-    return gtsfm_attention_split_f32(q_dev, ldq, k_dev, ldk, v_dev, ldv, out_dev, ldo, problems_dev, counts_dev, nproblems, max_q, max_q, heads, scale, -1,
+    // no workspace, key counts unknown to the host (max_k = 0): fused schedule, merged state parked in LDS
+    return gtsfm_attention_split_f32(q_dev, ldq, k_dev, ldk, v_dev, ldv, out_dev, ldo, problems_dev, counts_dev, nproblems, max_q, 0, heads, scale, -1,
                                      0, nullptr, 0, stream);
 }
 
-extern "C" size_t gtsfm_attention_split_workspace_bytes(int max_k, int heads, size_t rows) {
-    // the split schedule holds one unnormalised O row + (m, l) per head, per key segment and token row
+extern "C" size_t gtsfm_attention_split_workspace_bytes(int nproblems, int max_q, int max_k, int heads, size_t rows) {
+    // enough for either schedule: the split schedule's partial states (one unnormalised O row + (m, l) per head, key segment and
+    // token row) or the fused schedule's parking space (34 floats per thread of the launch)
     const int nseg = (((max_k < 1 ? 1 : max_k) + 63) / 64 + 15) / 16;
-    return (size_t)nseg * rows * ((size_t)heads * 64 + (size_t)heads * 2) * sizeof(float);
+    const size_t split = (size_t)nseg * rows * ((size_t)heads * 64 + (size_t)heads * 2);
+    const size_t park = (size_t)((heads * nproblems + 7) / 8 * 8) * ((max_q + 127) / 128) * 34 * 256;
+    return (split > park ? split : park) * sizeof(float);
 }
 
 extern "C" int gtsfm_attention_split_f32(const float* q_dev, int ldq, const float* k_dev, int ldk, const float* v_dev, int ldv, float* out_dev,
@@ -204,7 +208,7 @@ extern "C" int gtsfm_attention_split_f32(const float* q_dev, int ldq, const floa
     AttnParams p = {};
     p.q = q_dev, p.ldq = ldq, p.k = k_dev, p.ldk = ldk, p.v = v_dev, p.ldv = ldv, p.out = out_dev, p.ldo = ldo;
     p.problems = (const AttnProblem*)problems_dev, p.counts = counts_dev, p.scale = scale, p.heads = heads;
-    p.max_k = max_k, p.force_split = mode, p.split_workspace = (float*)workspace_dev, p.split_workspace_floats = workspace_bytes / sizeof(float), p.part_rows = rows;
+    p.max_k = max_k, p.force_split = mode, p.workspace = (float*)workspace_dev, p.workspace_floats = workspace_bytes / sizeof(float), p.part_rows = rows;
     return launch_attention(p, nproblems, max_q, (hipStream_t)stream);
 }
 
@@ -266,7 +270,7 @@ SgWorkspace sg_workspace_layout(const BatchDims& d) {
     w.max0 = take(T);
     w.idx0 = take(T);
     w.idx1 = take(T);
-    w.attn_floats = attention_split_floats(2 * d.P, 4, d.max_n, d.max_n, T);  // 0 unless the batch is small enough for the split schedule
+    w.attn_floats = attention_workspace_floats(2 * d.P, 4, d.max_n, d.max_n, T);  // split partials (small batches) or fused parking space; 0 below 1025 keypoints
     w.attn = take(w.attn_floats);
     w.total = o;
     return w;
@@ -359,7 +363,7 @@ static int sg_forward_phased(const float* wts, int num_layers, float bin_score, 
         // the attention output lands in the second half of cat([x, .]); attn.merge is folded into mlp.0 at load time
         ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = X + 256, ap.ldo = 512;
         ap.problems = (l % 2 == 0) ? self_p : cross_p, ap.counts = counts, ap.scale = 0.125f, ap.heads = 4;
-        ap.max_k = d.max_n, ap.split_workspace = (float*)(wsp + ws.attn), ap.split_workspace_floats = ws.attn_floats, ap.part_rows = T;
+        ap.max_k = d.max_n, ap.workspace = ws.attn_floats ? (float*)(wsp + ws.attn) : nullptr, ap.workspace_floats = ws.attn_floats, ap.part_rows = T;
         TRY(launch_attention(ap, 2 * npairs, d.max_n, stream));
         TRY(gemm(X, 512, 512, 512, MLP, 512, 0, nullptr, 0, 1));       // mlp.0 (+BN, merge folded) + ReLU
         TRY(gemm(MLP, 512, 512, 256, X, 512, 0, X, 512, 0));           // mlp.3, desc += delta
@@ -550,7 +554,7 @@ LgWorkspace lg_workspace_layout(const LgDims& d) {
     w.pack = take(d.pack_floats), w.z = take(d.z_floats), w.part = take(d.part_floats);
     w.uv_row = take(T + 16 * d.P + 8), w.uv_col = take(T + 16 * d.P + 8);
     w.max0 = take(T), w.idx0 = take(T), w.idx1 = take(T), w.m_int = take(T), w.ms_int = take(T);
-    w.attn_floats = attention_split_floats(2 * d.P, 4, d.max_n, d.max_n, T);  // 0 unless the batch is small enough for the split schedule
+    w.attn_floats = attention_workspace_floats(2 * d.P, 4, d.max_n, d.max_n, T);  // split partials (small batches) or fused parking space; 0 below 1025 keypoints
     w.attn = take(w.attn_floats);
     w.total = o;
     return w;
@@ -672,7 +676,7 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
         // the attention context lands in the second half of cat([x, .]); out_proj / to_out are folded into ffn.0 at load time
         ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = X + 256, ap.ldo = 512;
         ap.counts = live, ap.scale = 0.125f, ap.heads = 4;
-        ap.max_k = d.max_n, ap.split_workspace = (float*)(wsp + ws.attn), ap.split_workspace_floats = ws.attn_floats, ap.part_rows = d.Tp;
+        ap.max_k = d.max_n, ap.workspace = ws.attn_floats ? (float*)(wsp + ws.attn) : nullptr, ap.workspace_floats = ws.attn_floats, ap.part_rows = d.Tp;
         if (l == 0 && phase == 2) {  // the first self block was run per image (phase 1): step over its weights
             const float *w, *b, *raw;
             cur.linear(768, 256, &w, &b, &raw), cur.linear(512, 512, &w, &b, &raw);

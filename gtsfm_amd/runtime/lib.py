@@ -80,7 +80,7 @@ SIGNATURES = {
         [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
          C.c_int, C.c_int, C.c_float, C.c_void_p],
     ),
-    "gtsfm_attention_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_size_t]),
+    "gtsfm_attention_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t]),
     "gtsfm_attention_split_f32": (
         C.c_int,
         [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

@@ -180,9 +180,10 @@ int gtsfm_attention_f32(const float* q_dev, int ldq, const float* k_dev, int ldk
  * its 128 queries; what gtsfm_attention_f32 runs), 1 = split (one workgroup per query tile and 1024-key segment writes an
  * unnormalised partial (O, m, l) to the workspace, a second kernel merges the segments in ascending order -- fills the chip for a
  * single pair, the per-call plugin API), 0 = chosen from the launch geometry as the matchers do. max_k: upper bound of the key
- * counts; rows: rows of the q / out arrays; workspace_dev: gtsfm_attention_split_workspace_bytes(max_k, heads, rows) bytes
- * (may be NULL for mode -1). */
-size_t gtsfm_attention_split_workspace_bytes(int max_k, int heads, size_t rows);
+ * counts (0: unknown); rows: rows of the q / out arrays; workspace_dev: gtsfm_attention_split_workspace_bytes(...) bytes -- the
+ * split schedule's partial states or, for the fused schedule, parking space for the merged state between key segments (NULL with
+ * mode -1: parked in LDS, one workgroup per CU instead of two). */
+size_t gtsfm_attention_split_workspace_bytes(int nproblems, int max_q, int max_k, int heads, size_t rows);
 int gtsfm_attention_split_f32(const float* q_dev, int ldq, const float* k_dev, int ldk, const float* v_dev, int ldv,
                               float* out_dev, int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems,
                               int max_q, int max_k, int heads, float scale, int mode, size_t rows, void* workspace_dev,

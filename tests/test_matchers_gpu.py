@@ -114,7 +114,7 @@ def test_attention_split_schedule_is_bit_identical_to_fused(lib, gpu_device):
     problems = [(0, 0), (1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (7, 6), (7, 5), (4, 2), (2, 4)]
     d = qkv.to(gpu_device)
     cnt = torch.tensor(counts, dtype=torch.int32, device=gpu_device)
-    ws = torch.empty(int(lib.gtsfm_attention_split_workspace_bytes(max(counts), 4, total)), dtype=torch.uint8, device=gpu_device)
+    ws = torch.empty(int(lib.gtsfm_attention_split_workspace_bytes(len(problems), max(counts), max(counts), 4, total)), dtype=torch.uint8, device=gpu_device)
 
     def run(sel, mode):
         prob = torch.tensor([[offs[a], a, offs[b], b] for a, b in sel], dtype=torch.int32, device=gpu_device)

@@ -22,7 +22,7 @@ def run(n, npairs, mode, reps=20):
     out = torch.empty((nseq * cap, 256), device=dev)
     probs = torch.tensor([[s * cap, s, s * cap, s] for s in range(nseq)], dtype=torch.int32, device=dev)
     counts = torch.full((nseq,), n, dtype=torch.int32, device=dev)
-    ws = torch.empty(int(lib.gtsfm_attention_split_workspace_bytes(n, 4, nseq * cap)), dtype=torch.uint8, device=dev)
+    ws = torch.empty(int(lib.gtsfm_attention_split_workspace_bytes(nseq, n, n, 4, nseq * cap)), dtype=torch.uint8, device=dev)
     args = (qkv.data_ptr(), 768, qkv.data_ptr() + 1024, 768, qkv.data_ptr() + 2048, 768, out.data_ptr(), 256, probs.data_ptr(), counts.data_ptr(), nseq, n, n, 4,
             0.125, mode, nseq * cap, ws.data_ptr(), ws.numel(), stream.cuda_stream)
     L.check(lib.gtsfm_attention_split_f32(*args), "attention")

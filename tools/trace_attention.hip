@@ -33,6 +33,8 @@ int main(int argc, char** argv) {
     AttnParams p = {};
     p.q = qkv, p.ldq = 768, p.k = qkv + 256, p.ldk = 768, p.v = qkv + 512, p.ldv = 768, p.out = out, p.ldo = 256;
     p.problems = (const AttnProblem*)probs_d, p.counts = counts_d, p.scale = 0.125f, p.heads = 4, p.max_k = n, p.force_split = -1;
+    p.workspace_floats = attention_workspace_floats(nseq, 4, n, n, rows);
+    hipMalloc(&p.workspace, p.workspace_floats * 4 + 16);
     const size_t nwg = (size_t)(nseq * 4 + 7) / 8 * 8 * ((n + 127) / 128);
 #ifdef GTSFM_TRACE
     unsigned long long* trace;
