@@ -49,6 +49,7 @@ __device__ __forceinline__ float logsigmoid(float x) { return fminf(x, 0.f) - lo
 
 // dst[r][0:256] = src[r][0:256] for r < rows (row strides lds / ldd floats)
 int launch_copy_rows256(const float* src, int lds, float* dst, int ldd, int rows, hipStream_t stream);
+int launch_move_blocks(const float* src, const int* src_index, float* dst, const int* dst_index, int nblocks, long long block_floats, hipStream_t stream);
 int launch_sg_encode_input(const float* kpts, const float* scores, const SeqDesc* seqs, const int* counts, int nseq, int max_n,
                            float* enc_in, hipStream_t stream);
 int launch_lg_posenc(const float* kpts, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* Wr, float* enc,

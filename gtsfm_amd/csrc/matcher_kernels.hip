@@ -156,6 +156,24 @@ int launch_copy_rows256(const float* src, int lds, float* dst, int ldd, int rows
     return GTSFM_OK;
 }
 
+// dst block b <- src block src_index[b] (gather) or dst block dst_index[b] <- src block b (scatter); a block = block_floats contiguous
+// floats (an image's rows of the feature table), a multiple of 2. One workgroup row per block, float2 granularity.
+__global__ __launch_bounds__(256) void move_blocks_kernel(const float* __restrict__ src, const int* __restrict__ src_index, float* __restrict__ dst,
+                                                          const int* __restrict__ dst_index, long long block_floats) {
+    const int b = blockIdx.y;
+    const float2* s = reinterpret_cast<const float2*>(src + (size_t)(src_index ? src_index[b] : b) * block_floats);
+    float2* d = reinterpret_cast<float2*>(dst + (size_t)(dst_index ? dst_index[b] : b) * block_floats);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < block_floats / 2; i += (long long)gridDim.x * 256) d[i] = s[i];
+}
+
+int launch_move_blocks(const float* src, const int* src_index, float* dst, const int* dst_index, int nblocks, long long block_floats, hipStream_t stream) {
+    if (nblocks <= 0 || block_floats <= 0) return GTSFM_OK;
+    const long long per_block = ceil_div((int)((block_floats / 2 + 255) / 256), 1);
+    hipLaunchKernelGGL(move_blocks_kernel, dim3((unsigned)(per_block < 64 ? per_block : 64), nblocks), dim3(256), 0, stream, src, src_index, dst, dst_index, block_floats);
+    GTSFM_CHECK_LAUNCH("move_blocks_kernel");
+    return GTSFM_OK;
+}
+
 int launch_sg_encode_input(const float* kpts, const float* scores, const SeqDesc* seqs, const int* counts, int nseq, int max_n,
                            float* enc_in, hipStream_t stream) {
     if (nseq <= 0 || max_n <= 0) return GTSFM_OK;

@@ -75,6 +75,7 @@ SIGNATURES = {
     "gtsfm_pack_blob": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
     "gtsfm_match_desc_ints": (C.c_size_t, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gtsfm_match_build_desc": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gtsfm_move_blocks_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "gtsfm_attention_f32": (
         C.c_int,
         [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

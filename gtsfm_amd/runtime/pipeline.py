@@ -15,8 +15,23 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from gtsfm_amd.runtime import lib as _lib
 from gtsfm_amd.runtime.matcher_engine import LightGlueEngine, SuperGlueEngine
 from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+
+
+def _move_blocks(src: torch.Tensor, dst: torch.Tensor, src_index: Optional[torch.Tensor] = None, dst_index: Optional[torch.Tensor] = None) -> None:
+    """Image blocks of a feature table moved by index on the current stream (``gtsfm_move_blocks_f32``): dst[b] = src[src_index[b]],
+    or dst[dst_index[b]] = src[b]. src / dst: contiguous float32 [blocks, ...] with equal block shapes; indices int32 on the device."""
+    n = int((src_index if src_index is not None else dst_index).numel())
+    block = int(np.prod(src.shape[1:]))
+    assert src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype == torch.float32 and tuple(src.shape[1:]) == tuple(dst.shape[1:])
+    if block % 2:  # scores [images, K] with odd K: two blocks of one table never alias, a trailing float moves with torch
+        (dst.index_copy_(0, dst_index.long(), src[:n]) if dst_index is not None else torch.index_select(src, 0, src_index.long(), out=dst[:n]))
+        return
+    lib = _lib.load()
+    _lib.check(lib.gtsfm_move_blocks_f32(src.data_ptr(), _lib.ptr(src_index), dst.data_ptr(), _lib.ptr(dst_index), n, block,
+                                         torch.cuda.current_stream(src.device).cuda_stream), "gtsfm_move_blocks_f32")
 
 
 class _GraphedChunk:
@@ -50,10 +65,10 @@ class _GraphedChunk:
         return self.matcher.match_batch(kp, de, self.n, self.n, self.hw, workspace=self.ws, **self.kwargs)
 
     def _gather(self, feats, idx: torch.Tensor):
-        torch.index_select(feats["xy"], 0, idx, out=self.kp)
-        torch.index_select(feats["descriptors"], 0, idx, out=self.de)
+        _move_blocks(feats["xy"], self.kp, src_index=idx)
+        _move_blocks(feats["descriptors"], self.de, src_index=idx)
         if self.is_sg:
-            torch.index_select(feats["scores"], 0, idx, out=self.sc)
+            _move_blocks(feats["scores"], self.sc, src_index=idx)
 
     def replay(self, feats, idx: torch.Tensor):
         self._gather(feats, idx)
@@ -152,31 +167,38 @@ class FrontEndPipeline:
         """x after the matcher's per-image first block for the images in `used`, as a table shaped like feats["descriptors"]
         (rows of other images keep their descriptors; they are never read). On the caller's stream, 2 * pair_chunk images per
         launch sequence (the matcher workspace a pair chunk needs anyway)."""
-        table = feats["descriptors"].clone()
+        table = torch.empty_like(feats["descriptors"])  # only the rows of the images in `used` are written -- and only those are read
         is_sg = isinstance(self.matcher, SuperGlueEngine)
         step = 2 * self.pair_chunk
         for c0 in range(0, len(used), step):
             ids = [int(i) for i in used[c0 : c0 + step]]
-            idx = torch.tensor(ids, dtype=torch.long, device=table.device)
             cnt = [int(counts[i]) for i in ids]
             if min(cnt) == 0:  # an empty keypoint set never reaches the matcher (empty-input early-out): drop it here too
                 keep = [q for q, c in enumerate(cnt) if c > 0]
                 ids, cnt = [ids[q] for q in keep], [cnt[q] for q in keep]
                 if not ids:
                     continue
-                idx = torch.tensor(ids, dtype=torch.long, device=table.device)
+            idx = torch.tensor(ids, dtype=torch.int32, device=table.device)
             hw = [shapes[i] for i in ids]
             if full:
-                kp = feats["xy"].index_select(0, idx).reshape(-1, 2)
-                de = feats["descriptors"].index_select(0, idx).reshape(-1, 256)
-                sc = feats["scores"].index_select(0, idx).reshape(-1) if is_sg else None
+                k = feats["xy"].shape[1]
+                kp = torch.empty((len(ids), k, 2), dtype=torch.float32, device=table.device)
+                de = torch.empty((len(ids), k, 256), dtype=torch.float32, device=table.device)
+                _move_blocks(feats["xy"], kp, src_index=idx)
+                _move_blocks(feats["descriptors"], de, src_index=idx)
+                kp, de = kp.reshape(-1, 2), de.reshape(-1, 256)
+                sc = None
+                if is_sg:
+                    sc = torch.empty((len(ids), k), dtype=torch.float32, device=table.device)
+                    _move_blocks(feats["scores"], sc, src_index=idx)
+                    sc = sc.reshape(-1)
             else:
                 kp = torch.cat([feats["xy"][i, :c] for i, c in zip(ids, cnt)], 0)
                 de = torch.cat([feats["descriptors"][i, :c] for i, c in zip(ids, cnt)], 0)
                 sc = torch.cat([feats["scores"][i, :c] for i, c in zip(ids, cnt)], 0) if is_sg else None
             x = self.matcher.prepare_images(kp, sc, de, cnt, hw) if is_sg else self.matcher.prepare_images(kp, de, cnt, hw)
             if full:
-                table.index_copy_(0, idx, x.reshape(len(ids), -1, 256))
+                _move_blocks(x.reshape(len(ids), -1, 256), table, dst_index=idx)
             else:
                 row = 0
                 for i, c in zip(ids, cnt):
@@ -186,7 +208,7 @@ class FrontEndPipeline:
 
     def _replay_chunk(self, feats, chunk, k, hw0, matcher_kwargs, si, stream):
         key = (si, len(chunk), k, tuple(hw0), tuple(sorted(matcher_kwargs.items())))
-        idx = torch.tensor([i for p in chunk for i in p], dtype=torch.long, device=feats["xy"].device)
+        idx = torch.tensor([i for p in chunk for i in p], dtype=torch.int32, device=feats["xy"].device)
         g = self._graphs.get(key)
         if g is None:
             hw = [[hw0[0], hw0[1], hw0[0], hw0[1]]] * len(chunk)
@@ -197,18 +219,24 @@ class FrontEndPipeline:
 
     def _match_chunk(self, feats, chunk, shapes, counts, full, matcher_kwargs):
         """One ragged multi-pair launch sequence on the current stream."""
-        idx = torch.tensor([i for p in chunk for i in p], dtype=torch.long, device=feats["xy"].device)
+        ids = [i for p in chunk for i in p]
         n0 = [int(counts[i]) for i, _ in chunk]
         n1 = [int(counts[j]) for _, j in chunk]
         hw = [[shapes[i][0], shapes[i][1], shapes[j][0], shapes[j][1]] for i, j in chunk]
-        if full:  # every image has exactly K keypoints: plain gathers
-            kp = feats["xy"].index_select(0, idx).reshape(-1, 2)
-            sc = feats["scores"].index_select(0, idx).reshape(-1)
-            de = feats["descriptors"].index_select(0, idx).reshape(-1, 256)
+        if full:  # every image has exactly K keypoints: block gathers by image index
+            idx = torch.tensor(ids, dtype=torch.int32, device=feats["xy"].device)
+            k = feats["xy"].shape[1]
+            kp = torch.empty((len(ids), k, 2), dtype=torch.float32, device=idx.device)
+            sc = torch.empty((len(ids), k), dtype=torch.float32, device=idx.device)
+            de = torch.empty((len(ids), k, 256), dtype=torch.float32, device=idx.device)
+            _move_blocks(feats["xy"], kp, src_index=idx)
+            _move_blocks(feats["scores"], sc, src_index=idx)
+            _move_blocks(feats["descriptors"], de, src_index=idx)
+            kp, sc, de = kp.reshape(-1, 2), sc.reshape(-1), de.reshape(-1, 256)
         else:
-            kp = torch.cat([feats["xy"][i, : counts[i]] for i in idx.tolist()], 0)
-            sc = torch.cat([feats["scores"][i, : counts[i]] for i in idx.tolist()], 0)
-            de = torch.cat([feats["descriptors"][i, : counts[i]] for i in idx.tolist()], 0)
+            kp = torch.cat([feats["xy"][i, : counts[i]] for i in ids], 0)
+            sc = torch.cat([feats["scores"][i, : counts[i]] for i in ids], 0)
+            de = torch.cat([feats["descriptors"][i, : counts[i]] for i in ids], 0)
         if isinstance(self.matcher, SuperGlueEngine):
             out = self.matcher.match_batch(kp, sc, de, n0, n1, hw, **matcher_kwargs)
         else:

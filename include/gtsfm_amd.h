@@ -170,6 +170,13 @@ size_t gtsfm_match_desc_ints(int superglue, int npairs, const int32_t* n0_host, 
 int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* n0_host, const int32_t* n1_host,
                            const int32_t* hw_host, int32_t* desc_host);
 
+/* Block moves inside device memory: dst block b <- src block src_index[b] (src_index_dev == NULL: b), written at dst block
+ * dst_index[b] (dst_index_dev == NULL: b); a block is block_floats contiguous floats (even).    replaces the per-pair numpy -> torch
+ * marshalling of gtsfm/frontend/matcher/{superglue,lightglue}_matcher.py:75-102 in the batched pipeline: the keypoint sets of a
+ * pair chunk are gathered from the resident feature table [images][max_keypoints][2 | 1 | 256] by image index. */
+int gtsfm_move_blocks_f32(const float* src_dev, const int32_t* src_index_dev, float* dst_dev, const int32_t* dst_index_dev,
+                          int nblocks, int64_t block_floats, void* stream);
+
 /* out = softmax(scale * q k^T) v per head (head h = columns [64h, 64h+64)).          replaces SG:85-89,98-106
  * problems_dev: [nproblems][4] int32 {q_row_off, q_count_idx, k_row_off, k_count_idx}; counts_dev: int32 array the
  * *_count_idx fields index; max_q: upper bound of the query counts (grid sizing). */
