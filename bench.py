@@ -292,6 +292,23 @@ def cpu_baseline(views: np.ndarray, matcher: str, n_keypoints: int, sinkhorn_ite
     return out, oracle_out
 
 
+def reference_cpu_run(matcher: str, n_keypoints: int, sinkhorn_iters: int):
+    """The committed run of tools/cpu_baseline.py (SURVEY.md section 8d protocol: the reference's OWN model files, 1 warm-up + 5
+    repetitions, median, in the build container where /root/reference is mounted), quoted next to the live single-sample figure."""
+    try:
+        ref = json.loads((REPO / "profiles" / "r03_cpu_baseline.json").read_text())
+    except (OSError, ValueError):
+        return None
+    out = {"source": "profiles/r03_cpu_baseline.json (tools/cpu_baseline.py)", "protocol": ref["protocol"], "cores": ref["host"]["cores"],
+           "superpoint_s_per_image": ref["superpoint"]["s_per_image"], "superpoint_kind": ref["superpoint"]["kind"]}
+    key = f"n{n_keypoints}_sinkhorn{sinkhorn_iters}" if matcher == "superglue" else f"n{n_keypoints}"
+    entry = ref.get(matcher, {}).get(key)
+    if entry is not None:
+        out.update(matcher=matcher, matcher_kind=entry["kind"], match_s_per_pair=entry["s_per_pair"], independent_pairs_per_s=entry["independent_pairs_per_s"])
+    out["superglue_s_per_pair"] = {k: v["s_per_pair"] for k, v in ref.get("superglue", {}).items()}
+    return out
+
+
 def parity_check(oracle_out, gpu_feats, gpu_rows, gpu_match):
     """GPU result of the timed workload vs the oracle on the SAME two images (the first pair of the step): keypoints
     bit-exact, scores / descriptors / match scores within 1e-4, match indices bit-exact."""
@@ -686,6 +703,9 @@ def main() -> None:
                 view_of = (lambda s: (5 * s) % args.images) if independent else (lambda s: s)  # noqa: E731
                 sample_views = np.stack([views_np[view_of(first[0])], views_np[view_of(first[1])]])
                 base, ora = cpu_baseline(sample_views, args.matcher, args.keypoints, args.sinkhorn)
+                ref_run = reference_cpu_run(args.matcher, args.keypoints, args.sinkhorn)
+                if ref_run is not None:
+                    base["reference_run"] = ref_run
                 result["cpu_baseline"] = base
                 gpu_match = None
                 if res:

@@ -333,6 +333,126 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small launches (round 3): the same product on 64 x 64 workgroup tiles. One keypoint-set PAIR (the per-call plugin API) has
+// M = 2 x 2048 .. 2 x 5000 token rows: with 128 x 128 tiles a projection is 64 .. 480 workgroups on a chip that holds 512, every
+// one of them a full-length K loop at one workgroup per CU (profiles/r03_plugin_single_pair_kernel_stats_*.csv: 38 us per
+// 512 -> 256 launch at M = 4096 AND at M = 10240). Four times as many workgroups of a quarter of the work each put every CU to
+// work and shorten the critical path. Same arithmetic, bit for bit: an output element is the same k-ordered chain of
+// v_mfma_f32_32x32x2_f32 steps from a zero accumulator (fragments, stage depth and step order as in gemm_dma_walk_kernel), then
+// bias, alpha, ReLU, rotary, residual in the same order and form -- which tile shape computes it is a launch-geometry decision.
+// Workgroup = 4 waves as 2 (M) x 2 (N), one 32 x 32 accumulator each; LDS image of a stage as above with 64 rows per operand, two
+// stages; a wave moves two 8-row pieces of A and of W per stage; a lane owns an output row and stores 4 x 16 bytes.
+// ---------------------------------------------------------------------------------------------------------------
+#define DS_A_FLOATS (64 * DM_KC)
+#define DS_STAGE_FLOATS (2 * DS_A_FLOATS)
+
+template <bool HAS_RES, bool ROT>
+__global__ __launch_bounds__(256, 4) void gemm_dma_small_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A 2048 | W 2048]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int M = p.m_dev ? *p.m_dev : p.M;
+    const int N = p.n_dev ? *p.n_dev : p.N;
+    // block order: the column blocks of one row tile are neighbours (A rows shared through the L2)
+    const int ncb = (p.N + 63) / 64;
+    const int mt = blockIdx.x / ncb, cb = blockIdx.x % ncb;
+    const int m0 = mt * 64, n0 = cb * 64;
+    if (p.tile_cnt_idx) {  // ragged batch with 128-row-aligned sequences: this 64-row tile is half of a 128-row tile of one sequence
+        const int c = p.live_counts[p.tile_cnt_idx[mt >> 1]];
+        const int r0 = p.tile_row0[mt >> 1] + 64 * (mt & 1);
+        if (r0 >= c) return;
+        M = min(M, m0 + c - r0);
+    }
+    if (m0 >= M || n0 >= N) return;
+    const int j = lane & 31, kh = lane >> 5;
+    const int nstages = p.K / DM_KC;
+    const int drow = lane >> 3, dpos = lane & 7;
+    const char* baseA = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
+    const char* baseW = reinterpret_cast<const char*>(p.wraw);
+    unsigned offA[2], offW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 16 * wave + 8 * i + drow;
+        offA[i] = (unsigned)(min(r, M - 1 - m0) * p.lda + dm_swz(r, dpos) * 4) * 4u;  // rows beyond M / N are clamped (computed, never stored)
+        offW[i] = (unsigned)(min(n0 + r, N - 1) * p.ldw + dm_swz(r, dpos) * 4) * 4u;
+    }
+    auto stage_dma = [&](int st, float* sA) {
+        const char* a = baseA + (size_t)st * (DM_KC * 4);
+        const char* w = baseW + (size_t)st * (DM_KC * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(a + offA[i]), sA + (16 * wave + 8 * i) * DM_KC, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(w + offW[i]), sA + DS_A_FLOATS + (16 * wave + 8 * i) * DM_KC, 16, 0, 0);
+        }
+    };
+    auto frag = [&](const float* base, int row, int step) {  // 16-byte fragment: floats 8 step + 4 kh .. + 3 of `row`
+        return *reinterpret_cast<const f32x4*>(base + row * DM_KC + dm_swz(row, 2 * step + kh) * 4);
+    };
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    const int row = m0 + 32 * wm + j;             // the lane's output row
+    const int colb = n0 + 32 * wn + 4 * kh;       // its columns: colb + 8 q + 0..3, q = 0..3
+    const int nbias = (p.N + 63) / 64 * 64;
+    f32x4 bia[4], aux[4];
+    const bool rot = ROT && n0 < p.rot_cols;     // rot_cols is a multiple of 128: the same columns as in the 128-column blocks
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int cc = colb + 8 * q;
+        bia[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias && cc < nbias) bia[q] = *reinterpret_cast<const f32x4*>(p.bias + cc);
+        if (HAS_RES) {
+            aux[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < M && cc < N) aux[q] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldres + cc);
+        }
+        if (ROT) {  // pairs f = (col % 64) / 2 and f + 1 of the row's [f][cos, sin] table
+            aux[q] = f32x4{1.f, 0.f, 1.f, 0.f};
+            if (rot && row < M) aux[q] = *reinterpret_cast<const f32x4*>(p.rot_enc + (size_t)row * 64 + (cc & 63));
+        }
+    }
+    stage_dma(0, lds);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    const int ra = 32 * wm + j, rw = 32 * wn + j;
+#pragma unroll 1
+    for (int st = 0; st < nstages; ++st) {
+        const float* sA = lds + (st & 1) * DS_STAGE_FLOATS;
+        const float* sW = sA + DS_A_FLOATS;
+        if (st + 1 < nstages) stage_dma(st + 1, lds + ((st + 1) & 1) * DS_STAGE_FLOATS);  // the other buffer was last read one stage ago
+#pragma unroll
+        for (int s = 0; s < DM_KC / 8; ++s) {
+            const f32x4 a = frag(sA, ra, s), b = frag(sW, rw, s);
+            // weights are the MFMA's A operand, activations its B operand (a lane then owns one output row)
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, c, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    }
+    if (row >= M) return;
+    float* crow = p.C + (size_t)row * p.ldc + p.c_coff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = colb + 8 * q;
+        if (col >= N) continue;  // N % 4 == 0: a 16-byte group is inside or outside
+        f32x4 v = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+        v = v + bia[q];
+        if (p.alpha != 1.0f) v = v * p.alpha;
+        if (p.relu) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+        if (rot) {  // (x0, x1) -> (x0 c - x1 s, x1 c + x0 s) per feature pair, as apply_cached_rotary_emb
+            const f32x4 e = aux[q];
+            v = f32x4{(v.x * e.x) + ((-v.y) * e.y), (v.y * e.x) + (v.x * e.y), (v.z * e.z) + ((-v.w) * e.w), (v.w * e.z) + (v.z * e.w)};
+        }
+        if (HAS_RES) v = aux[q] + v;
+        *reinterpret_cast<f32x4*>(crow + col) = v;
+    }
+}
+
 bool gemm_uses_dma(int K, int ldw) {
     static const char* which = getenv("GTSFM_GEMM");  // "mfma" forces the register-staged kernel (A/B measurements)
     return K % DM_KC == 0 && ldw % 4 == 0 && !(which && which[0] == 'm');
@@ -367,6 +487,26 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
         nbw = ncb;
     }
     q.nb_per_wg = nbw;
+    // Small launches take 64 x 64 tiles (gemm_dma_small_kernel: bit-identical results). Measured (tools/bench_gemm_small.py, us per
+    // launch, 128 x 128 -> 64 x 64 tiles): 4096 rows (one pair at N = 2048) 512->256 36.8 -> 15.3, 512->512 39.1 -> 24.6, 256->768
+    // 24.5 -> 21.1; 10240 rows (one pair at the 5000 cap) 512->512 71.5 -> 51.9, 512->256 41.2 -> 33.0, 256->768 41.4 -> 43.4; 20480 rows
+    // 512->512 107.0 -> 93.9 (640 large tiles), 256->768 72.5 -> 75.6 (960); 40960 rows 512->512 177 -> 193 (1280): the small tiling
+    // wins up to ~700 large tiles. GTSFM_GEMM_SMALL_BELOW overrides the threshold (0: never).
+    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!p.res || (p.ldres & 3) == 0);
+    const char* small_env = getenv("GTSFM_GEMM_SMALL_BELOW");
+    const long long small_below = small_env ? atoll(small_env) : 700;
+    if (!bt.problems && !bt.ln_gamma && vec_ok && !p.n_dev && nbw == 1 && (long long)mtiles * ncb < small_below) {
+        const dim3 sgrid(ceil_div(p.M, 64) * ceil_div(p.N, 64));
+        const size_t slds = (size_t)2 * DS_STAGE_FLOATS * sizeof(float);
+        if (q.rot_enc)
+            hipLaunchKernelGGL((gemm_dma_small_kernel<false, true>), sgrid, dim3(256), slds, stream, q);
+        else if (q.res)
+            hipLaunchKernelGGL((gemm_dma_small_kernel<true, false>), sgrid, dim3(256), slds, stream, q);
+        else
+            hipLaunchKernelGGL((gemm_dma_small_kernel<false, false>), sgrid, dim3(256), slds, stream, q);
+        GTSFM_CHECK_LAUNCH("gemm_dma_small_kernel");
+        return GTSFM_OK;
+    }
     const dim3 grid(ceil_div(mtiles, 8) * 8 * ceil_div(ncb, nbw), nprob);
     const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
     if (bt.ln_gamma)

@@ -773,3 +773,36 @@ def test_graph_replay_survives_descriptor_cache_eviction_and_empty_pair_lists(gp
     torch.cuda.synchronize()
     assert torch.equal(first[0]["matches"], again[0]["matches"]) and torch.equal(first[0]["mscores"], again[0]["mscores"])
     assert int((first[0]["matches"] > -1).sum()) > 0
+
+
+@pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
+def test_single_pair_schedules_are_bit_identical_to_the_batch_schedules(gpu_device, monkeypatch, matcher):
+    """One pair on its own takes the schedules that fill the chip -- 64 x 64 GEMM tiles, attention split over key segments -- while a
+    batch takes 128 x 128 tiles and the fused attention. Forcing either set on the SAME single pair (rotary epilogue, residual
+    epilogue, per-tile live counts after point pruning, 3 key segments) must give identical matches and scores, bit for bit."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+
+    n0, n1 = 2300, 2100
+    k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(n0, n1, (1024, 1024), (1024, 1024), seed=91)
+    if matcher == "superglue":
+        eng = ME.SuperGlueEngine(synthetic.synthetic_superglue_state_dict(num_layers=4), gpu_device)
+        run = lambda: eng.match_pair(k0, s0, d0, k1, s1, d1, (1024, 1024), (1024, 1024), sinkhorn_iterations=10)  # noqa: E731
+    else:
+        sd = synthetic.synthetic_lightglue_state_dict(num_layers=3, match_bias=-2.0, match_gain=30.0)  # the recipe of the 5000-keypoint test: pruning fires
+        eng = ME.LightGlueEngine(sd, gpu_device)
+        run = lambda: eng.match_pair(k0, d0, k1, d1, (1024, 1024), (1024, 1024), depth_confidence=-1.0)  # noqa: E731
+    monkeypatch.setenv("GTSFM_GEMM_SMALL_BELOW", "0")
+    monkeypatch.setenv("GTSFM_ATTENTION_SPLIT", "0")
+    batch_like = run()
+    monkeypatch.setenv("GTSFM_GEMM_SMALL_BELOW", str(1 << 40))
+    monkeypatch.setenv("GTSFM_ATTENTION_SPLIT", "1")
+    single_like = run()
+    monkeypatch.delenv("GTSFM_GEMM_SMALL_BELOW")
+    monkeypatch.delenv("GTSFM_ATTENTION_SPLIT")
+    default = run()
+    for key in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+        np.testing.assert_array_equal(batch_like[key], single_like[key])
+        np.testing.assert_array_equal(batch_like[key], default[key])
+    assert (default["matches0"] > -1).sum() > 50
+    if matcher == "lightglue":
+        assert default["kept"][0] < n0  # point pruning was active: the GEMMs ran on per-tile live counts

@@ -204,6 +204,34 @@ def test_linear_rowmajor_aligned_layout(lib, gpu_device, m, k, n, relu, res, m_l
     assert float((got[:m_live, 4 : n_live + 4] - ref[:m_live, :n_live]).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("m,k,n,relu,res,alpha,m_live", [(4096, 256, 768, 0, 0, 1.0, 4096), (4096, 512, 256, 0, 1, 1.0, 4096), (1000, 512, 512, 1, 1, 0.5, 1000),
+                                                         (10240, 256, 512, 0, 0, 1.0, 10240), (70, 256, 256, 1, 0, 0.25, 70), (1, 32, 64, 0, 1, 1.0, 1),
+                                                         (2500, 512, 132, 0, 0, 1.0, 2100)])
+def test_linear_small_tiles_are_bit_identical_to_large_tiles(lib, gpu_device, monkeypatch, m, k, n, relu, res, alpha, m_live):
+    """Launches that would not fill the chip with 128 x 128 tiles (one keypoint-set pair: the per-call plugin API) run on 64 x 64
+    tiles (gemm_dma_small_kernel). Same k-ordered MFMA chain per output element and the same epilogue: the two tilings must agree
+    BIT FOR BIT, so that which one runs stays a launch-geometry decision (batched == single-pair results)."""
+    gen = torch.Generator().manual_seed(m + 7 * k + n)
+    ad = torch.randn((m, k), generator=gen).to(gpu_device)
+    wd = (torch.randn((n, k), generator=gen) / k**0.5).to(gpu_device)
+    bp = _pad64(torch.randn((n,), generator=gen), gpu_device)
+    rd = torch.randn((m, n + 4), generator=gen).to(gpu_device)
+    md = torch.tensor([m_live], dtype=torch.int32, device=gpu_device)
+
+    def run(small_below):
+        monkeypatch.setenv("GTSFM_GEMM_SMALL_BELOW", str(small_below))
+        out = torch.full((m, n + 8), -5.0, device=gpu_device)
+        _check(lib, lib.gtsfm_linear_rowmajor_f32(ad.data_ptr(), k, m, md.data_ptr() if m_live < m else None, k, wd.data_ptr(), k, bp.data_ptr(), n, None,
+                                                  out.data_ptr(), n + 8, 4, rd.data_ptr() if res else None, n + 4, alpha, relu, _stream()))
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    large, small = run(0), run(1 << 40)
+    assert torch.equal(large, small)
+    assert torch.all(small[:, :4] == -5.0) and torch.all(small[:, n + 4 :] == -5.0) and torch.all(small[m_live:] == -5.0)
+    assert float(small[:m_live, 4 : n + 4].abs().max()) > 0.1
+
+
 def test_linear_with_packed_activation_operand(lib, gpu_device):
     """A B^T of two activation matrices through pack_rows (score GEMM, superglue.py:257-258)."""
     a, b = torch.randn((150, 256)), torch.randn((90, 256))
