@@ -364,9 +364,11 @@ def fewest_images_for(pairs: int) -> int:
 
 
 def default_pair_chunk(keypoints: int) -> int:
-    """Pairs per launch sequence: ~70 k token rows per chunk (workspace ~2 GB per stream at the 5000 cap), a power of two in 4 .. 32."""
+    """Pairs per launch sequence: a power of two in 4 .. 32 with at most ~82 k keypoints per image side of a chunk (16 pairs and ~3.5 GB of
+    workspace per stream at the 5000 cap: the LightGlue rate does not depend on it -- 8 / 16 / 25 / 32 pairs: 111.7 / 111.7 / 112.1 / 112.2
+    image-pairs/s -- but SuperGlue's Sinkhorn sweeps fill the chip better with 16 score matrices in flight than with 8)."""
     c = 32
-    while c > 4 and c * keypoints > 70000:
+    while c > 4 and c * keypoints > 82000:
         c //= 2
     return c
 

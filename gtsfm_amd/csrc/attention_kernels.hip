@@ -72,6 +72,9 @@ __device__ unsigned long long* g_attn_trace;  // [workgroup][wave][10]: S issue,
 // The single-buffered form (198 VGPRs, 34 KiB) therefore stays the default.
 #define ATD_DBUF 0
 #endif
+#ifndef ATD_PARK_GLOBAL
+#define ATD_PARK_GLOBAL ATD_DBUF  // the fused schedule parks its merged state in the caller's workspace instead of LDS
+#endif
 #define ATD_LDS_TILE_FLOATS ((ATD_DBUF ? 2 : 1) * ATD_STAGE_FLOATS)
 #define ATD_OC_FLOATS (34 * 256)  // merged state between segments: 32 accumulator registers + (m, l), x 256 threads
 #ifndef ATD_WGS_PER_CU
@@ -113,10 +116,12 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
     // Ks + b * ATD_TILE_FLOATS, of V at Vs + b * ATD_VTILE_FLOATS
     float* Ks = lds;
     float* Vs = lds + (ATD_DBUF ? 2 : 1) * ATD_TILE_FLOATS;
-    // fused schedule only: this thread's merged (O, m, l) of the segments done so far is parked between segments -- in a
-    // workgroup-private slab of the caller's workspace (L2-resident; written and read once per 1024 keys), or behind the tiles in
-    // LDS when the caller gave none (gtsfm_attention_f32: at the price of one workgroup per CU). Thread-private slots: no barrier.
-    float* Oc = (!SPLIT && p.park) ? p.park + (size_t)blockIdx.x * ATD_OC_FLOATS : lds + ATD_LDS_TILE_FLOATS;
+    // fused schedule only: this thread's merged (O, m, l) of the segments done so far is parked between segments in a 34 KiB LDS
+    // slab behind the tiles (thread-private slots: no barrier). The double-buffered build has no LDS to spare for it and parks
+    // in a workgroup-private slab of the caller's workspace instead -- which the PMC counters showed as 1.4 GB of extra HBM-side
+    // traffic per 32-sequence launch at N = 5000 (5120 workgroups x 34 KiB x 4 segment boundaries, written and read back):
+    // harmless for the time of an MFMA-bound kernel, but one more reason the single-buffered form is the default.
+    float* Oc = (ATD_PARK_GLOBAL && !SPLIT && p.park) ? p.park + (size_t)blockIdx.x * ATD_OC_FLOATS : lds + ATD_LDS_TILE_FLOATS;
     // XCD-aware block order (speed only): workgroups are dispatched round-robin over the 8 XCDs, each with a private L2. All
     // query tiles (and segments) of one (problem, head) share the same K / V, so they get linear ids that are congruent
     // mod 8 -> same XCD -> K / V are fetched into ONE L2 instead of eight.
@@ -457,7 +462,7 @@ static int at_fused_grid(int nproblems, int heads, int max_q) { return ceil_div(
 size_t attention_workspace_floats(int nproblems, int heads, int max_q, int max_k, size_t rows) {
     if (nproblems <= 0 || at_segments(max_k) < 2) return 0;  // one segment: neither schedule needs memory
     const size_t split = (size_t)at_segments(max_k) * rows * ((size_t)heads * 64 + (size_t)heads * 2);
-    const size_t park = (size_t)at_fused_grid(nproblems, heads, max_q) * ATD_OC_FLOATS;
+    const size_t park = ATD_PARK_GLOBAL ? (size_t)at_fused_grid(nproblems, heads, max_q) * ATD_OC_FLOATS : 0;  // single buffers: parked in LDS
     // the schedule is picked per launch (and can be forced): hold enough for whichever the launch geometry picks
     return at_wants_split(nproblems, heads, max_q, max_k) ? (split > park ? split : park) : park;
 }
@@ -487,8 +492,8 @@ int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t 
         q.nseg = 1;
         dim3 grid(at_fused_grid(nproblems, p.heads, max_q));
         size_t lds_bytes = tile_bytes;
-        if (p.workspace && p.workspace_floats >= (size_t)grid.x * ATD_OC_FLOATS) {
-            q.park = p.workspace;  // merged state between segments in the workspace: two workgroups per CU
+        if (ATD_PARK_GLOBAL && p.workspace && p.workspace_floats >= (size_t)grid.x * ATD_OC_FLOATS) {
+            q.park = p.workspace;  // (double-buffered build) merged state between segments in the workspace: two workgroups per CU
         } else if (p.max_k <= 0 || at_segments(max_k) > 1) {
             q.lds_has_oc = 1;      // ... in LDS behind the tiles (callers without a workspace)
             lds_bytes += (size_t)ATD_OC_FLOATS * sizeof(float);

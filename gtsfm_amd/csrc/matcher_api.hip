@@ -205,7 +205,8 @@ extern "C" int gtsfm_attention_f32(const float* q_dev, int ldq, const float* k_d
 
 extern "C" size_t gtsfm_attention_split_workspace_bytes(int nproblems, int max_q, int max_k, int heads, size_t rows) {
     // enough for either schedule: the split schedule's partial states (one unnormalised O row + (m, l) per head, key segment and
-    // token row) or the fused schedule's parking space (34 floats per thread of the launch)
+    // token row) or the parking space of the fused schedule's double-buffered build (34 floats per thread of the launch; the default
+    // build parks in LDS and ignores it)
     const int nseg = (((max_k < 1 ? 1 : max_k) + 63) / 64 + 15) / 16;
     const size_t split = (size_t)nseg * rows * ((size_t)heads * 64 + (size_t)heads * 2);
     const size_t park = (size_t)((heads * nproblems + 7) / 8 * 8) * ((max_q + 127) / 128) * 34 * 256;

@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import threading
 from collections import OrderedDict
 from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 
@@ -124,6 +125,9 @@ class _MatcherBase:
         self._pinning = False
         self.desc_cache_capacity = 64
         self._staging: Optional[dict] = None
+        # match_pair() re-uses the engine's staging buffers and workspace: calls from several threads of one worker process
+        # (Dask workers can be configured with more than one) take turns
+        self._pair_lock = threading.Lock()
 
     def _stage_pair(self, arrays0: Sequence[np.ndarray], arrays1: Sequence[np.ndarray]) -> List[torch.Tensor]:
         """Host arrays of the two images of ONE pair -> device tensors [n0 + n1, ...], one per array: converted to float32 straight
@@ -298,13 +302,14 @@ class SuperGlueEngine(_MatcherBase):
                 "matches0": np.full(n0, -1, dtype=np.int32), "matches1": np.full(n1, -1, dtype=np.int32),
                 "matching_scores0": np.zeros(n0, dtype=np.float32), "matching_scores1": np.zeros(n1, dtype=np.float32),
             }
-        kp, sc, de = self._stage_pair((k0, s0, d0), (k1, s1, d1))
-        out = self.match_batch(
-            kp, sc.reshape(-1), de, [n0], [n1], [[shape0[0], shape0[1], shape1[0], shape1[1]]],
-            sinkhorn_iterations, match_threshold, return_ot,
-        )
-        m = out["matches"].cpu().numpy().astype(np.int64)
-        ms = out["mscores"].cpu().numpy()
+        with self._pair_lock:
+            kp, sc, de = self._stage_pair((k0, s0, d0), (k1, s1, d1))
+            out = self.match_batch(
+                kp, sc.reshape(-1), de, [n0], [n1], [[shape0[0], shape0[1], shape1[0], shape1[1]]],
+                sinkhorn_iterations, match_threshold, return_ot,
+            )
+            m = out["matches"].cpu().numpy().astype(np.int64)
+            ms = out["mscores"].cpu().numpy()
         res = {"matches0": m[:n0], "matches1": m[n0:], "matching_scores0": ms[:n0], "matching_scores1": ms[n0:]}
         if return_ot:
             ld = (n1 + 1 + 3) // 4 * 4
@@ -484,10 +489,12 @@ class LightGlueEngine(_MatcherBase):
                 "matches0": np.full(n0, -1, dtype=np.int64), "matches1": np.full(n1, -1, dtype=np.int64),
                 "matching_scores0": np.zeros(n0, dtype=np.float32), "matching_scores1": np.zeros(n1, dtype=np.float32), "stop": 1,
             }
-        kp, de = self._stage_pair((k0, d0), (k1, d1))
-        out = self.match_batch(kp, de, [n0], [n1], [[shape0[0], shape0[1], shape1[0], shape1[1]]], **kwargs)
-        m = out["matches"].cpu().numpy().astype(np.int64)
-        ms = out["mscores"].cpu().numpy()
+        with self._pair_lock:
+            kp, de = self._stage_pair((k0, d0), (k1, d1))
+            out = self.match_batch(kp, de, [n0], [n1], [[shape0[0], shape0[1], shape1[0], shape1[1]]], **kwargs)
+            m = out["matches"].cpu().numpy().astype(np.int64)
+            ms = out["mscores"].cpu().numpy()
+            out = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in out.items() if k in ("stop", "kept", "sim")}
         m0 = m[:n0]
         valid = m0 > -1
         res = {

@@ -7,6 +7,7 @@ PyTorch is used for device memory and streams only; all arithmetic runs in libgt
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, Mapping, Optional
 
 import numpy as np
@@ -146,6 +147,11 @@ class SuperPointEngine:
         array. The plugin selects on the host with the reference's own ``Keypoints`` methods and downloads only what it keeps
         (5000 of ~8000 rows at GTSfM's cap)."""
         assert gray.ndim == 2
+        lock = self.__dict__.setdefault("_detect_lock", threading.Lock())  # the pinned staging buffers are the engine's: one call at a time
+        with lock:
+            return self._detect_lazy_locked(gray, **kwargs)
+
+    def _detect_lazy_locked(self, gray: np.ndarray, **kwargs):
         stage = self._pinned("image", gray.shape, torch.uint8 if gray.dtype == np.uint8 else torch.float32)
         stage.numpy()[...] = gray
         img = stage.to(self.device, non_blocking=True)[None]
@@ -163,13 +169,14 @@ class SuperPointEngine:
 
         def fetch(indices: np.ndarray) -> np.ndarray:
             indices = np.asarray(indices, dtype=np.int64)
-            rows = self._pinned("descriptors", (len(indices), 256), torch.float32)
-            if len(indices):
-                idx = self._pinned("indices", (len(indices),), torch.int64)
-                idx.numpy()[...] = indices
-                rows.copy_(desc.index_select(0, idx.to(self.device, non_blocking=True)), non_blocking=True)
-                torch.cuda.current_stream(self.device).synchronize()
-            return rows.numpy().copy()
+            with self.__dict__["_detect_lock"]:
+                rows = self._pinned("descriptors", (len(indices), 256), torch.float32)
+                if len(indices):
+                    idx = self._pinned("indices", (len(indices),), torch.int64)
+                    idx.numpy()[...] = indices
+                    rows.copy_(desc.index_select(0, idx.to(self.device, non_blocking=True)), non_blocking=True)
+                    torch.cuda.current_stream(self.device).synchronize()
+                return rows.numpy().copy()
 
         return host[:, :2].copy(), host[:, 2].copy(), fetch
 

@@ -453,6 +453,33 @@ def test_batch_mixing_sweep_tiers_equals_single_pairs(gpu_device, matcher):
             assert (one["matches0"] > -1).sum() > 20
 
 
+@pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
+def test_eight_wave_sweep_tier_vs_oracle(gpu_device, matcher):
+    """Keypoint sets beyond 5120 (a user raising max_keypoints above GTSfM's default): the score matrix's rows are shared by the 8
+    waves of a 512-thread workgroup (Sinkhorn / double softmax / extraction); one layer keeps the CPU oracle to seconds."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+
+    n0, n1 = 260, 5300
+    k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(n0, n1, (1024, 1024), (1024, 1024), seed=61)
+    if matcher == "superglue":
+        sd = synthetic.synthetic_superglue_state_dict(num_layers=1)
+        res = ME.SuperGlueEngine(sd, gpu_device).match_pair(k0, s0, d0, k1, s1, d1, (1024, 1024), (1024, 1024), sinkhorn_iterations=20)
+        with torch.no_grad():
+            ora = sgo.superglue_forward(sd, T(k0)[None], T(k1)[None], T(s0)[None], T(s1)[None], T(d0).T[None].contiguous(), T(d1).T[None].contiguous(),
+                                        (1024, 1024), (1024, 1024), sinkhorn_iterations=20)
+    else:
+        sd = synthetic.synthetic_lightglue_state_dict(num_layers=1, match_bias=-2.0, match_gain=30.0)
+        res = ME.LightGlueEngine(sd, gpu_device).match_pair(k0, d0, k1, d1, (1024, 1024), (1024, 1024), pruning_threshold=None)
+        with torch.no_grad():
+            ora = lgo.lightglue_forward(sd, T(k0)[None], T(k1)[None], T(d0)[None], T(d1)[None], (1024, 1024), (1024, 1024), pruning_threshold=None,
+                                        return_intermediates=True)
+    np.testing.assert_array_equal(res["matches0"], ora["matches0"][0].numpy())
+    np.testing.assert_array_equal(res["matches1"], ora["matches1"][0].numpy())
+    np.testing.assert_allclose(res["matching_scores0"], ora["matching_scores0"][0].numpy(), rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(res["matching_scores1"], ora["matching_scores1"][0].numpy(), rtol=0, atol=SCORE_TOL)
+    assert (res["matches0"] > -1).sum() > 10
+
+
 def test_lightglue_fused_layernorm_epilogue_is_bit_identical(gpu_device, monkeypatch):
     """GTSFM_FUSED_LN=1: LayerNorm + GELU applied by the ffn.0 GEMM's workgroups to their own rows (opt-in)
     must give the same bits as the separate layernorm_gelu_kernel, incl. ragged sequences and early-stopped pairs."""

@@ -9,13 +9,13 @@ lib = L.load(); dev = torch.device("cuda:0")
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 num = [int(a) for a in sys.argv[2:]]
 if what in ("attention", "all"):
-    bench.measure_attention_roofline(lib, dev, *(num or [5000, 8]), reps=4)
+    bench.measure_attention_roofline(lib, dev, *(num or [5000, 16]), reps=4)
 if what == "gemm":
     bench.measure_gemm_roofline(lib, dev, *num, reps=4)
 if what == "all":
     for k, n in ((256, 768), (512, 512), (512, 256)):
-        bench.measure_gemm_roofline(lib, dev, 81920, k, n, reps=4)
+        bench.measure_gemm_roofline(lib, dev, 163840, k, n, reps=4)
 if what in ("sinkhorn", "all"):
-    bench.measure_sinkhorn_roofline(lib, dev, *(num or [5000, 8]), iters=4)
+    bench.measure_sinkhorn_roofline(lib, dev, *(num or [5000, 16]), iters=4)
 if what in ("conv", "all"):
     bench.measure_conv_roofline(lib, dev, 8, 1024, 1024, reps=2)

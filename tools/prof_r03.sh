@@ -11,7 +11,7 @@ B="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --streams 1 --graphs 0 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lg -o lg -- $B --pairs 100 > $OUT/lg.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sg -o sg -- $B --matcher superglue --sinkhorn 20 --pairs 64 > $OUT/sg.log 2>&1
 find $OUT -name "*kernel_trace.csv" -delete
-for W in "attention 5000 8" "gemm 81920 256 768" "gemm 81920 512 512" "gemm 81920 512 256" "sinkhorn 5000 8"; do
+for W in "attention 5000 16" "gemm 163840 256 768" "gemm 163840 512 512" "gemm 163840 512 256" "sinkhorn 5000 16"; do
   TAG=$(echo $W | tr ' ' '_')
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$C -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_kernels.py $W > $OUT/pmc_${TAG}_$C.log 2>&1
