@@ -688,18 +688,34 @@ def main() -> None:
                 else:  # dominant kernel of this workload first; the other kernels alongside
                     result["roofline"] = measure_attention_roofline(lib, device, args.keypoints, chunk_pairs)
                     rows = 2 * chunk_pairs * (-(-args.keypoints // 128) * 128)  # LightGlue aligns every keypoint set to 128 rows
-                    other = [measure_gemm_roofline(lib, device, rows, k, nn) for k, nn in ((256, 768), (512, 512), (512, 256), (256, 512))]
-                    other.append(measure_score_gemm_roofline(lib, device, args.keypoints, chunk_pairs))
-                    other.append(measure_sinkhorn_roofline(lib, device, args.keypoints, chunk_pairs))  # SuperGlue legs (headline or secondary)
+                    def guarded(fn, *fargs):  # a secondary kernel's micro-measurement must not cost the line its headline
+                        try:
+                            return fn(*fargs)
+                        except Exception as exc:  # noqa: BLE001
+                            torch.cuda.synchronize(device)
+                            return {"kernel": fn.__name__, "error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+
+                    other = [guarded(measure_gemm_roofline, lib, device, rows, k, nn) for k, nn in ((256, 768), (512, 512), (512, 256), (256, 512))]
+                    other.append(guarded(measure_score_gemm_roofline, lib, device, args.keypoints, chunk_pairs))
+                    other.append(guarded(measure_sinkhorn_roofline, lib, device, args.keypoints, chunk_pairs))  # SuperGlue legs (headline or secondary)
                     result["roofline_other"] = [r for r in other if r is not None] + [conv_roof]
             if world == 1 and not args.no_secondary and not detect_only and not scene and args.pair_definition == "exhaustive":
-                result["secondary"] = secondary_rates(args, detector, matcher, device, h, w, mk, not args.no_cpu_baseline)
+                # every leg has its own timed region and must not be able to take the headline line down with it
+                def leg(name, fn, *fargs):
+                    try:
+                        return fn(*fargs)
+                    except Exception as exc:  # noqa: BLE001
+                        torch.cuda.synchronize(device)
+                        return {"error": f"{type(exc).__name__}: {str(exc)[:300]}", "leg": name}
+
+                sec = leg("secondary_rates", secondary_rates, args, detector, matcher, device, h, w, mk, not args.no_cpu_baseline)
+                result["secondary"] = sec if "error" not in sec else {"rates": sec}
                 if getattr(pipe, "last_shared_images", 0):
-                    result["secondary"]["headline_per_pair_first_layer"] = unshared_rate(args, detector, matcher, images, pairs, shapes, mk)
+                    result["secondary"]["headline_per_pair_first_layer"] = leg("unshared", unshared_rate, args, detector, matcher, images, pairs, shapes, mk)
                 if args.matcher == "lightglue":
-                    result["secondary"]["lightglue_adaptive_depth"] = adaptive_depth_rate(args, detector, device, images, pairs, shapes)
-                result["secondary"]["verifier_stage"] = verifier_rate(pipe, feats, res, h, w, ms_per_step, device, not args.no_cpu_baseline)
-                result["secondary"]["plugin_api"] = plugin_api_rate(args, pipe, views_np, device, h, w)
+                    result["secondary"]["lightglue_adaptive_depth"] = leg("adaptive", adaptive_depth_rate, args, detector, device, images, pairs, shapes)
+                result["secondary"]["verifier_stage"] = leg("verifier", verifier_rate, pipe, feats, res, h, w, ms_per_step, device, not args.no_cpu_baseline)
+                result["secondary"]["plugin_api"] = leg("plugin_api", plugin_api_rate, args, pipe, views_np, device, h, w)
             if world == 1 and not args.no_cpu_baseline:  # rank 0 at N = 1 only
                 first = all_pairs[0] if all_pairs else (0, min(1, len(views_np) - 1))
                 view_of = (lambda s: (5 * s) % args.images) if independent else (lambda s: s)  # noqa: E731
