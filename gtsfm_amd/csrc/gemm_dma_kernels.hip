@@ -212,7 +212,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): next stage's DMA, bias / residual / rotary loads; older stores are long done
         __syncthreads();  // (also after the last stage: the epilogue below re-uses the consumed buffer as scratch)
         GT_SEG(3)
+#ifdef GTSFM_GEMM_ABLATE_EPILOGUE  // developer ablation (tools/build_variant.sh): what a fully hidden epilogue would buy -- results are garbage
+        if (last && p.alpha == 12345.f) {
+#else
         if (last) {
+#endif
             // epilogue of column block cbi; its stores drain under the next block's MFMAs
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
