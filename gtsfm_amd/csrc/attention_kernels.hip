@@ -268,9 +268,13 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
         // the same query): m follows the running maximum only when that has moved by more than AT_REBASE (base-2 units),
         // so exp2(s - m) <= 2^AT_REBASE stays far from overflow while most tiles skip the rebase (subtract + rescale of O
         // and l) entirely. out = O / l does not depend on the choice of m.
+#if defined(AT_ABLATE) && (AT_ABLATE & 1)  // developer ablation builds (tools/build_variant.sh; results are garbage): bit 1 = no softmax arithmetic
+        float mloc = sc0[0];
+#else
         float mloc = fmaxf(sc0[0], sc1[0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(sc0[r], sc1[r]));
+#endif
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));  // finite on every tile: key k0 is always valid
         const bool rebase = (ts == 0) || (mloc > AT_REBASE);
         float d = 0.f;
@@ -293,12 +297,16 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
             m += d;
         }
         float lsum = 0.f;
+#if defined(AT_ABLATE) && (AT_ABLATE & 1)
+        lsum = sc0[3] + sc1[5];
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             sc0[r] = __builtin_amdgcn_exp2f(sc0[r]);
             sc1[r] = __builtin_amdgcn_exp2f(sc1[r]);
             lsum += sc0[r] + sc1[r];
         }
+#endif
         lsum += __shfl_xor(lsum, 32, 64);
         l += lsum;
         // the next tile was accumulated relative to m_start; bring it to the (possibly rebased) reference
@@ -311,9 +319,13 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
         }
         TRACE_SEG(1)
         if (!ATD_DBUF) {
+#if !(defined(AT_ABLATE) && (AT_ABLATE & 2))  // bit 2 = no waits, no barriers in the tile loop
             __builtin_amdgcn_s_waitcnt(0x0f70);  // own V(t) DMA landed (issued one phase ago)
             __syncthreads();                     // B1: K buffer free, V(t) visible
+#endif
+#if !(defined(AT_ABLATE) && (AT_ABLATE & 4))  // bit 4 = no tile DMA in the loop
             if (t + 2 < t_end) tile_dma(kbase, p.ldk, k0 + 2 * AT_KT, Ks, false);
+#endif
             TRACE_SEG(2)
         }
         // ---- phase 2: O^T += V^T P^T. Accumulator register r of S^T tile T holds key 32T + (r&3) + 8(r>>2) + 4kh, so it IS
@@ -335,9 +347,13 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
         }
         TRACE_SEG(3)
         if (!ATD_DBUF && more) {
+#if !(defined(AT_ABLATE) && (AT_ABLATE & 2))
             __builtin_amdgcn_s_waitcnt(0x0f70);  // own K(t+2) DMA landed
             __syncthreads();                     // B2: V buffer free, K(t+2) visible
+#endif
+#if !(defined(AT_ABLATE) && (AT_ABLATE & 4))
             tile_dma(vbase, p.ldv, k0 + AT_KT, Vs, true);
+#endif
         }
         TRACE_SEG(4)
         // ---- fused schedule, end of a segment: fold (O, m, l) into the merged state, which waits in Oc (each thread reads and
