@@ -72,6 +72,12 @@ __device__ unsigned long long* g_attn_trace;  // [workgroup][wave][10]: S issue,
 // The single-buffered form (198 VGPRs, 34 KiB) therefore stays the default.
 #define ATD_DBUF 0
 #endif
+#ifndef ATD_UNROLL2
+// Single-buffered loop unrolled twice (the two score tiles swap roles instead of being copied): 166 -> 207 VGPRs, still two waves per
+// SIMD; A/B/A on one box (tools/bench_attention.py): 2.106 / 2.071 / 2.107 ms for 64 sequences at N = 2048, 3.227 / 3.163 / 3.238 ms
+// for 16 at N = 5000 (rolled / unrolled / rolled): +1.7 % / +2.0 %. The softmax-phase VALU work is what the ablations price highest.
+#define ATD_UNROLL2 1
+#endif
 #ifndef ATD_PARK_GLOBAL
 #define ATD_PARK_GLOBAL ATD_DBUF  // the fused schedule parks its merged state in the caller's workspace instead of LDS
 #endif
@@ -390,10 +396,18 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
             tile_step(std::integral_constant<int, 1>{}, sb0, sb1, sa0, sa1, t + 1);
         }
     } else {
-        for (int t = t_begin; t < t_end; ++t) {  // (unrolled twice to spare the 32 moves the loop needs 9 registers more than it has)
+#if ATD_UNROLL2  // two tiles per iteration, the score tiles swapping roles: spares 32 register moves per tile
+        for (int t = t_begin; t < t_end; t += 2) {
+            tile_step(std::integral_constant<int, 0>{}, sa0, sa1, sb0, sb1, t);
+            if (t + 1 >= t_end) break;
+            tile_step(std::integral_constant<int, 0>{}, sb0, sb1, sa0, sa1, t + 1);
+        }
+#else
+        for (int t = t_begin; t < t_end; ++t) {
             tile_step(std::integral_constant<int, 0>{}, sa0, sa1, sb0, sb1, t);
             sa0 = sb0, sa1 = sb1;
         }
+#endif
     }
 #ifdef GTSFM_TRACE
     if (lane == 0 && g_attn_trace) {
