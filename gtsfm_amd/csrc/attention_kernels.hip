@@ -34,7 +34,7 @@
 #include "mfma_tiles.h"
 
 #define AT_KT 64       // keys per tile
-#define AT_QB 128      // queries per workgroup
+#define AT_QB 128      // queries per workgroup of 4 waves (the 8-wave form of the fused schedule owns 256)
 #define AT_REBASE 8.0f  // rebase the softmax reference when the running maximum moved by more than this (base-2 units)
 #ifndef AT_SEG_TILES
 #define AT_SEG_TILES 16  // key tiles per segment
@@ -71,6 +71,9 @@ __device__ unsigned long long* g_attn_trace;  // [workgroup][wave][10]: S issue,
 // rest of the gap to the nominal peak is clock (2.16 GHz under the profiler's counters, profiles/r03_effective_clock.csv).
 // The single-buffered form (198 VGPRs, 34 KiB) therefore stays the default.
 #define ATD_DBUF 0
+#endif
+#ifndef ATD_FUSED_WAVES
+#define ATD_FUSED_WAVES 4  // waves per workgroup of the fused schedule
 #endif
 #ifndef ATD_UNROLL2
 // Single-buffered loop unrolled twice (the two score tiles swap roles instead of being copied): 166 -> 207 VGPRs, still two waves per
@@ -115,8 +118,11 @@ __device__ __forceinline__ float at_merge(float acc, float seg, const AtMergeWei
     return __fadd_rn(__fmul_rn(acc, w.a), __fmul_rn(seg, w.b));
 }
 
-template <bool SPLIT>
-__global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(AttnParams p) {
+// NWV = waves per workgroup: 4 (128 queries, two workgroups per CU) or 8 (256 queries, one workgroup per CU: every K / V tile that
+// travels into LDS then serves twice as many queries). A query's arithmetic does not depend on NWV.
+template <bool SPLIT, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? ATD_WGS_PER_CU : 1) void attention_dma_kernel(AttnParams p) {
+    constexpr int NT = 64 * NWV;  // threads
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // LDS: K tile(s) [64 keys][64 floats] swizzled, then V tile(s) in padded 4-row blocks (see velem); buffer b of K at
     // Ks + b * ATD_TILE_FLOATS, of V at Vs + b * ATD_VTILE_FLOATS
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
     // in a workgroup-private slab of the caller's workspace instead -- which the PMC counters showed as 1.4 GB of extra HBM-side
     // traffic per 32-sequence launch at N = 5000 (5120 workgroups x 34 KiB x 4 segment boundaries, written and read back):
     // harmless for the time of an MFMA-bound kernel, but one more reason the single-buffered form is the default.
-    float* Oc = (ATD_PARK_GLOBAL && !SPLIT && p.park) ? p.park + (size_t)blockIdx.x * ATD_OC_FLOATS : lds + ATD_LDS_TILE_FLOATS;
+    float* Oc = (ATD_PARK_GLOBAL && !SPLIT && p.park) ? p.park + (size_t)blockIdx.x * (34 * NT) : lds + ATD_LDS_TILE_FLOATS;
     // XCD-aware block order (speed only): workgroups are dispatched round-robin over the 8 XCDs, each with a private L2. All
     // query tiles (and segments) of one (problem, head) share the same K / V, so they get linear ids that are congruent
     // mod 8 -> same XCD -> K / V are fetched into ONE L2 instead of eight.
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
     const int h = g % p.heads;
     const AttnProblem pr = p.problems[g / p.heads];
     const int nq = p.counts[pr.q_cnt_idx], nk = p.counts[pr.k_cnt_idx];
-    const int q0 = (SPLIT ? within % p.qtiles : within) * AT_QB;
+    const int q0 = (SPLIT ? within % p.qtiles : within) * (32 * NWV);
     if (q0 >= nq) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -193,8 +199,8 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
     const int dma_col_k = (dpos ^ ((4 * wave + drow) & 15)) << 2, dma_col_v = dpos << 2;
     auto tile_dma = [&](const float* base, int ld, int k0, float* dst, bool is_v) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rb = 16 * i + 4 * wave;
+        for (int i = 0; i < 16 / NWV; ++i) {  // 16 pieces of 4 rows per tile, 16 / NWV per wave: rows 4 NWV i + 4 wave .. + 3
+            const int rb = 4 * NWV * i + 4 * wave;
             int key = k0 + rb + drow;
             key = key < nk ? key : nk - 1;  // clamp: keys beyond nk are masked to -inf (their V rows meet P = 0)
             __builtin_amdgcn_global_load_lds(base + (size_t)key * ld + (is_v ? dma_col_v : dma_col_k), dst + (is_v ? (rb >> 2) * ATD_VBLOCK_FLOATS : rb * 64), 16, 0, 0);
@@ -366,24 +372,24 @@ __global__ __launch_bounds__(256, ATD_WGS_PER_CU) void attention_dma_kernel(Attn
         // writes only its own 34 slots, so no barrier is involved) while the registers serve the next segment.
         if (!SPLIT && (next_fresh || (!more && t >= AT_SEG_TILES))) {
             if (t >= AT_SEG_TILES) {  // not the first segment: merged <- merged (+) this segment
-                const AtMergeWeights w = at_merge_weights(Oc[32 * 256 + tid], m);
+                const AtMergeWeights w = at_merge_weights(Oc[32 * NT + tid], m);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    o0[r] = at_merge(Oc[r * 256 + tid], o0[r], w);
-                    o1[r] = at_merge(Oc[(16 + r) * 256 + tid], o1[r], w);
+                    o0[r] = at_merge(Oc[r * NT + tid], o0[r], w);
+                    o1[r] = at_merge(Oc[(16 + r) * NT + tid], o1[r], w);
                 }
-                l = at_merge(Oc[33 * 256 + tid], l, w);
+                l = at_merge(Oc[33 * NT + tid], l, w);
                 m = w.m;
             }
             if (more) {  // park the merged state (O, m, l) and start the next segment from a fresh one
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    Oc[r * 256 + tid] = o0[r];
-                    Oc[(16 + r) * 256 + tid] = o1[r];
+                    Oc[r * NT + tid] = o0[r];
+                    Oc[(16 + r) * NT + tid] = o1[r];
                     o0[r] = o1[r] = 0.f;
                 }
-                Oc[32 * 256 + tid] = m;
-                Oc[33 * 256 + tid] = l;
+                Oc[32 * NT + tid] = m;
+                Oc[33 * NT + tid] = l;
                 m = 0.f, l = 0.f;
             }
             TRACE_SEG(5)
@@ -487,12 +493,16 @@ static bool at_wants_split(int nproblems, int heads, int max_q, int max_k) {
     return (long long)nproblems * heads * ceil_div(max_q, AT_QB) < 2 * 256 * ATD_WGS_PER_CU;
 }
 
-static int at_fused_grid(int nproblems, int heads, int max_q) { return ceil_div(heads * nproblems, 8) * 8 * ceil_div(max_q, AT_QB); }
+static int at_fused_waves() {  // GTSFM_ATTENTION_WAVES = 4 | 8 (read per launch: A/B measurements; results are identical)
+    const char* env = getenv("GTSFM_ATTENTION_WAVES");
+    return env && env[0] == '8' ? 8 : (env && env[0] == '4' ? 4 : ATD_FUSED_WAVES);
+}
+static int at_fused_grid(int nproblems, int heads, int max_q) { return ceil_div(heads * nproblems, 8) * 8 * ceil_div(max_q, 32 * at_fused_waves()); }
 
 size_t attention_workspace_floats(int nproblems, int heads, int max_q, int max_k, size_t rows) {
     if (nproblems <= 0 || at_segments(max_k) < 2) return 0;  // one segment: neither schedule needs memory
     const size_t split = (size_t)at_segments(max_k) * rows * ((size_t)heads * 64 + (size_t)heads * 2);
-    const size_t park = ATD_PARK_GLOBAL ? (size_t)at_fused_grid(nproblems, heads, max_q) * ATD_OC_FLOATS : 0;  // single buffers: parked in LDS
+    const size_t park = ATD_PARK_GLOBAL ? (size_t)at_fused_grid(nproblems, heads, max_q) * (ATD_OC_FLOATS / 4 * at_fused_waves()) : 0;  // single buffers: parked in LDS
     // the schedule is picked per launch (and can be forced): hold enough for whichever the launch geometry picks
     return at_wants_split(nproblems, heads, max_q, max_k) ? (split > park ? split : park) : park;
 }
@@ -516,19 +526,24 @@ int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t 
         q.part_o = p.workspace;
         q.part_ml = p.workspace + (size_t)q.nseg * p.part_rows * p.heads * 64;
         dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles * q.nseg);
-        hipLaunchKernelGGL((attention_dma_kernel<true>), grid, dim3(256), tile_bytes, stream, q);
+        hipLaunchKernelGGL((attention_dma_kernel<true, 4>), grid, dim3(256), tile_bytes, stream, q);
         hipLaunchKernelGGL(attention_combine_kernel, dim3(ceil_div(max_q, 4), nproblems), dim3(256), 0, stream, q);
     } else {
         q.nseg = 1;
+        const int nwv = at_fused_waves();
+        q.qtiles = ceil_div(max_q, 32 * nwv);
         dim3 grid(at_fused_grid(nproblems, p.heads, max_q));
         size_t lds_bytes = tile_bytes;
-        if (ATD_PARK_GLOBAL && p.workspace && p.workspace_floats >= (size_t)grid.x * ATD_OC_FLOATS) {
+        if (ATD_PARK_GLOBAL && p.workspace && p.workspace_floats >= (size_t)grid.x * (ATD_OC_FLOATS / 4 * nwv)) {
             q.park = p.workspace;  // (double-buffered build) merged state between segments in the workspace: two workgroups per CU
         } else if (p.max_k <= 0 || at_segments(max_k) > 1) {
             q.lds_has_oc = 1;      // ... in LDS behind the tiles (callers without a workspace)
-            lds_bytes += (size_t)ATD_OC_FLOATS * sizeof(float);
+            lds_bytes += (size_t)ATD_OC_FLOATS / 4 * nwv * sizeof(float);
         }                          // else: the caller vouches for one segment (the kernel traps if a problem has more)
-        hipLaunchKernelGGL((attention_dma_kernel<false>), grid, dim3(256), lds_bytes, stream, q);
+        if (nwv == 8)
+            hipLaunchKernelGGL((attention_dma_kernel<false, 8>), grid, dim3(512), lds_bytes, stream, q);
+        else
+            hipLaunchKernelGGL((attention_dma_kernel<false, 4>), grid, dim3(256), lds_bytes, stream, q);
     }
     GTSFM_CHECK_LAUNCH("attention kernel");
     return GTSFM_OK;
