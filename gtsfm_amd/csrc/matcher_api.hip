@@ -186,7 +186,7 @@ extern "C" int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* 
 
 extern "C" int gtsfm_move_blocks_f32(const float* src_dev, const int32_t* src_index_dev, float* dst_dev, const int32_t* dst_index_dev, int nblocks,
                                      int64_t block_floats, void* stream) {
-    GTSFM_CHECK_ARG(src_dev && dst_dev && nblocks >= 0 && block_floats >= 0 && block_floats % 2 == 0, "move_blocks: bad arguments");
+    GTSFM_CHECK_ARG(src_dev && dst_dev && nblocks >= 0 && nblocks <= 65535 && block_floats >= 0 && block_floats % 2 == 0, "move_blocks: bad arguments (at most 65535 blocks of an even number of floats)");
     GTSFM_CHECK_ARG(((uintptr_t)src_dev | (uintptr_t)dst_dev) % 8 == 0, "move_blocks: arrays must be 8-byte aligned");
     return launch_move_blocks(src_dev, src_index_dev, dst_dev, dst_index_dev, nblocks, block_floats, (hipStream_t)stream);
 }
