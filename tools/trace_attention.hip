@@ -54,33 +54,16 @@ int main(int argc, char** argv) {
     printf("attention %d seq x %d: %.3f ms per launch, %.1f TFLOP/s (%.3f of 157.3)\n", nseq, n, ms, 1024.0 * n * n * nseq / (ms * 1e-3) / 1e12,
            1024.0 * n * n * nseq / (ms * 1e-3) / 1e12 / 157.3);
 #ifdef GTSFM_TRACE
-    // one more launch on its own for the clock: cycles between the first start and the last end of the workgroups of one XCD
-    // (the s_memtime counters of different XCDs are not synchronised) against the launch's HIP-event time
-    hipMemset(trace, 0, nwg * 4 * 10 * 8);
-    hipEventRecord(e0);
-    launch_attention(p, nseq, n, 0);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms1; hipEventElapsedTime(&ms1, e0, e1);
     std::vector<unsigned long long> t(nwg * 4 * 10);
     hipMemcpy(t.data(), trace, t.size() * 8, hipMemcpyDeviceToHost);
     double sum[8] = {0}; size_t waves = 0;
-    unsigned long long lo[8], hi[8];
-    for (int x = 0; x < 8; ++x) lo[x] = ~0ull, hi[x] = 0;
     for (size_t w = 0; w < nwg * 4; ++w) {
         if (t[w * 10 + 7] == 0) continue;
         ++waves;
         for (int k = 0; k < 8; ++k) sum[k] += (double)t[w * 10 + k];
-        const int x = (int)((w / 4) & 7);
-        if (t[w * 10 + 8] < lo[x]) lo[x] = t[w * 10 + 8];
-        if (t[w * 10 + 9] > hi[x]) hi[x] = t[w * 10 + 9];
     }
-    double span = 0;
-    for (int x = 0; x < 8; ++x) span += (double)(hi[x] - lo[x]) / 8;
-    printf("one launch: %.3f ms by HIP events, %.0f shader cycles from first workgroup start to last end (mean over the XCDs) -> %.2f GHz effective clock\n", ms1, span, span / (ms1 * 1e-3) / 1e9);
     const char* names[6] = {"S(t+1) MFMA issue", "mask + softmax VALU", "vmcnt + barrier 1 + K DMA issue", "PV MFMA issue", "vmcnt + barrier 2 + V DMA issue + sc=sn", "segment merge"};
-    const double tiles = sum[7] / waves;
-    printf("workgroup slots busy: wave lifetime x workgroups / (512 slots x span) = %.3f\n", (sum[6] / waves) * (waves / 4.0) / (512.0 * span));
+    const double tiles = sum[7] / waves;  // (the effective clock comes from GRBM_GUI_ACTIVE, tools/prof_clock.sh: s_memtime counters of different CUs are not comparable)
     printf("%zu waves, %.1f tiles each; per wave and TILE (shader-clock cycles; two waves share a SIMD's matrix pipe: 2 x 8192 = 16384 when it never idles):\n", waves, tiles);
     double acc = 0;
     for (int k = 0; k < 6; ++k) { printf("  %-42s %9.0f\n", names[k], sum[k] / waves / tiles); acc += sum[k] / waves / tiles; }
