@@ -75,6 +75,13 @@ __device__ unsigned long long* g_attn_trace;  // [workgroup][wave][10]: S issue,
 #ifndef ATD_FUSED_WAVES
 #define ATD_FUSED_WAVES 4  // waves per workgroup of the fused schedule
 #endif
+#ifndef ATD_INTERLEAVE_SOFTMAX
+// 1: the S(t+1) MFMAs and the softmax VALU of tile t as ONE fenced, interleaved instruction stream (8 MFMAs, then a quarter of the row
+// maximum / of the exponentials, ...). Built on the hypothesis that the two workgroups of a CU fall into step and idle the matrix pipe
+// together during their softmax phases (the ~1.5 k idle cycles per tile of the cycle budget); measured A/B/A on one box: 2.047 / 2.031 /
+// 2.047 ms (64 sequences, N = 2048) and 3.146 / 3.130 / 3.145 ms (16, N = 5000), interleaved / plain / interleaved: 0.6 % SLOWER. Off.
+#define ATD_INTERLEAVE_SOFTMAX 0
+#endif
 #ifndef ATD_UNROLL2
 // Single-buffered loop unrolled twice (the two score tiles swap roles instead of being copied): 166 -> 207 VGPRs, still two waves per
 // SIMD; A/B/A on one box (tools/bench_attention.py): 2.106 / 2.071 / 2.107 ms for 64 sequences at N = 2048, 3.227 / 3.163 / 3.238 ms
@@ -99,6 +106,18 @@ __device__ __forceinline__ void mfma8(f32x16& acc0, f32x16& acc1, const f32x4 a0
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+}
+
+// A query's keys live in the two 32-lane halves of the wave: combine a per-lane value with the other half's. v_permlane32_swap (gfx950)
+// exchanges the upper half of one register with the lower half of another in the VALU -- `__shfl_xor(v, 32)` is a ds_bpermute, an LDS
+// round trip on the softmax's critical path twice per tile. Same values, same (commutative) operation: bit-identical to the shuffle form.
+__device__ __forceinline__ float at_halves_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float at_halves_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // THE merge of two softmax partial states over disjoint key sets, (O, m, l) <- (O, m, l) (+) (Os, ms, ls): m are reference
@@ -247,12 +266,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? ATD_WGS_PER_CU : 1) void atten
     // raised wave priority over the softmax, round 3: the softmax phase shrinks from 2.9 k to 2.0 k cycles per tile and the
     // barrier waits grow by as much, tools/trace_attention.hip.)
     TRACE_DECL
-    auto tile_step = [&](auto par_c, f32x16& sc0, f32x16& sc1, f32x16& sn0, f32x16& sn1, const int t) {
+    auto tile_step = [&](auto par_c, auto last_c, f32x16& sc0, f32x16& sc1, f32x16& sn0, f32x16& sn1, const int t) {
         constexpr int PAR = decltype(par_c)::value;
+        constexpr bool more = !decltype(last_c)::value;  // compile time: the last tile of the walk has its own body (no S phase to interleave with)
         constexpr int KB = ATD_DBUF ? PAR : 0, KB_NEXT = ATD_DBUF ? PAR ^ 1 : 0, VB = ATD_DBUF ? PAR : 0, VB_NEXT = ATD_DBUF ? PAR ^ 1 : 0;
         const int k0 = t * AT_KT;
         const int ts = t % AT_SEG_TILES;  // tile index inside its segment (t_begin is a multiple of AT_SEG_TILES)
-        const bool more = t + 1 < t_end;
         const bool next_fresh = !SPLIT && more && ts == AT_SEG_TILES - 1;  // fused: the next tile opens a new segment
         if (ATD_DBUF) {
             __builtin_amdgcn_s_waitcnt(0x0f70);  // own pieces of K(t+1) and V(t) landed (issued one tile ago)
@@ -266,9 +285,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? ATD_WGS_PER_CU : 1) void atten
         // difference is applied below when that tile is soft-maxed: its own rebase test sees scores relative to the old m.
         // A tile that opens a segment starts from reference 0, like the very first one.)
         const float m_start = m;
-        if (more) s_phase(KB_NEXT, sn0, sn1, next_fresh ? 0.f : -m_start);
-        TRACE_SEG(0)
-        if (k0 + AT_KT > nk) {  // mask (last tile only)
+        if (!more && k0 + AT_KT > nk) {  // mask: only the last tile of the keys can be partial (compiled into the last-tile body only)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -280,14 +297,64 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? ATD_WGS_PER_CU : 1) void atten
         // the same query): m follows the running maximum only when that has moved by more than AT_REBASE (base-2 units),
         // so exp2(s - m) <= 2^AT_REBASE stays far from overflow while most tiles skip the rebase (subtract + rescale of O
         // and l) entirely. out = O / l does not depend on the choice of m.
+        auto row_max = [&]() {
 #if defined(AT_ABLATE) && (AT_ABLATE & 1)  // developer ablation builds (tools/build_variant.sh; results are garbage): bit 1 = no softmax arithmetic
-        float mloc = sc0[0];
+            return sc0[0];
 #else
-        float mloc = fmaxf(sc0[0], sc1[0]);
+            float mx = fmaxf(sc0[0], sc1[0]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(sc0[r], sc1[r]));
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sc0[r], sc1[r]));
+            return mx;
 #endif
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));  // finite on every tile: key k0 is always valid
+        };
+        auto exponentiate = [&]() {
+            float sum = 0.f;
+#if defined(AT_ABLATE) && (AT_ABLATE & 1)
+            sum = sc0[3] + sc1[5];
+#else
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc0[r] = __builtin_amdgcn_exp2f(sc0[r]);
+                sc1[r] = __builtin_amdgcn_exp2f(sc1[r]);
+                sum += sc0[r] + sc1[r];
+            }
+#endif
+            return sum;
+        };
+        float mloc;
+#if ATD_INTERLEAVE_SOFTMAX
+        // The S(t+1) MFMAs and the softmax VALU of tile t as ONE instruction stream (two straight-line blocks around the rare
+        // rebase branch): a wave that issues its 64 S MFMAs first and its ~90 softmax instructions afterwards offers the matrix
+        // pipe nothing for the length of the softmax, and the two workgroups of a CU fall into step (the one behind has the pipe to
+        // itself while the other is in its softmax, and catches up), so both idle the pipe together: ~1.5 k cycles per tile in the
+        // cycle budget. Interleaved, every gap between two MFMAs carries two or three VALU instructions and no such phase exists.
+        if (more) {
+            const float neg_m = next_fresh ? 0.f : -m_start;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sn0[r] = sn1[r] = neg_m;
+            // four k-steps, each: 8 MFMAs + the maximum over 8 of the 32 scores, fenced so that the scheduler keeps the interleave
+            mloc = -__builtin_inff();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mfma8(sn0, sn1, kfrag(KB_NEXT, j, u), kfrag(KB_NEXT, 32 + j, u), qreg[u]);
+#if !(defined(AT_ABLATE) && (AT_ABLATE & 1))
+#pragma unroll
+                for (int r = 4 * u; r < 4 * u + 4; ++r) mloc = fmaxf(mloc, fmaxf(sc0[r], sc1[r]));
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#if defined(AT_ABLATE) && (AT_ABLATE & 1)
+            mloc = sc0[0];
+#endif
+        } else {
+            mloc = row_max();
+        }
+#else
+        if (more) s_phase(KB_NEXT, sn0, sn1, next_fresh ? 0.f : -m_start);
+        TRACE_SEG(0)
+        mloc = row_max();
+#endif
+        mloc = at_halves_max(mloc);  // finite on every tile: key k0 is always valid
         const bool rebase = (ts == 0) || (mloc > AT_REBASE);
         float d = 0.f;
         if (__any(rebase)) {  // wave-uniform
@@ -308,18 +375,33 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? ATD_WGS_PER_CU : 1) void atten
             }
             m += d;
         }
-        float lsum = 0.f;
-#if defined(AT_ABLATE) && (AT_ABLATE & 1)
-        lsum = sc0[3] + sc1[5];
-#else
+        float lsum;
+#if ATD_INTERLEAVE_SOFTMAX
+        if (more) {
+            lsum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sc0[r] = __builtin_amdgcn_exp2f(sc0[r]);
-            sc1[r] = __builtin_amdgcn_exp2f(sc1[r]);
-            lsum += sc0[r] + sc1[r];
-        }
+            for (int u = 4; u < 8; ++u) {  // each k-step: 8 MFMAs + 8 of the 32 exponentials and their sum
+                mfma8(sn0, sn1, kfrag(KB_NEXT, j, u), kfrag(KB_NEXT, 32 + j, u), qreg[u]);
+#if !(defined(AT_ABLATE) && (AT_ABLATE & 1))
+#pragma unroll
+                for (int r = 4 * (u - 4); r < 4 * (u - 4) + 4; ++r) {
+                    sc0[r] = __builtin_amdgcn_exp2f(sc0[r]);
+                    sc1[r] = __builtin_amdgcn_exp2f(sc1[r]);
+                    lsum += sc0[r] + sc1[r];
+                }
 #endif
-        lsum += __shfl_xor(lsum, 32, 64);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#if defined(AT_ABLATE) && (AT_ABLATE & 1)
+            lsum = sc0[3] + sc1[5];
+#endif
+        } else {
+            lsum = exponentiate();
+        }
+#else
+        lsum = exponentiate();
+#endif
+        lsum = at_halves_sum(lsum);
         l += lsum;
         // the next tile was accumulated relative to m_start; bring it to the (possibly rebased) reference
         if (more && !next_fresh && __any(d != 0.f)) {
@@ -395,26 +477,31 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? ATD_WGS_PER_CU : 1) void atten
             TRACE_SEG(5)
         }
     };
-    if (ATD_DBUF) {
-        for (int t = t_begin; t < t_end; t += 2) {  // t_begin is even (a multiple of AT_SEG_TILES): parity of t = parity inside the segment
-            tile_step(std::integral_constant<int, 0>{}, sa0, sa1, sb0, sb1, t);
-            if (t + 1 >= t_end) break;
-            tile_step(std::integral_constant<int, 1>{}, sb0, sb1, sa0, sa1, t + 1);
-        }
-    } else {
-#if ATD_UNROLL2  // two tiles per iteration, the score tiles swapping roles: spares 32 register moves per tile
-        for (int t = t_begin; t < t_end; t += 2) {
-            tile_step(std::integral_constant<int, 0>{}, sa0, sa1, sb0, sb1, t);
-            if (t + 1 >= t_end) break;
-            tile_step(std::integral_constant<int, 0>{}, sb0, sb1, sa0, sa1, t + 1);
-        }
-#else
-        for (int t = t_begin; t < t_end; ++t) {
-            tile_step(std::integral_constant<int, 0>{}, sa0, sa1, sb0, sb1, t);
-            sa0 = sb0, sa1 = sb1;
-        }
-#endif
+    using Par0 = std::integral_constant<int, 0>;
+    using Par1 = std::integral_constant<int, 1>;
+    using NotLast = std::false_type;
+    using Last = std::true_type;
+    // t_begin is even (a multiple of AT_SEG_TILES): parity of t = parity inside the segment. Two tiles per iteration, the two score
+    // tiles swapping roles (no copies); the last tile of the walk runs a body without an S phase.
+    int t = t_begin;
+#if ATD_DBUF || ATD_UNROLL2
+    for (; t + 2 < t_end; t += 2) {
+        tile_step(Par0{}, NotLast{}, sa0, sa1, sb0, sb1, t);
+        tile_step(Par1{}, NotLast{}, sb0, sb1, sa0, sa1, t + 1);
     }
+    if (t + 1 < t_end) {
+        tile_step(Par0{}, NotLast{}, sa0, sa1, sb0, sb1, t);
+        tile_step(Par1{}, Last{}, sb0, sb1, sa0, sa1, t + 1);
+    } else {
+        tile_step(Par0{}, Last{}, sa0, sa1, sb0, sb1, t);
+    }
+#else
+    for (; t + 1 < t_end; ++t) {
+        tile_step(Par0{}, NotLast{}, sa0, sa1, sb0, sb1, t);
+        sa0 = sb0, sa1 = sb1;
+    }
+    tile_step(Par0{}, Last{}, sa0, sa1, sb0, sb1, t);
+#endif
 #ifdef GTSFM_TRACE
     if (lane == 0 && g_attn_trace) {
         unsigned long long* o = g_attn_trace + ((size_t)blockIdx.x * 4 + wave) * 10;
