@@ -566,6 +566,7 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(AttnParams p) {
 }
 
 static int at_segments(int max_k) { return ceil_div(ceil_div(max_k < 1 ? 1 : max_k, AT_KT), AT_SEG_TILES); }
+int attention_segments(int max_k) { return at_segments(max_k); }
 
 // The split schedule pays one extra round trip of O through the workspace; it is chosen when the unsplit launch would not fill
 // the chip's workgroup slots (256 CUs x ATD_WGS_PER_CU) twice and the keys span more than one segment. Measured (MI355X,

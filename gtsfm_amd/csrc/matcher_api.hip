@@ -207,7 +207,7 @@ extern "C" size_t gtsfm_attention_split_workspace_bytes(int nproblems, int max_q
     // enough for either schedule: the split schedule's partial states (one unnormalised O row + (m, l) per head, key segment and
     // token row) or the parking space of the fused schedule's double-buffered build (34 floats per thread of the launch; the default
     // build parks in LDS and ignores it)
-    const int nseg = (((max_k < 1 ? 1 : max_k) + 63) / 64 + 15) / 16;
+    const int nseg = attention_segments(max_k);
     const size_t split = (size_t)nseg * rows * ((size_t)heads * 64 + (size_t)heads * 2);
     const size_t park = (size_t)((heads * nproblems + 7) / 8 * 8) * ((max_q + 127) / 128) * 34 * 256;
     return (split > park ? split : park) * sizeof(float);
