@@ -61,3 +61,21 @@ def test_scene_partitions_cover_every_pair_once(world):
         assert max(len(parallel.images_touched(p)) for p in parts) <= 76
     rows_of = sorted(parallel.table_index(i, 101, world) for i in range(101))
     assert len(set(rows_of)) == 101 and rows_of[-1] < world * (-(-101 // world))
+
+
+def test_default_workload_helpers():
+    """The headline's shape follows from the keypoint cap: fewest images whose exhaustive pairs cover the pair count (SURVEY.md
+    section 8d: P exhaustive pairs <=> n images), a power-of-two pair chunk by keypoint count."""
+    import bench
+
+    for pairs in (1, 2, 3, 100, 250, 1000, 1035, 5000):
+        n = bench.fewest_images_for(pairs)
+        assert n * (n - 1) // 2 >= pairs and (n - 1) * (n - 2) // 2 < pairs
+    assert (bench.fewest_images_for(250), bench.fewest_images_for(1000), bench.fewest_images_for(5000)) == (23, 46, 101)
+    assert (bench.default_pair_chunk(5000), bench.default_pair_chunk(2048), bench.default_pair_chunk(512), bench.default_pair_chunk(20000)) == (16, 32, 32, 4)
+    args = bench.parse_args([])
+    assert (args.keypoints, args.pairs, args.images, args.pair_chunk, args.matcher, args.mode) == (5000, 250, 23, 16, "lightglue", "replica")
+    args = bench.parse_args(["--keypoints", "2048"])
+    assert (args.pairs, args.images, args.pair_chunk) == (1000, 46, 32)
+    args = bench.parse_args(["--mode", "scene"])
+    assert (args.pairs, args.images, args.matcher) == (5000, 101, "superglue")
