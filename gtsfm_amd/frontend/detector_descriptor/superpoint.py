@@ -52,11 +52,9 @@ class SuperPointDetectorDescriptor(DetectorDescriptorBase):
     def _ensure_model_loaded(self) -> None:
         if self._model is not None:
             return
-        if not self._use_cuda:
-            raise RuntimeError(
-                "gtsfm_amd's SuperPointDetectorDescriptor runs on the GPU only (use_cuda=False requested); "
-                "use the reference implementation for CPU execution."
-            )
+        from gtsfm_amd.frontend.registry import warn_if_cpu_requested
+
+        warn_if_cpu_requested(self._use_cuda, "SuperPointDetectorDescriptor")
         import torch
 
         from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine

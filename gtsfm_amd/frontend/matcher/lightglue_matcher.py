@@ -58,8 +58,9 @@ class LightGlueMatcher(MatcherBase):
 
             if self._features != "superpoint":
                 raise ValueError(f"gtsfm_amd's LightGlueMatcher supports features='superpoint' only (got {self._features!r}).")
-            if not self._use_cuda:
-                raise RuntimeError("gtsfm_amd's LightGlueMatcher runs on the GPU only (use_cuda=False requested).")
+            from gtsfm_amd.frontend.registry import warn_if_cpu_requested
+
+            warn_if_cpu_requested(self._use_cuda, "LightGlueMatcher")
             candidates = [Path(self._weights_path)] if self._weights_path is not None else _default_weight_candidates(self._features)
             path = next((c for c in candidates if c.exists()), None)
             if path is None:

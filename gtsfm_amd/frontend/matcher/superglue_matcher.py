@@ -58,8 +58,9 @@ class SuperGlueMatcher(MatcherBase):
 
             from gtsfm_amd.runtime.matcher_engine import SuperGlueEngine
 
-            if not self._use_cuda:
-                raise RuntimeError("gtsfm_amd's SuperGlueMatcher runs on the GPU only (use_cuda=False requested).")
+            from gtsfm_amd.frontend.registry import warn_if_cpu_requested
+
+            warn_if_cpu_requested(self._use_cuda, "SuperGlueMatcher")
             self._model = SuperGlueEngine(torch.load(str(self._weights_path), map_location="cpu"))
 
     def match(

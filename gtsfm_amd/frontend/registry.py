@@ -36,3 +36,19 @@ except Exception:  # noqa: BLE001
         @abc.abstractmethod
         def get_ui_metadata() -> UiMetadata:
             ...
+
+
+def warn_if_cpu_requested(use_cuda: bool, plugin: str) -> None:
+    """``use_cuda=False`` (the reference's own contract tests construct the plugins that way, and the reference then runs its torch
+    model on the CPU): this package has no CPU path. With a GPU present the plugin runs on it and says so once -- outputs are the
+    reference's within the parity tolerances on either device, so GTSfM's tests and configs work unchanged on a GPU box; without a
+    GPU the first call raises ``RuntimeError`` (``require_gpu``), never a silent fallback."""
+    if use_cuda:
+        return
+    import warnings
+
+    import torch
+
+    if torch.cuda.is_available():
+        warnings.warn(f"gtsfm_amd.{plugin}: use_cuda=False was requested, but this implementation has no CPU path; running on the GPU.",
+                      RuntimeWarning, stacklevel=3)

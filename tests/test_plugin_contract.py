@@ -42,10 +42,11 @@ def test_superpoint_plugin_is_lazy_picklable_and_registered(sp_weights):
 def test_superpoint_plugin_has_no_cpu_fallback(sp_weights):
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    det = SuperPointDetectorDescriptor(weights_path=sp_weights)
     img = Image(value_array=synthetic.synthetic_gray_image(64, 64, 0))
-    with pytest.raises(RuntimeError):
-        det.detect_and_describe(img)
+    for use_cuda in (True, False):  # use_cuda=False (the reference's contract tests) is no CPU switch either: no GPU, no result
+        det = SuperPointDetectorDescriptor(use_cuda=use_cuda, weights_path=sp_weights)
+        with pytest.raises(RuntimeError):
+            det.detect_and_describe(img)
 
 
 def test_keypoints_top_k_and_mask():

@@ -1,5 +1,6 @@
-"""-m gpu: the reference's OWN plugin contract tests, restated against the gtsfm_amd plugins with ``use_cuda=True`` (the reference
-constructs ``SuperPointDetectorDescriptor(use_cuda=False)``; this package has no CPU path -- INTEGRATION.md section 2):
+"""-m gpu: the reference's OWN plugin contract tests, restated against the gtsfm_amd plugins (the reference constructs
+``SuperPointDetectorDescriptor(use_cuda=False)``; this package has no CPU path: with a GPU present such an object runs on it and
+warns, ``test_use_cuda_false_as_the_reference_tests_construct_it`` -- INTEGRATION.md section 1):
 
 * ``tests/frontend/detector/test_detector_base.py:27-56``  (number of detections, coordinate range, scales, pickling)
 * ``tests/frontend/detector_descriptor/test_detector_descriptor_base.py:29-42``  (keypoints <-> descriptors)
@@ -115,3 +116,22 @@ def test_on_dummy_data_of_the_reference_dtypes(plugins):
     assert isinstance(m, np.ndarray) and m.dtype == np.uint32
     m = plugins["lightglue"].match(k1, k2, d1, d2, (h, w, 3), (h, w, 3))
     assert isinstance(m, np.ndarray) and m.dtype == np.int64 and (m.size == 0 or m.shape[1] == 2)
+
+
+def test_use_cuda_false_as_the_reference_tests_construct_it(plugins, lund_images, tmp_path):
+    """tests/frontend/detector_descriptor/test_superpoint.py:18 builds ``SuperPointDetectorDescriptor(use_cuda=False)``. There is no CPU
+    path here: on a GPU box the object runs on the GPU, says so (RuntimeWarning), and returns exactly what ``use_cuda=True`` returns."""
+    from gtsfm_amd.frontend.detector_descriptor.superpoint import SuperPointDetectorDescriptor
+    from gtsfm_amd.frontend.matcher.superglue_matcher import SuperGlueMatcher
+
+    ref = plugins["detector_descriptor"]
+    det = SuperPointDetectorDescriptor(max_keypoints=ref.max_keypoints, use_cuda=False, weights_path=ref._config["weights_path"])
+    with pytest.warns(RuntimeWarning, match="no CPU path"):
+        kp, desc = det.detect_and_describe(lund_images[0])
+    kp_ref, desc_ref = ref.detect_and_describe(lund_images[0])
+    assert kp == kp_ref and np.array_equal(desc, desc_ref)
+    sg = SuperGlueMatcher(use_cuda=False, weights_path=plugins["superglue"]._weights_path)
+    kp2, desc2 = ref.detect_and_describe(lund_images[1])
+    with pytest.warns(RuntimeWarning, match="no CPU path"):
+        m = sg.match(kp, kp2, desc, desc2, lund_images[0].shape, lund_images[1].shape)
+    np.testing.assert_array_equal(m, plugins["superglue"].match(kp, kp2, desc, desc2, lund_images[0].shape, lund_images[1].shape))
