@@ -44,12 +44,21 @@ constexpr float SW_FLT_MIN = 1.17549435e-38f;
 
 __device__ __forceinline__ float sw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <int NCH>
+// Score-matrix reads. NT = nontemporal: when the matrices of one launch together exceed the 256 MiB Infinity Cache, every sweep streams
+// them from HBM anyway and reads that do not allocate in the caches are 4-8 % faster (4.63 -> 4.92 TB/s, 21 pairs at 5000 columns;
+// 4.87 -> 5.18 at 2048, 32 pairs); when they fit (1-2 pairs at the cap, <= 15 at 2048) the plain reads hit the cache on the next
+// sweep and NT costs 11 %. The launcher chooses (speed only: the same values are loaded).
+template <bool NT>
+__device__ __forceinline__ f32x4 sw_zload(const float* ptr) {
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr)) : *reinterpret_cast<const f32x4*>(ptr);
+}
+
+template <int NCH, bool NT = false>
 __device__ __forceinline__ void sw_load_row(const float* __restrict__ zr, int n, int lane, f32x4 (&dst)[NCH]) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int col = 4 * (lane + 64 * c);
-        if (col < n) dst[c] = *reinterpret_cast<const f32x4*>(zr + col);  // col < n implies col + 3 < ld (ld = n rounded up to 4)
+        if (col < n) dst[c] = sw_zload<NT>(zr + col);  // col < n implies col + 3 < ld (ld = n rounded up to 4)
     }
 }
 
@@ -58,7 +67,7 @@ __device__ __forceinline__ void sw_load_row(const float* __restrict__ zr, int n,
 // ---------------------------------------------------------------------------------------------------------------
 
 // 168 registers (3 waves per SIMD) spill 33 of them at NCH = 8; 2 waves per SIMD still keep 64 KiB of rows in flight per CU
-template <int NCH>
+template <int NCH, bool NT>
 __global__ __launch_bounds__(256, NCH >= 8 ? 2 : 3) void sinkhorn_rows_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                                const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
                                                                float* __restrict__ rowvec, const float* __restrict__ colvec,
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 2 : 3) void sinkhorn_rows_kernel(co
 
     auto load = [&](int i, f32x4(&dst)[NCH]) {
         if (i < m) {
-            sw_load_row<NCH>(Z + (size_t)i * ld, n, lane, dst);
+            sw_load_row<NCH, NT>(Z + (size_t)i * ld, n, lane, dst);
         } else {  // dustbin row: Z[m][j] = bin_score
 #pragma unroll
             for (int c = 0; c < NCH; ++c) dst[c] = f32x4{alpha, alpha, alpha, alpha};
@@ -476,16 +485,16 @@ __device__ __forceinline__ bool sw_wide_tier(int n) {
     return NW == 4 ? (n > SW_MAX_COLS && n <= SW_WIDE4_COLS) : (n > SW_WIDE4_COLS && n <= SW_WIDE8_COLS);
 }
 
-template <int NW, int NCH>
+template <int NW, int NCH, bool NT = false>
 __device__ __forceinline__ void sw_load_slice(const float* __restrict__ zr, int n, int wave, int lane, f32x4 (&dst)[NCH]) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int col = 256 * (wave + NW * c) + 4 * lane;
-        if (col < n) dst[c] = *reinterpret_cast<const f32x4*>(zr + col);
+        if (col < n) dst[c] = sw_zload<NT>(zr + col);
     }
 }
 
-template <int NW, int NCH>
+template <int NW, int NCH, bool NT>
 __global__ __launch_bounds__(64 * NW) void sinkhorn_rows_wide_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                                      const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
                                                                      float* __restrict__ rowvec, const float* __restrict__ colvec,
@@ -519,7 +528,7 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_rows_wide_kernel(const float
 
     auto load = [&](int i, f32x4(&dst)[NCH]) {
         if (i < m) {
-            sw_load_slice<NW, NCH>(Z + (size_t)i * ld, n, wave, lane, dst);
+            sw_load_slice<NW, NCH, NT>(Z + (size_t)i * ld, n, wave, lane, dst);
         } else {  // dustbin row: Z[m][j] = bin_score
 #pragma unroll
             for (int c = 0; c < NCH; ++c) dst[c] = f32x4{alpha, alpha, alpha, alpha};
@@ -860,16 +869,21 @@ int launch_sinkhorn(const SweepArgs& a, float bin_score, int iters, hipStream_t 
         group = group < 1 ? 1 : (group > a.npairs ? a.npairs : group);
     }
     const int nch = chunks_for(a.max_n);
+    // nontemporal score-matrix reads once the launch's matrices cannot stay in the Infinity Cache between sweeps (see sw_zload)
+    static const char* nt_env = getenv("GTSFM_SWEEP_NT_MB");
+    const double nt_mb = nt_env ? atof(nt_env) : 256.0;
     for (int pair0 = 0; pair0 < a.npairs; pair0 += group) {
         const int g = (a.npairs - pair0 < group) ? a.npairs - pair0 : group;
+        const bool nt = g * z_mb > nt_mb;
         const dim3 grid_rows(ceil_div(a.max_m + 1, SW_ROWS), g), grid_cols(ceil_div(a.max_n + 1, 256), g);
         for (int it = 0; it < iters; ++it) {
-#define SW_LAUNCH_SINKHORN(N)                                                                                                          \
-    hipLaunchKernelGGL((sinkhorn_rows_kernel<N>), grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, \
-                       a.partials, bin_score, pair0)
-#define SW_LAUNCH_SINKHORN_WIDE(NW, N)                                                                                                  \
-    hipLaunchKernelGGL((sinkhorn_rows_wide_kernel<NW, N>), grid_rows, dim3(64 * NW), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, \
-                       a.colvec, a.partials, bin_score, pair0)
+#define SW_SINKHORN_ARGS stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, a.partials, bin_score, pair0
+#define SW_LAUNCH_SINKHORN(N)                                                                           \
+    if (nt) hipLaunchKernelGGL((sinkhorn_rows_kernel<N, true>), grid_rows, dim3(256), 0, SW_SINKHORN_ARGS); \
+    else hipLaunchKernelGGL((sinkhorn_rows_kernel<N, false>), grid_rows, dim3(256), 0, SW_SINKHORN_ARGS)
+#define SW_LAUNCH_SINKHORN_WIDE(NW, N)                                                                                 \
+    if (nt) hipLaunchKernelGGL((sinkhorn_rows_wide_kernel<NW, N, true>), grid_rows, dim3(64 * NW), 0, SW_SINKHORN_ARGS); \
+    else hipLaunchKernelGGL((sinkhorn_rows_wide_kernel<NW, N, false>), grid_rows, dim3(64 * NW), 0, SW_SINKHORN_ARGS)
             // every tier the batch can hold; the blocks of pairs of another tier return at once
             if (a.max_n > SW_WIDE4_COLS) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_SINKHORN_WIDE)
             if (a.max_n > SW_MAX_COLS) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_SINKHORN_WIDE)
