@@ -870,7 +870,7 @@ int launch_sinkhorn(const SweepArgs& a, float bin_score, int iters, hipStream_t 
     }
     const int nch = chunks_for(a.max_n);
     // nontemporal score-matrix reads once the launch's matrices cannot stay in the Infinity Cache between sweeps (see sw_zload)
-    static const char* nt_env = getenv("GTSFM_SWEEP_NT_MB");
+    const char* nt_env = getenv("GTSFM_SWEEP_NT_MB");  // read per call (tests switch it)
     const double nt_mb = nt_env ? atof(nt_env) : 256.0;
     for (int pair0 = 0; pair0 < a.npairs; pair0 += group) {
         const int g = (a.npairs - pair0 < group) ? a.npairs - pair0 : group;

@@ -293,6 +293,40 @@ def test_sinkhorn_batch_composition_does_not_change_a_pair(lib, gpu_device):
         np.testing.assert_array_equal(v_all[q, : nn + 1], v1[0, : nn + 1])
 
 
+def test_sinkhorn_nontemporal_reads_are_bit_identical(lib, gpu_device, monkeypatch):
+    """Launches whose score matrices exceed the Infinity Cache read them nontemporally (sw_zload<true>); a speed choice per launch, so
+    the kernels are forced on for small batches of every tier (GTSFM_SWEEP_NT_MB=0) and compared with the plain reads bit for bit."""
+    from gtsfm_amd.runtime import lib as L
+
+    rng = np.random.default_rng(10)
+    shapes = [(90, 200), (33, 700), (64, 2048), (70, 2600), (50, 5000), (40, 6000)]
+    m = np.array([s[0] for s in shapes], dtype=np.int32)
+    n = np.array([s[1] for s in shapes], dtype=np.int32)
+    flat = []
+    for mm, nn in shapes:
+        z = np.zeros((mm + 1, (nn + 1 + 3) // 4 * 4), dtype=np.float32)
+        z[:mm, :nn] = (rng.standard_normal((mm, nn)) * 6.0).astype(np.float32)
+        flat.append(z.reshape(-1))
+    z_host = np.concatenate(flat)
+
+    def run():
+        z_dev = T(z_host).to(gpu_device)
+        ws = torch.empty(int(lib.gtsfm_sinkhorn_workspace_bytes(len(shapes), m.ctypes.data, n.ctypes.data)), dtype=torch.uint8, device=gpu_device)
+        u = torch.zeros((len(shapes), int(m.max()) + 1), device=gpu_device)
+        v = torch.zeros((len(shapes), int(n.max()) + 1), device=gpu_device)
+        L.check(lib.gtsfm_sinkhorn_f32(z_dev.data_ptr(), len(shapes), m.ctypes.data, n.ctypes.data, 1.0, 9, ws.data_ptr(), ws.numel(),
+                                       u.data_ptr(), v.data_ptr(), _stream()), "sinkhorn")
+        return u.cpu().numpy(), v.cpu().numpy()
+
+    monkeypatch.setenv("GTSFM_SWEEP_NT_MB", "1e9")
+    u_plain, v_plain = run()
+    monkeypatch.setenv("GTSFM_SWEEP_NT_MB", "0")
+    u_nt, v_nt = run()
+    assert np.abs(u_plain).max() > 0
+    np.testing.assert_array_equal(u_nt, u_plain)
+    np.testing.assert_array_equal(v_nt, v_plain)
+
+
 def test_superglue_plugin_contract(gpu_device, sg_sd, tmp_path):
     """SuperGlueMatcher.match vs the restated reference wrapper (gtsfm/frontend/matcher/superglue_matcher.py:75-113)
     and the reference's contract tests (tests/frontend/matcher/test_matcher_base.py:51-107,
