@@ -32,6 +32,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -971,6 +972,22 @@ def plugin_api_rate(args, pipe, views_np, device, h, w):
             got.append(mt.match(feats[i][0], feats[j][0], feats[i][1], feats[j][1], shape, shape))
             each.append(time.perf_counter() - t0)
         t_match = float(sum(each))
+        # several worker threads on ONE matcher object (GTSfM's --threads_per_worker, gtsfm/runner.py:155,436): every concurrent call runs
+        # on a lane of its own (matcher_engine._MatcherBase._lane) and fills the part of the chip one pair's launches leave idle
+        threaded = {}
+        for nthreads in (2, 3):
+            def work(tid, nthreads=nthreads):
+                for q in range(tid, 2 * len(pairs), nthreads):
+                    i, j = pairs[q % len(pairs)]
+                    mt.match(feats[i][0], feats[j][0], feats[i][1], feats[j][1], shape, shape)
+            for rep in range(2):  # the first round creates the lanes (workspace, staging buffers)
+                ths = [threading.Thread(target=work, args=(tid,)) for tid in range(nthreads)]
+                t0 = time.perf_counter()
+                for th in ths:
+                    th.start()
+                for th in ths:
+                    th.join()
+                threaded[str(nthreads)] = round(2 * len(pairs) / (time.perf_counter() - t0), 1)
     # the same pair through the batched, device-resident pipeline (device top-k keeps detection order, the plugin's Keypoints.get_top_k does
     # not, so the index pairs are compared as coordinate pairs)
     dev_feats = pipe.detect(torch.from_numpy(views_np[:n_img]).to(device))
@@ -986,6 +1003,7 @@ def plugin_api_rate(args, pipe, views_np, device, h, w):
         "detect_ms_per_image": round(per_img * 1e3, 2), "match_ms_per_pair": round(per_pair * 1e3, 2),
         "match_ms_each_call": [round(t * 1e3, 2) for t in each],
         "images_per_s": round(1.0 / per_img, 1), "pairs_per_s_match_only": round(1.0 / per_pair, 1),
+        "pairs_per_s_match_only_by_worker_threads": {"1": round(1.0 / per_pair, 1), **threaded},
         "value": round(1.0 / (per_pair + per_img * args.images / max(1, args.pairs)), 1), "unit": "image-pairs/s",
         "value_note": f"exhaustive scene of the headline's shape ({args.images} images, {args.pairs} pairs): 1 / (match + detect x images / pairs), PCIe and per-call synchronisation included",
         "keypoints_per_image": [int(min(len(f[0]) for f in feats)), int(max(len(f[0]) for f in feats))], "matches_first_pair": int(len(got[0])),

@@ -52,14 +52,17 @@ class SuperPointDetectorDescriptor(DetectorDescriptorBase):
     def _ensure_model_loaded(self) -> None:
         if self._model is not None:
             return
-        from gtsfm_amd.frontend.registry import warn_if_cpu_requested
+        from gtsfm_amd.frontend.registry import MODEL_LOAD_LOCK, warn_if_cpu_requested
 
-        warn_if_cpu_requested(self._use_cuda, "SuperPointDetectorDescriptor")
-        import torch
+        with MODEL_LOAD_LOCK:
+            if self._model is not None:
+                return
+            warn_if_cpu_requested(self._use_cuda, "SuperPointDetectorDescriptor")
+            import torch
 
-        from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+            from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
 
-        self._model = SuperPointEngine(torch.load(str(self._config["weights_path"]), map_location="cpu"))
+            self._model = SuperPointEngine(torch.load(str(self._config["weights_path"]), map_location="cpu"))
 
     def detect_and_describe(self, image: Image) -> Tuple[Keypoints, np.ndarray]:
         """Keypoints (with responses, no scales) and their (K, 256) float32 unit descriptors for one image."""

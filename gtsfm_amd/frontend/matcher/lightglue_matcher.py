@@ -51,15 +51,19 @@ class LightGlueMatcher(MatcherBase):
         return state
 
     def _ensure_model_loaded(self):
-        if self._model is None:
+        if self._model is not None:
+            return
+        from gtsfm_amd.frontend.registry import MODEL_LOAD_LOCK, warn_if_cpu_requested
+
+        with MODEL_LOAD_LOCK:
+            if self._model is not None:
+                return
             import torch
 
             from gtsfm_amd.runtime.matcher_engine import LightGlueEngine
 
             if self._features != "superpoint":
                 raise ValueError(f"gtsfm_amd's LightGlueMatcher supports features='superpoint' only (got {self._features!r}).")
-            from gtsfm_amd.frontend.registry import warn_if_cpu_requested
-
             warn_if_cpu_requested(self._use_cuda, "LightGlueMatcher")
             candidates = [Path(self._weights_path)] if self._weights_path is not None else _default_weight_candidates(self._features)
             path = next((c for c in candidates if c.exists()), None)

@@ -53,15 +53,18 @@ class SuperGlueMatcher(MatcherBase):
         return state
 
     def _ensure_model_loaded(self) -> None:
-        if self._model is None:
-            import torch
+        if self._model is not None:
+            return
+        from gtsfm_amd.frontend.registry import MODEL_LOAD_LOCK, warn_if_cpu_requested
 
-            from gtsfm_amd.runtime.matcher_engine import SuperGlueEngine
+        with MODEL_LOAD_LOCK:
+            if self._model is None:
+                import torch
 
-            from gtsfm_amd.frontend.registry import warn_if_cpu_requested
+                from gtsfm_amd.runtime.matcher_engine import SuperGlueEngine
 
-            warn_if_cpu_requested(self._use_cuda, "SuperGlueMatcher")
-            self._model = SuperGlueEngine(torch.load(str(self._weights_path), map_location="cpu"))
+                warn_if_cpu_requested(self._use_cuda, "SuperGlueMatcher")
+                self._model = SuperGlueEngine(torch.load(str(self._weights_path), map_location="cpu"))
 
     def match(
         self,

@@ -5,6 +5,7 @@ subclass is registered by ``__name__`` at class-definition time and exposes a st
 from __future__ import annotations
 
 import abc
+import threading
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -36,6 +37,11 @@ except Exception:  # noqa: BLE001
         @abc.abstractmethod
         def get_ui_metadata() -> UiMetadata:
             ...
+
+
+# The plugins build their device engine on first use, in the worker process. A worker with several threads (--threads_per_worker)
+# may make the first calls at the same time: one of them builds, the others wait (module-level: plugin objects must stay picklable).
+MODEL_LOAD_LOCK = threading.Lock()
 
 
 def warn_if_cpu_requested(use_cuda: bool, plugin: str) -> None:

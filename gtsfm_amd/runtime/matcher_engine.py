@@ -26,7 +26,10 @@ LightGlue (upstream ``cvg/LightGlue`` module names)
 from __future__ import annotations
 
 import contextlib
+import copy
 import ctypes as C
+import os
+import queue
 import threading
 from collections import OrderedDict
 from typing import Dict, List, Mapping, Optional, Sequence, Tuple
@@ -125,9 +128,48 @@ class _MatcherBase:
         self._pinning = False
         self.desc_cache_capacity = 64
         self._staging: Optional[dict] = None
-        # match_pair() re-uses the engine's staging buffers and workspace: calls from several threads of one worker process
-        # (Dask workers can be configured with more than one) take turns
-        self._pair_lock = threading.Lock()
+        # match_pair() re-uses an engine's staging buffers and workspace, so one thread at a time owns them. Calls from several
+        # threads of one worker process (GTSfM's ``--threads_per_worker``, gtsfm/runner.py:155,436) do not queue behind each other,
+        # though: up to ``max_lanes`` of them run side by side, each on a LANE = an engine of its own (own workspace, staging
+        # buffers, descriptor cache and HIP stream) that shares this engine's weights. One pair leaves a fifth of the chip idle
+        # between and inside its ~230 launches (320 attention workgroups on 512 slots at N = 5000); a second and third launch sequence
+        # fill it: 86 -> 102 -> 107 pairs/s at the cap, 346 -> 429 -> 450 at N = 2048 (tools/bench_plugin_threads.py). Lanes are created
+        # when a call finds every existing one busy; a single-threaded caller only ever has the first.
+        self.max_lanes = max(1, int(os.environ.get("GTSFM_PLUGIN_LANES", "3")))
+        self._lanes: list = [self]
+        self._free_lanes: "queue.LifoQueue" = queue.LifoQueue()
+        self._free_lanes.put(self)
+        self._lanes_lock = threading.Lock()
+        self._lane_stream: Optional[torch.cuda.Stream] = None
+
+    def _sibling(self) -> "_MatcherBase":
+        """An engine sharing this one's weights (read-only on the device) and nothing a call writes."""
+        other = copy.copy(self)
+        other._workspace, other._staging, other._lane_stream = None, None, None
+        other._desc_cache, other._desc_pinned, other._pinning = OrderedDict(), set(), False
+        other._lanes, other._free_lanes = [other], None  # lanes are handed out by the engine they were made from
+        return other
+
+    @contextlib.contextmanager
+    def _lane(self):
+        """An engine no other thread is using -- this one or a sibling -- with its own stream current."""
+        try:
+            eng = self._free_lanes.get_nowait()
+        except queue.Empty:
+            eng = None
+            with self._lanes_lock:
+                if len(self._lanes) < self.max_lanes:
+                    eng = self._sibling()
+                    self._lanes.append(eng)
+            if eng is None:
+                eng = self._free_lanes.get()
+        try:
+            if eng._lane_stream is None:
+                eng._lane_stream = torch.cuda.Stream(self.device)
+            with torch.cuda.stream(eng._lane_stream):
+                yield eng
+        finally:
+            self._free_lanes.put(eng)
 
     def _stage_pair(self, arrays0: Sequence[np.ndarray], arrays1: Sequence[np.ndarray]) -> List[torch.Tensor]:
         """Host arrays of the two images of ONE pair -> device tensors [n0 + n1, ...], one per array: converted to float32 straight
@@ -302,18 +344,19 @@ class SuperGlueEngine(_MatcherBase):
                 "matches0": np.full(n0, -1, dtype=np.int32), "matches1": np.full(n1, -1, dtype=np.int32),
                 "matching_scores0": np.zeros(n0, dtype=np.float32), "matching_scores1": np.zeros(n1, dtype=np.float32),
             }
-        with self._pair_lock:
-            kp, sc, de = self._stage_pair((k0, s0, d0), (k1, s1, d1))
-            out = self.match_batch(
+        with self._lane() as eng:
+            kp, sc, de = eng._stage_pair((k0, s0, d0), (k1, s1, d1))
+            out = eng.match_batch(
                 kp, sc.reshape(-1), de, [n0], [n1], [[shape0[0], shape0[1], shape1[0], shape1[1]]],
                 sinkhorn_iterations, match_threshold, return_ot,
             )
             m = out["matches"].cpu().numpy().astype(np.int64)
             ms = out["mscores"].cpu().numpy()
+            ot = out["ot"].cpu().numpy() if return_ot else None
         res = {"matches0": m[:n0], "matches1": m[n0:], "matching_scores0": ms[:n0], "matching_scores1": ms[n0:]}
         if return_ot:
             ld = (n1 + 1 + 3) // 4 * 4
-            res["ot"] = out["ot"].cpu().numpy().reshape(n0 + 1, ld)[:, : n1 + 1]
+            res["ot"] = ot.reshape(n0 + 1, ld)[:, : n1 + 1]
         return res
 
 
@@ -489,9 +532,9 @@ class LightGlueEngine(_MatcherBase):
                 "matches0": np.full(n0, -1, dtype=np.int64), "matches1": np.full(n1, -1, dtype=np.int64),
                 "matching_scores0": np.zeros(n0, dtype=np.float32), "matching_scores1": np.zeros(n1, dtype=np.float32), "stop": 1,
             }
-        with self._pair_lock:
-            kp, de = self._stage_pair((k0, d0), (k1, d1))
-            out = self.match_batch(kp, de, [n0], [n1], [[shape0[0], shape0[1], shape1[0], shape1[1]]], **kwargs)
+        with self._lane() as eng:
+            kp, de = eng._stage_pair((k0, d0), (k1, d1))
+            out = eng.match_batch(kp, de, [n0], [n1], [[shape0[0], shape0[1], shape1[0], shape1[1]]], **kwargs)
             m = out["matches"].cpu().numpy().astype(np.int64)
             ms = out["mscores"].cpu().numpy()
             out = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in out.items() if k in ("stop", "kept", "sim")}

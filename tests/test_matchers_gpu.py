@@ -561,6 +561,53 @@ def test_lightglue_plugin_contract(gpu_device, tmp_path):
         matcher.match(Keypoints(k0), kp1, d0, d1, (480, 640, 3), (360, 500, 3))
 
 
+@pytest.mark.parametrize("which", ["superglue", "lightglue"])
+def test_plugin_match_from_several_threads_equals_one_at_a_time(gpu_device, sg_sd, tmp_path, which):
+    """GTSfM's ``--threads_per_worker`` (gtsfm/runner.py:155,436) lets several Dask threads call ``match`` on ONE scattered matcher
+    object at once. The engine hands every concurrent call a lane of its own (workspace, staging buffers, stream; shared weights):
+    ragged pairs matched from three threads, repeatedly, give exactly the arrays the same calls give one after the other, and no more
+    than ``max_lanes`` lanes ever exist."""
+    import threading
+
+    from gtsfm_amd.common.keypoints import Keypoints
+    from gtsfm_amd.frontend.matcher.lightglue_matcher import LightGlueMatcher
+    from gtsfm_amd.frontend.matcher.superglue_matcher import SuperGlueMatcher
+
+    if which == "superglue":
+        torch.save(sg_sd, str(tmp_path / "sg.pth"))
+        matcher = SuperGlueMatcher(weights_path=tmp_path / "sg.pth")
+    else:
+        torch.save(synthetic.synthetic_lightglue_state_dict(), str(tmp_path / "lg.pth"))
+        matcher = LightGlueMatcher(features="superpoint", weights_path=tmp_path / "lg.pth")
+    jobs = []
+    for seed, (n0, n1) in enumerate([(220, 190), (700, 40), (1, 300), (513, 512), (90, 2100), (300, 300), (64, 65), (1200, 900), (33, 7)]):
+        k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(n0, n1, (480, 640), (360, 500), seed=70 + seed)
+        jobs.append((Keypoints(k0, responses=s0), Keypoints(k1, responses=s1), d0, d1, (480, 640, 3), (360, 500, 3)))
+    serial = [matcher.match(*j) for j in jobs]
+    assert sum(len(m) for m in serial) > 100
+    results, errors = {}, []
+
+    def worker(tid):
+        try:
+            for rep in range(3):
+                for q in range(tid, len(jobs), 3):
+                    results[(rep, q)] = matcher.match(*jobs[q])
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 3 * len(jobs)
+    for (rep, q), m in results.items():
+        np.testing.assert_array_equal(m, serial[q])
+    engine = matcher._model
+    assert 1 <= len(engine._lanes) <= engine.max_lanes
+
+
 def test_lightglue_full_size_properties(gpu_device):
     """BASELINE config-3 scale (N = 2048 per image): determinism, mutual one-to-one matches, planted
     correspondences recovered, early stopping never changes which layer's assignment head is reported."""
