@@ -327,6 +327,36 @@ def test_sinkhorn_nontemporal_reads_are_bit_identical(lib, gpu_device, monkeypat
     np.testing.assert_array_equal(v_nt, v_plain)
 
 
+def test_superglue_end_to_end_with_nontemporal_sinkhorn_reads(sg_engine, monkeypatch):
+    """The score matrices the Sinkhorn kernels read nontemporally were written by the score GEMM one launch earlier (the benchmark's
+    32-pair chunks are in that regime): forced on for a small ragged batch, matches, scores and the transport matrix are the plain
+    reads' bit for bit."""
+    specs = [(300, 257, (480, 640), (480, 640), 31), (96, 2300, (240, 320), (600, 400), 32)]
+    feats = [synthetic.synthetic_pair_features(a, b, s0, s1, seed=sd) for a, b, s0, s1, sd in specs]
+    dev = sg_engine.device
+    kp = T(np.concatenate([np.concatenate([f[0], f[3]]) for f in feats])).to(dev)
+    sc = T(np.concatenate([np.concatenate([f[1], f[4]]) for f in feats])).to(dev)
+    de = T(np.concatenate([np.concatenate([f[2], f[5]]) for f in feats])).to(dev)
+    n0, n1 = [s[0] for s in specs], [s[1] for s in specs]
+    hw = [[s[2][0], s[2][1], s[3][0], s[3][1]] for s in specs]
+
+    def run(mb):
+        monkeypatch.setenv("GTSFM_SWEEP_NT_MB", mb)
+        out = sg_engine.match_batch(kp, sc, de, n0, n1, hw, sinkhorn_iterations=20, return_ot=True)
+        ot, off, mats = out["ot"].cpu().numpy(), 0, []
+        for a, b in zip(n0, n1):  # the row stride is padded to 4 floats; the padding is never written
+            ld = (b + 1 + 3) // 4 * 4
+            mats.append(ot[off : off + (a + 1) * ld].reshape(a + 1, ld)[:, : b + 1].copy())
+            off += (a + 1) * ld
+        return [out["matches"].cpu().numpy(), out["mscores"].cpu().numpy(), *mats]
+
+    plain = run("1e9")
+    assert (plain[0] >= 0).sum() > 50
+    for _ in range(3):
+        for got, want in zip(run("0"), plain):
+            np.testing.assert_array_equal(got, want)
+
+
 def test_superglue_plugin_contract(gpu_device, sg_sd, tmp_path):
     """SuperGlueMatcher.match vs the restated reference wrapper (gtsfm/frontend/matcher/superglue_matcher.py:75-113)
     and the reference's contract tests (tests/frontend/matcher/test_matcher_base.py:51-107,
