@@ -27,6 +27,7 @@
 // uniformly strided GEMM / attention tiles.
 #define CV_ROW_PITCH (CV_HW * MT_LDS_ROW + 56)
 #define CV_HALO_FLOATS ((CV_TH + 2) * CV_ROW_PITCH)
+#define CV_PATCH_W (CV_TW + 4)  // gray-image patch under the halo tile of the fused first layer: (CV_TH + 4) x (CV_TW + 4) floats
 
 // FUSE_C1A: the input activation is not read from HBM but recomputed on the fly from the gray image: the halo tile of
 // conv1b's input IS relu(conv1a(image)) (superpoint.py:148-149), 9 fma per value in conv1a_kernel's tap order (bit-identical
@@ -79,25 +80,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
         // stage the halo tile of this 64-channel chunk: 180 pixels x 16 float4
         if (FUSE_C1A) {
             float* w1 = lds + CV_HALO_FLOATS;  // [9 taps][64] + [64] bias
+            // the gray image under the halo tile and one pixel around it, as conv1a sees it: u8 / 255 (or the float image), zero
+            // outside the image (conv1a's padding). One load, one conversion and one division per PIXEL here; round 1-2 did all
+            // three per (halo pixel, tap, 4-channel group) -- 9 x 16 times as often, with global-load latency in the inner loop --
+            // and the fused layer, 43 % of SuperPoint's FLOPs, ran at 0.63 of the MFMA peak where the plain 64 -> 64 layers reach 0.8
+            float* patch = w1 + 640;           // [CV_TH + 4][CV_PATCH_W]
             for (int idx = tid; idx < 10 * 64 / 4; idx += 256)
                 *reinterpret_cast<f32x4*>(&w1[idx * 4]) = *reinterpret_cast<const f32x4*>((idx < 144 ? p.w1a : p.b1a - 576) + idx * 4);
-            __syncthreads();
             const size_t img_b = (size_t)b * p.H * p.W;
+            if (tid < (CV_TH + 4) * CV_PATCH_W) {
+                const int iy = y0 - 2 + tid / CV_PATCH_W, ix = x0 - 2 + tid % CV_PATCH_W;
+                float a = 0.f;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                    a = p.img_is_u8 ? (float)reinterpret_cast<const uint8_t*>(p.img)[img_b + (size_t)iy * p.W + ix] / 255.0f
+                                    : reinterpret_cast<const float*>(p.img)[img_b + (size_t)iy * p.W + ix];
+                patch[tid] = a;
+            }
+            __syncthreads();
             for (int idx = tid; idx < CV_HALO_PIX * 16; idx += 256) {
                 const int pix = idx >> 4, q = idx & 15;
-                const int gy = y0 - 1 + pix / CV_HW, gx = x0 - 1 + pix % CV_HW;
+                const int hy = pix / CV_HW, hx = pix % CV_HW;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
                     v = *reinterpret_cast<const f32x4*>(&w1[576 + q * 4]);
+                    const float* pa = patch + hy * CV_PATCH_W + hx;  // image pixel (gy - 1, gx - 1)
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
-                            const int iy = gy + ky - 1, ix = gx + kx - 1;
-                            float a = 0.f;
-                            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                                a = p.img_is_u8 ? (float)reinterpret_cast<const uint8_t*>(p.img)[img_b + (size_t)iy * p.W + ix] / 255.0f
-                                                : reinterpret_cast<const float*>(p.img)[img_b + (size_t)iy * p.W + ix];
+                            const float a = pa[ky * CV_PATCH_W + kx];
                             const f32x4 wt = *reinterpret_cast<const f32x4*>(&w1[(ky * 3 + kx) * 64 + q * 4]);
                             v.x = fmaf(a, wt.x, v.x);
                             v.y = fmaf(a, wt.y, v.y);
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
                     }
                     v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
                 }
-                *reinterpret_cast<f32x4*>(&lds[(pix / CV_HW) * CV_ROW_PITCH + (pix % CV_HW) * MT_LDS_ROW + q * 4]) = v;
+                *reinterpret_cast<f32x4*>(&lds[hy * CV_ROW_PITCH + hx * MT_LDS_ROW + q * 4]) = v;
             }
         } else {
             for (int idx = tid; idx < CV_HALO_PIX * 16; idx += 256) {
@@ -198,7 +210,7 @@ int launch_conv3x3(const ConvParams& pin, hipStream_t stream) {
     size_t lds_bytes = (size_t)CV_HALO_FLOATS * sizeof(float);
     if (p.img) {
         GTSFM_CHECK_ARG(p.Cin == 64 && p.w1a && p.b1a, "conv3x3: the fused first layer needs Cin == 64 and conv1a weights");
-        lds_bytes += 640 * sizeof(float);
+        lds_bytes += (640 + (CV_TH + 4) * CV_PATCH_W) * sizeof(float);
         hipLaunchKernelGGL(conv3x3_mfma_kernel<true>, grid, dim3(256), lds_bytes, stream, p);
     } else {
         hipLaunchKernelGGL(conv3x3_mfma_kernel<false>, grid, dim3(256), lds_bytes, stream, p);
