@@ -56,6 +56,21 @@ extern "C" int gtsfm_conv3x3_f32(const float* in_dev, int in_stride, int in_coff
     return launch_conv3x3(p, (hipStream_t)stream);
 }
 
+extern "C" int gtsfm_conv1_fused_f32(const void* image_dev, int image_is_u8, const float* w1a_dev, const float* b1a_dev,
+                                     const float* packed_w1b_dev, const float* bias1b_dev, int batch, int h, int w, int pool, float* out_dev,
+                                     void* stream) {
+    GTSFM_CHECK_ARG(image_dev && w1a_dev && b1a_dev && packed_w1b_dev && bias1b_dev && out_dev, "conv1_fused: null pointer");
+    GTSFM_CHECK_ARG(batch >= 0 && h >= 0 && w >= 0, "conv1_fused: bad shape");
+    if (batch == 0 || h == 0 || w == 0) return GTSFM_OK;
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = nullptr, p.in_stride = 64, p.out = out_dev, p.out_stride = 64;
+    p.wpack = packed_w1b_dev, p.bias = bias1b_dev;
+    p.B = batch, p.H = h, p.W = w, p.Cin = 64, p.Cout = 64, p.relu = 1, p.pool = pool;
+    p.img = image_dev, p.img_is_u8 = image_is_u8, p.w1a = w1a_dev, p.b1a = b1a_dev;
+    return launch_conv3x3(p, (hipStream_t)stream);
+}
+
 extern "C" int gtsfm_linear_f32(const float* a_dev, int lda, int m, const int32_t* m_dev, int k, const float* packed_w_dev,
                                 const float* bias_dev, int n, float* c_dev, int ldc, int c_coff, const float* res_dev, int ldres,
                                 float alpha, int relu, void* stream) {

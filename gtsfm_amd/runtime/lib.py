@@ -39,6 +39,10 @@ SIGNATURES = {
         [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     ),
+    "gtsfm_conv1_fused_f32": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    ),
     "gtsfm_linear_f32": (
         C.c_int,
         [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,

@@ -61,6 +61,14 @@ int gtsfm_conv3x3_f32(const float* in_dev, int in_stride, int in_coff, float* ou
                       const float* packed_w_dev, const float* bias_dev, int batch, int h, int w, int cin, int cout,
                       int relu, int pool, void* stream);
 
+/* SuperPoint's first two layers as gtsfm_sp_forward runs them: y = [maxpool2x2] relu(conv1b(relu(conv1a(image)))), conv1a
+ * recomputed inside conv1b's halo staging (its 64-channel output never reaches HBM).            replaces SP:148-150
+ * image: [batch][h][w] uint8 (read as x / 255) or float32; w1a: [9 taps][64] (tap = 3 ky + kx), b1a: [64];
+ * packed_w1b: gtsfm_pack_conv3x3(conv1b.weight, 64, 64); bias1b: [64]; out: [batch][ho][wo][64] */
+int gtsfm_conv1_fused_f32(const void* image_dev, int image_is_u8, const float* w1a_dev, const float* b1a_dev,
+                          const float* packed_w1b_dev, const float* bias1b_dev, int batch, int h, int w, int pool,
+                          float* out_dev, void* stream);
+
 /* C[:, c_coff:c_coff+n] = (res +) relu?(alpha * (A[:, :k] W^T + bias))              replaces SP:162,191, SG:49-60,
  * A: [m][lda]; C: [m][ldc]; res (optional): [m][ldres]; m_dev (optional): row count in device memory (<= m).
  * nn.Linear / Conv1d(kernel_size=1) / Conv2d(kernel_size=1).                                     98-119,254 */

@@ -101,6 +101,31 @@ def test_conv3x3_matches_aten(lib, gpu_device, sd, name, batch, h, w, pool):
     assert float((got - ref).abs().max()) < 5e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("batch,h,w,pool,u8", [(2, 37, 53, 1, True), (1, 64, 48, 0, False), (1, 9, 200, 1, True), (3, 1, 1, 0, True)])
+def test_fused_first_layer_matches_aten(lib, gpu_device, sd, batch, h, w, pool, u8):
+    """relu(conv1a) recomputed inside conv1b's halo staging (gtsfm_conv1_fused_f32, the form gtsfm_sp_forward runs) vs ATen:
+    conv1a's values are the 9-fma sums of the stand-alone first layer (u8 / 255 read from the gray patch staged once per tile),
+    so the result matches F.conv2d of F.conv2d within the conv tolerance, at image borders and for ragged tiles."""
+    gen = torch.Generator().manual_seed(h * 1000 + w)
+    img = torch.randint(0, 256, (batch, h, w), generator=gen, dtype=torch.uint8) if u8 else torch.rand((batch, h, w), generator=gen)
+    x = (img.float() / 255.0 if u8 else img)[:, None]
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(x, sd["conv1a.weight"], sd["conv1a.bias"], padding=1)), sd["conv1b.weight"], sd["conv1b.bias"], padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    out = torch.full((batch, ho, wo, 64), float("nan"), device=gpu_device)
+    w1a = sd["conv1a.weight"].reshape(64, 9).t().contiguous().to(gpu_device)  # [tap][channel]
+    b1a = sd["conv1a.bias"].contiguous().to(gpu_device)
+    wp, bp = _pack_conv(lib, sd["conv1b.weight"], gpu_device), _pad64(sd["conv1b.bias"], gpu_device)
+    imd = img.contiguous().to(gpu_device)
+    _check(lib, lib.gtsfm_conv1_fused_f32(imd.data_ptr(), int(u8), w1a.data_ptr(), b1a.data_ptr(), wp.data_ptr(), bp.data_ptr(), batch, h, w, pool,
+                                          out.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert not torch.isnan(got).any()
+    assert float((got - ref).abs().max()) < 5e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_conv3x3_strided_channel_views(lib, gpu_device, sd):
     """Reads a channel window of a wider NHWC buffer and writes into a channel window of another."""
     wt, bs = sd["conv2a.weight"], sd["conv2a.bias"]
