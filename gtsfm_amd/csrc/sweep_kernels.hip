@@ -372,9 +372,13 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(con
             }
         }
     }
+    // LightGlue's row term logsigmoid(z0_i) of the block's 32 rows, one per lane, computed ahead of the sweep (log1pf / expf stay out
+    // of the row loop)
+    float ci_lane = 0.f;
+    if (!SG && r0 + (lane & 31) < m) ci_lane = logsigmoid(zlogit[s0.row_off + r0 + (lane & 31)]);
     auto process = [&](int i, const f32x4(&zz)[NCH]) {
         const float a_i = rowvec[vec0 + i];
-        const float c_i = SG ? 0.f : logsigmoid(zlogit[s0.row_off + i]);
+        const float c_i = SG ? 0.f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ci_lane), __builtin_amdgcn_readfirstlane(i - r0)));
         float best = NEG;
         int bidx = SW_NO_INDEX;
 #pragma unroll
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float*
                                                                     const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
                                                                     const float* __restrict__ rowvec, const float* __restrict__ colvec,
                                                                     const float* __restrict__ zlogit, float* __restrict__ max0,
-                                                                    int* __restrict__ idx0, float* __restrict__ partials) {
+                                                                    int* __restrict__ idx0, float* __restrict__ partials, int n_above) {
     __shared__ float xv[2][NW];
     __shared__ int xi[2][NW];
     const int p = blockIdx.y;
@@ -711,7 +715,9 @@ __global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float*
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
     const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
     const int r0 = blockIdx.x * SW_ROWS;
-    if (r0 >= m || !sw_wide_tier<NW>(n)) return;
+    // this launch's pairs: n_above < n <= the widest row NW waves hold. Arg-maxima do not depend on how a row is cut into slices, so --
+    // unlike the Sinkhorn / double-softmax sweeps, whose sums do -- the launcher is free to pick the tiering (launch_extract_matches)
+    if (r0 >= m || n <= n_above || n > (NW == 4 ? SW_WIDE4_COLS : SW_WIDE8_COLS)) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ld = pd.ld;
     const float* Z = zbuf + pd.z_off;
@@ -734,9 +740,11 @@ __global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float*
             }
         }
     }
+    float ci_lane = 0.f;  // logsigmoid(z0_i) of the block's rows, one per lane (see extract_rows_kernel)
+    if (!SG && r0 + (lane & 31) < m) ci_lane = logsigmoid(zlogit[s0.row_off + r0 + (lane & 31)]);
     auto process = [&](int i, const f32x4(&zz)[NCH], int slot) {
         const float a_i = rowvec[vec0 + i];
-        const float c_i = SG ? 0.f : logsigmoid(zlogit[s0.row_off + i]);
+        const float c_i = SG ? 0.f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ci_lane), __builtin_amdgcn_readfirstlane(i - r0)));
         float best = NEG;
         int bidx = SW_NO_INDEX;
 #pragma unroll
@@ -924,17 +932,25 @@ int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogi
                        zlogit, max0, idx0, a.partials)
 #define SW_LAUNCH_EXTRACT_SG_WIDE(NW, N)                                                                                                  \
     hipLaunchKernelGGL((extract_rows_wide_kernel<true, NW, N>), grid_rows, dim3(64 * NW), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, \
-                       a.colvec, zlogit, max0, idx0, a.partials)
+                       a.colvec, zlogit, max0, idx0, a.partials, (NW) == 8 ? above8 : SW_MAX_COLS)
 #define SW_LAUNCH_EXTRACT_LG_WIDE(NW, N)                                                                                                   \
     hipLaunchKernelGGL((extract_rows_wide_kernel<false, NW, N>), grid_rows, dim3(64 * NW), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, \
-                       a.colvec, zlogit, max0, idx0, a.partials)
+                       a.colvec, zlogit, max0, idx0, a.partials, (NW) == 8 ? above8 : SW_MAX_COLS)
+    // Rows beyond 2048 columns. LightGlue: eight waves per row for every width up to 10240 -- its extraction carries six register
+    // vectors per column chunk (value, index, two column terms, two rows in flight), four waves x 5 chunks at GTSfM's cap of 5000
+    // keypoints need 256 VGPRs + 44 spilled, eight waves x 3 chunks 187: 18.9 vs 19.05 ms per one-layer 16-pair call
+    // (tools/bench_extract.py). SuperGlue (no spills at four waves): the Sinkhorn tiers, four waves up to 5120 -- eight were 0.3-0.7 ms
+    // SLOWER. GTSFM_EXTRACT_WAVES=4 / 8 forces either; same arg-maxima in all cases.
+    const char* ew_env = getenv("GTSFM_EXTRACT_WAVES");
+    const bool four_up_to_5120 = ew_env ? ew_env[0] == '4' : superglue != 0;
+    const int above8 = four_up_to_5120 ? SW_WIDE4_COLS : SW_MAX_COLS;
     if (superglue) {
-        if (a.max_n > SW_WIDE4_COLS) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_EXTRACT_SG_WIDE)
-        if (a.max_n > SW_MAX_COLS) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_EXTRACT_SG_WIDE)
+        if (a.max_n > above8) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_EXTRACT_SG_WIDE)
+        if (four_up_to_5120 && a.max_n > SW_MAX_COLS) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_EXTRACT_SG_WIDE)
         SW_DISPATCH(chunks_for(a.max_n), SW_LAUNCH_EXTRACT_SG)
     } else {
-        if (a.max_n > SW_WIDE4_COLS) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_EXTRACT_LG_WIDE)
-        if (a.max_n > SW_MAX_COLS) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_EXTRACT_LG_WIDE)
+        if (a.max_n > above8) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_EXTRACT_LG_WIDE)
+        if (four_up_to_5120 && a.max_n > SW_MAX_COLS) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_EXTRACT_LG_WIDE)
         SW_DISPATCH(chunks_for(a.max_n), SW_LAUNCH_EXTRACT_LG)
     }
     hipLaunchKernelGGL(extract_cols_kernel, grid_cols, dim3(256), 0, stream, a.pairs, a.seqs, a.counts, a.partials, idx1);

@@ -518,6 +518,35 @@ def test_batch_mixing_sweep_tiers_equals_single_pairs(gpu_device, matcher):
 
 
 @pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
+def test_extraction_tiering_does_not_change_matches(gpu_device, monkeypatch, matcher):
+    """Arg-maxima do not depend on how a row is cut into slices: the match extraction runs eight waves per row for every width
+    beyond 2048 columns by default, four waves up to 5120 with GTSFM_EXTRACT_WAVES=4 -- same matches and scores bit for bit
+    (a 2600- and a 5000-column pair in one batch)."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+
+    specs = [(300, 2600, 41), (200, 5000, 42)]
+    feats = [synthetic.synthetic_pair_features(a, b, (480, 640), (480, 640), seed=sd) for a, b, sd in specs]
+    kp = T(np.concatenate([np.concatenate([f[0], f[3]]) for f in feats])).to(gpu_device)
+    sc = T(np.concatenate([np.concatenate([f[1], f[4]]) for f in feats])).to(gpu_device)
+    de = T(np.concatenate([np.concatenate([f[2], f[5]]) for f in feats])).to(gpu_device)
+    n0, n1, hw = [s[0] for s in specs], [s[1] for s in specs], [[480, 640, 480, 640]] * len(specs)
+    if matcher == "superglue":
+        eng = ME.SuperGlueEngine(synthetic.synthetic_superglue_state_dict(num_layers=4), gpu_device)
+        call = lambda: eng.match_batch(kp, sc, de, n0, n1, hw, sinkhorn_iterations=5)  # noqa: E731
+    else:
+        eng = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(num_layers=2, match_bias=-2.0, match_gain=30.0), gpu_device)
+        call = lambda: eng.match_batch(kp, de, n0, n1, hw, pruning_threshold=None)  # noqa: E731
+    got = {}
+    for waves in ("8", "4"):
+        monkeypatch.setenv("GTSFM_EXTRACT_WAVES", waves)
+        out = call()
+        got[waves] = (out["matches"].cpu().numpy(), out["mscores"].cpu().numpy())
+    assert (got["8"][0] >= 0).sum() > 20
+    np.testing.assert_array_equal(got["8"][0], got["4"][0])
+    np.testing.assert_array_equal(got["8"][1], got["4"][1])
+
+
+@pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
 def test_eight_wave_sweep_tier_vs_oracle(gpu_device, matcher):
     """Keypoint sets beyond 5120 (a user raising max_keypoints above GTSfM's default): the score matrix's rows are shared by the 8
     waves of a 512-thread workgroup (Sinkhorn / double softmax / extraction); one layer keeps the CPU oracle to seconds."""
