@@ -135,6 +135,9 @@ class _MatcherBase:
         # between and inside its ~230 launches (320 attention workgroups on 512 slots at N = 5000); a second and third launch sequence
         # fill it: 86 -> 102 -> 107 pairs/s at the cap, 346 -> 429 -> 450 at N = 2048 (tools/bench_plugin_threads.py). Lanes are created
         # when a call finds every existing one busy; a single-threaded caller only ever has the first.
+        self._init_lanes()
+
+    def _init_lanes(self) -> None:
         self.max_lanes = max(1, int(os.environ.get("GTSFM_PLUGIN_LANES", "3")))
         self._lanes: list = [self]
         self._free_lanes: "queue.LifoQueue" = queue.LifoQueue()

@@ -203,3 +203,53 @@ def test_bench_flop_accounting_matches_survey():
         assert abs(bench.matcher_flops("lightglue", n, 9.0, 0) / 1e9 - g) < 0.06, n
     # early exit scales the per-layer term only
     assert bench.matcher_flops("lightglue", 2048, 4.5, 0) < 0.51 * bench.matcher_flops("lightglue", 2048, 9.0, 0) + 1.2e9
+
+
+def test_matcher_engine_lanes_host_logic(monkeypatch):
+    """Concurrent match() calls of one worker process each get an engine lane nobody else is using; at most max_lanes exist; a
+    single-threaded caller only ever uses the first (matcher_engine._MatcherBase._lane; streams mocked: no GPU here)."""
+    import contextlib
+    import threading
+    import time
+    from collections import OrderedDict
+
+    from gtsfm_amd.runtime import matcher_engine as ME
+
+    monkeypatch.setattr(ME.torch.cuda, "Stream", lambda device=None: object())
+    monkeypatch.setattr(ME.torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    monkeypatch.setenv("GTSFM_PLUGIN_LANES", "2")
+    eng = object.__new__(ME._MatcherBase)
+    eng.device, eng._workspace, eng._staging = None, None, None
+    eng._desc_cache, eng._desc_pinned, eng._pinning = OrderedDict(), set(), False
+    eng.weights = object()
+    eng._init_lanes()
+    assert eng.max_lanes == 2
+    for _ in range(3):  # one caller: always the engine itself
+        with eng._lane() as lane:
+            assert lane is eng
+    assert len(eng._lanes) == 1
+
+    busy, seen, clashes, guard = set(), set(), [], threading.Lock()
+
+    def worker():
+        for _ in range(5):
+            with eng._lane() as lane:
+                with guard:
+                    if id(lane) in busy:
+                        clashes.append(id(lane))
+                    busy.add(id(lane))
+                    seen.add(id(lane))
+                time.sleep(0.002)
+                with guard:
+                    busy.discard(id(lane))
+
+    threads = [threading.Thread(target=worker) for _ in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not clashes
+    assert len(eng._lanes) == 2 and len(seen) == 2
+    sibling = next(lane for lane in eng._lanes if lane is not eng)
+    assert sibling.weights is eng.weights and sibling._desc_cache is not eng._desc_cache and sibling._workspace is None
+    assert eng._free_lanes.qsize() == 2
