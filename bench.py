@@ -602,6 +602,7 @@ def main() -> None:
     if scene:
         units_per_step = len(all_pairs)
         assert gathered is not None and sorted(gathered) == sorted(all_pairs), "the gathered match lists do not cover the scene's pairs"
+        assert len(gathered) == len(set(all_pairs)) == len(all_pairs)
     else:
         units_per_step = (n if detect_only else len(pairs)) * world
     value = units_per_step / (ms_per_step * 1e-3)
@@ -682,6 +683,10 @@ def main() -> None:
                 digest.update(np.asarray(pair, dtype=np.int64).tobytes())
                 digest.update(np.ascontiguousarray(per_pair[pair], dtype=np.int64).tobytes())
             result["match_digest"] = digest.hexdigest()
+        if scene:  # asserted above: every pair of the scene came back from exactly one rank
+            empty_ranks = sum(1 for r in range(world) if not parallel.partition_pairs_2d(all_pairs, r, world))
+            result["scene_check"] = {"pairs_gathered": len(gathered), "pairs_of_the_scene": len(all_pairs), "each_pair_exactly_once": True,
+                                     "ranks_without_pairs": empty_ranks}
         if dist is not None:
             result["distributed"] = {
                 "backend": dist.get_backend(), "world_size": world,

@@ -574,11 +574,14 @@ int attention_segments(int max_k) { return at_segments(max_k); }
 // one pair at N = 5000 (320) 0.51 -> 0.70, two pairs at N = 5000 (640) 0.67 -> 0.76, two pairs at N = 2048 (256) 0.71 -> 0.72;
 // 32 pairs at N = 2048 (4096) 0.84 -> 0.81 and 8 pairs at N = 5000 (2560) 0.82 -> 0.79: batches stay fused. The segment
 // structure itself costs the fused schedule 0.2 % (A/B against a build with one unbounded segment).
+static bool at_geometry_wants_split(int nproblems, int heads, int max_q, int max_k) {  // launch geometry alone (no environment)
+    return at_segments(max_k) >= 2 && (long long)nproblems * heads * ceil_div(max_q, AT_QB) < 2LL * gtsfm_cu_count() * ATD_WGS_PER_CU;
+}
 static bool at_wants_split(int nproblems, int heads, int max_q, int max_k) {
     const char* env = getenv("GTSFM_ATTENTION_SPLIT");  // "0": never, "1": whenever there is more than one segment (read per launch: tests toggle it)
     if (at_segments(max_k) < 2 || (env && env[0] == '0')) return false;
     if (env && env[0] == '1') return true;
-    return (long long)nproblems * heads * ceil_div(max_q, AT_QB) < 2 * 256 * ATD_WGS_PER_CU;
+    return at_geometry_wants_split(nproblems, heads, max_q, max_k);
 }
 
 static int at_fused_waves() {  // GTSFM_ATTENTION_WAVES = 4 | 8 (read per launch: A/B measurements; results are identical)
@@ -587,12 +590,14 @@ static int at_fused_waves() {  // GTSFM_ATTENTION_WAVES = 4 | 8 (read per launch
 }
 static int at_fused_grid(int nproblems, int heads, int max_q) { return ceil_div(heads * nproblems, 8) * 8 * ceil_div(max_q, 32 * at_fused_waves()); }
 
+// Sized from the launch GEOMETRY, never from GTSFM_ATTENTION_SPLIT: a workspace is held across calls (the pipeline's per-stream
+// workspaces, captured graphs, callers' own) while the switch is read per launch. A launch that wants the split schedule and finds
+// the workspace too small (the switch was turned on after sizing) runs the fused schedule instead -- the two are bit-identical.
 size_t attention_workspace_floats(int nproblems, int heads, int max_q, int max_k, size_t rows) {
     if (nproblems <= 0 || at_segments(max_k) < 2) return 0;  // one segment: neither schedule needs memory
     const size_t split = (size_t)at_segments(max_k) * rows * ((size_t)heads * 64 + (size_t)heads * 2);
     const size_t park = ATD_PARK_GLOBAL ? (size_t)at_fused_grid(nproblems, heads, max_q) * (ATD_OC_FLOATS / 4 * at_fused_waves()) : 0;  // single buffers: parked in LDS
-    // the schedule is picked per launch (and can be forced): hold enough for whichever the launch geometry picks
-    return at_wants_split(nproblems, heads, max_q, max_k) ? (split > park ? split : park) : park;
+    return at_geometry_wants_split(nproblems, heads, max_q, max_k) ? (split > park ? split : park) : park;
 }
 
 int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t stream) {
@@ -606,10 +611,11 @@ int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t 
     const int groups = p.heads * nproblems;
     const int max_k = p.max_k > 0 ? p.max_k : max_q;
     const size_t tile_bytes = (size_t)ATD_LDS_TILE_FLOATS * sizeof(float);
-    const bool split = p.workspace != nullptr && (p.force_split > 0 || (p.force_split == 0 && at_wants_split(nproblems, p.heads, max_q, max_k)));
+    bool split = p.workspace != nullptr && (p.force_split > 0 || (p.force_split == 0 && at_wants_split(nproblems, p.heads, max_q, max_k)));
+    const size_t need = (size_t)at_segments(max_k) * p.part_rows * ((size_t)p.heads * 64 + (size_t)p.heads * 2);
+    if (split && p.force_split <= 0 && (p.part_rows == 0 || p.workspace_floats < need)) split = false;  // not sized for it: the fused schedule gives the same bits
     if (split) {
         q.nseg = at_segments(max_k);
-        const size_t need = (size_t)q.nseg * p.part_rows * ((size_t)p.heads * 64 + (size_t)p.heads * 2);
         GTSFM_CHECK_ARG(p.part_rows > 0 && p.workspace_floats >= need, "attention: workspace too small for the split schedule (%zu < %zu floats)", p.workspace_floats, need);
         q.part_o = p.workspace;
         q.part_ml = p.workspace + (size_t)q.nseg * p.part_rows * p.heads * 64;

@@ -12,6 +12,9 @@
 #define GTSFM_ERR_WORKSPACE -3
 
 void gtsfm_set_error(const char* fmt, ...);
+// Compute units of the current device (hipDeviceProp_t::multiProcessorCount, read once per process; 256 on an MI355X and the
+// fallback when the query fails, e.g. in a build container without a GPU). Launch-geometry thresholds scale with it.
+int gtsfm_cu_count(void);
 
 #define GTSFM_CHECK_ARG(cond, ...)        \
     do {                                  \

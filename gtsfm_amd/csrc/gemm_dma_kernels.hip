@@ -498,7 +498,7 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     // wins up to ~700 large tiles. GTSFM_GEMM_SMALL_BELOW overrides the threshold (0: never).
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!p.res || (p.ldres & 3) == 0);
     const char* small_env = getenv("GTSFM_GEMM_SMALL_BELOW");
-    const long long small_below = small_env ? atoll(small_env) : 700;
+    const long long small_below = small_env ? atoll(small_env) : 700LL * gtsfm_cu_count() / 256;  // measured on 256 CUs; scales with the chip
     if (!bt.problems && !bt.ln_gamma && vec_ok && !p.n_dev && nbw == 1 && (long long)mtiles * ncb < small_below) {
         const dim3 sgrid(ceil_div(p.M, 64) * ceil_div(p.N, 64));
         const size_t slds = (size_t)2 * DS_STAGE_FLOATS * sizeof(float);

@@ -19,6 +19,19 @@ void gtsfm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int gtsfm_cu_count(void) {
+    static const int cus = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) {
+            (void)hipGetLastError();
+            return 256;
+        }
+        return (int)prop.multiProcessorCount;
+    }();
+    return cus;
+}
+
 extern "C" int gtsfm_abi_version(void) { return 1; }
 extern "C" const char* gtsfm_last_error(void) { return g_error; }
 

@@ -18,6 +18,7 @@ unpickler pair that names the stand-in ``gtsfm.common.keypoints.Keypoints`` INSI
 from __future__ import annotations
 
 import hashlib
+import logging
 import os
 import pickle
 from bz2 import BZ2File
@@ -27,6 +28,8 @@ from typing import Any, List, Optional, Tuple
 import numpy as np
 
 from gtsfm_amd.common.keypoints import Keypoints
+
+logger = logging.getLogger(__name__)
 
 NUM_KEYPOINTS_TO_SAMPLE_FOR_HASH = 10  # matcher_cacher.py:24
 
@@ -86,7 +89,23 @@ class _ReferenceNamesPickler(pickle._Pickler):  # the pure-Python pickler: the C
         return None
 
 
-class _ReferenceNamesUnpickler(pickle.Unpickler):
+class ForeignClassInCacheEntry(Exception):
+    """An entry names a class this installation cannot import (raised by ``find_class`` only)."""
+
+
+class _ForeignAwareUnpickler(pickle.Unpickler):
+    """Tells "this entry names a class that does not exist HERE" (the entry is valid for its writer: leave it) apart from every
+    other failure (a damaged or incompatible entry: the reference removes it, gtsfm/utils/io.py:442-447). Only the class lookup
+    is wrapped, so an ``AttributeError`` / ``ImportError`` raised while an object is being rebuilt stays a corruption."""
+
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except (ImportError, AttributeError) as exc:  # ModuleNotFoundError is an ImportError
+            raise ForeignClassInCacheEntry(f"{module}.{name}") from exc
+
+
+class _ReferenceNamesUnpickler(_ForeignAwareUnpickler):
     def find_class(self, module, name):
         if (module, name) == REFERENCE_KEYPOINTS_PATH:
             return Keypoints
@@ -100,17 +119,20 @@ def _stand_in_keypoints() -> bool:
 
 def read_from_bz2_file(file_path: Path) -> Optional[Any]:
     """gtsfm/utils/io.py:437-449: None when the file is missing; a corrupted file is removed. One deliberate difference: an
-    entry that fails to load because a CLASS it names cannot be imported here (an entry of a shared reference cache holding
-    types this installation lacks) is left alone -- it is valid for its writer -- and reported as a miss."""
+    entry that names a CLASS which cannot be imported here (an entry of a shared reference cache holding types this installation
+    lacks; detected in ``find_class`` only) is left alone -- it is valid for its writer -- logged and reported as a miss. Every other
+    failure, including an ``AttributeError`` / ``ImportError`` raised while an object is being rebuilt, removes the file like the reference."""
     file_path = Path(file_path)
     if not file_path.exists():
         return None
     try:
         with BZ2File(file_path, "rb") as f:
-            return _ReferenceNamesUnpickler(f).load() if _stand_in_keypoints() else pickle.load(f)
-    except (ImportError, AttributeError):  # ModuleNotFoundError is an ImportError
+            return (_ReferenceNamesUnpickler if _stand_in_keypoints() else _ForeignAwareUnpickler)(f).load()
+    except ForeignClassInCacheEntry as exc:
+        logger.warning("Cache entry %s names a class that cannot be imported here (%s): treated as a miss, file kept.", file_path, exc)
         return None
     except Exception:  # noqa: BLE001 - the reference swallows every failure and drops the file
+        logger.exception("Cache file %s was corrupted, removing it...", file_path)
         os.remove(file_path)
         return None
 

@@ -46,15 +46,25 @@ MODEL_LOAD_LOCK = threading.Lock()
 
 def warn_if_cpu_requested(use_cuda: bool, plugin: str) -> None:
     """``use_cuda=False`` (the reference's own contract tests construct the plugins that way, and the reference then runs its torch
-    model on the CPU): this package has no CPU path. With a GPU present the plugin runs on it and says so once -- outputs are the
-    reference's within the parity tolerances on either device, so GTSfM's tests and configs work unchanged on a GPU box; without a
-    GPU the first call raises ``RuntimeError`` (``require_gpu``), never a silent fallback."""
+    model on the CPU): this package has no CPU path. Called once per plugin INSTANCE, when it builds its device engine.
+
+    * ``GTSFM_AMD_STRICT_USE_CUDA=1``: ``use_cuda=False`` raises ``RuntimeError`` -- for deployments that use the flag to keep a
+      worker off the device or expect CPU-bit-exact results.
+    * default: with a GPU present the plugin runs on it, emits a ``RuntimeWarning`` and a WARNING log record naming the instance's
+      plugin -- outputs are the reference's within the parity tolerances on either device, so GTSfM's tests and configs work
+      unchanged on a GPU box; without a GPU the first call raises ``RuntimeError`` (``require_gpu``), never a silent fallback.
+    INTEGRATION.md section 1 documents this as a contract deviation."""
     if use_cuda:
         return
+    import logging
+    import os
     import warnings
 
     import torch
 
+    if os.environ.get("GTSFM_AMD_STRICT_USE_CUDA", "0") == "1":
+        raise RuntimeError(f"gtsfm_amd.{plugin}: use_cuda=False was requested and GTSFM_AMD_STRICT_USE_CUDA=1: this implementation has no CPU path")
     if torch.cuda.is_available():
-        warnings.warn(f"gtsfm_amd.{plugin}: use_cuda=False was requested, but this implementation has no CPU path; running on the GPU.",
-                      RuntimeWarning, stacklevel=3)
+        msg = f"gtsfm_amd.{plugin}: use_cuda=False was requested, but this implementation has no CPU path; running on the GPU (GTSFM_AMD_STRICT_USE_CUDA=1 makes this an error)."
+        logging.getLogger("gtsfm_amd").warning(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)

@@ -26,8 +26,8 @@ LightGlue (upstream ``cvg/LightGlue`` module names)
 from __future__ import annotations
 
 import contextlib
-import copy
 import ctypes as C
+import hashlib
 import os
 import queue
 import threading
@@ -115,10 +115,51 @@ def superglue_entries(sd: Mapping[str, torch.Tensor]) -> List[Entry]:
     return entries
 
 
+class _ImageEntry:
+    """One image's device-resident matcher inputs (the per-call plugin path): its keypoints (and scores) as uploaded and the output
+    of ``prepare_images`` -- the matcher block that sees ONE image. ``ready`` orders consumers on other lanes' streams behind it."""
+
+    __slots__ = ("kpts", "scores", "x", "ready", "stream")
+
+    def __init__(self, kpts, scores, x, ready, stream):
+        self.kpts, self.scores, self.x, self.ready, self.stream = kpts, scores, x, ready, stream
+
+
 class _MatcherBase:
+    # what a lane shares with the engine it was made from: read-only after construction (the weight blob lives on the device)
+    _SHARED_ATTRS: Tuple[str, ...] = ("device", "_lib", "weights", "num_layers", "desc_cache_capacity", "max_lanes")
+
     def __init__(self, device: Optional[torch.device]):
         self.device = require_gpu(device)
         self._lib = _lib.load()
+        self._init_host_state()
+
+    def _init_host_state(self) -> None:
+        self.desc_cache_capacity = 64
+        # match_pair() re-uses an engine's staging buffers and workspace, so one thread at a time owns them. Calls from several
+        # threads of one worker process (GTSfM's ``--threads_per_worker``, gtsfm/runner.py:155,436) do not queue behind each other,
+        # though: up to ``max_lanes`` of them run side by side, each on a LANE = an engine of its own (own workspace, staging
+        # buffers, descriptor cache and HIP stream) that shares this engine's weights. One pair leaves a fifth of the chip idle
+        # between and inside its ~230 launches (320 attention workgroups on 512 slots at N = 5000); a second and third launch sequence
+        # fill it: 86 -> 102 -> 107 pairs/s at the cap, 346 -> 429 -> 450 at N = 2048 (tools/bench_plugin_threads.py). Lanes are created
+        # when a call finds every existing one busy; a single-threaded caller only ever has the first. Memory: a lane at the
+        # 5000-keypoint cap holds ~0.5 GB of workspace + 10 MB of pinned / device staging (INTEGRATION.md section 3); ``release_lanes()``
+        # returns it.
+        self.max_lanes = max(1, int(os.environ.get("GTSFM_PLUGIN_LANES", "3")))
+        self._init_call_state()
+        self._lanes: list = [self]
+        self._free_lanes: "queue.LifoQueue" = queue.LifoQueue()
+        self._free_lanes.put(self)
+        self._lanes_lock = threading.Lock()
+        self._root: "_MatcherBase" = self
+        # per-call path: device-resident per-image inputs, shared by the lanes (see _image_entries)
+        self.image_cache_capacity = max(0, int(os.environ.get("GTSFM_PLUGIN_IMAGE_CACHE", "64")))
+        self._image_cache: "OrderedDict[tuple, _ImageEntry]" = OrderedDict()
+        self._image_cache_lock = threading.Lock()
+        self.image_cache_hits = self.image_cache_misses = 0
+
+    def _init_call_state(self) -> None:
+        """Everything a call writes; a lane has its own."""
         self._workspace: Optional[torch.Tensor] = None
         # pristine descriptor blocks per batch shape, least recently used first. A block a captured hipGraph copies from must
         # never be freed (the graph's copy node holds its ADDRESS): blocks touched inside ``pin_descriptors()`` are exempt
@@ -126,31 +167,18 @@ class _MatcherBase:
         self._desc_cache: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()
         self._desc_pinned: set = set()
         self._pinning = False
-        self.desc_cache_capacity = 64
         self._staging: Optional[dict] = None
-        # match_pair() re-uses an engine's staging buffers and workspace, so one thread at a time owns them. Calls from several
-        # threads of one worker process (GTSfM's ``--threads_per_worker``, gtsfm/runner.py:155,436) do not queue behind each other,
-        # though: up to ``max_lanes`` of them run side by side, each on a LANE = an engine of its own (own workspace, staging
-        # buffers, descriptor cache and HIP stream) that shares this engine's weights. One pair leaves a fifth of the chip idle
-        # between and inside its ~230 launches (320 attention workgroups on 512 slots at N = 5000); a second and third launch sequence
-        # fill it: 86 -> 102 -> 107 pairs/s at the cap, 346 -> 429 -> 450 at N = 2048 (tools/bench_plugin_threads.py). Lanes are created
-        # when a call finds every existing one busy; a single-threaded caller only ever has the first.
-        self._init_lanes()
-
-    def _init_lanes(self) -> None:
-        self.max_lanes = max(1, int(os.environ.get("GTSFM_PLUGIN_LANES", "3")))
-        self._lanes: list = [self]
-        self._free_lanes: "queue.LifoQueue" = queue.LifoQueue()
-        self._free_lanes.put(self)
-        self._lanes_lock = threading.Lock()
         self._lane_stream: Optional[torch.cuda.Stream] = None
 
     def _sibling(self) -> "_MatcherBase":
-        """An engine sharing this one's weights (read-only on the device) and nothing a call writes."""
-        other = copy.copy(self)
-        other._workspace, other._staging, other._lane_stream = None, None, None
-        other._desc_cache, other._desc_pinned, other._pinning = OrderedDict(), set(), False
-        other._lanes, other._free_lanes = [other], None  # lanes are handed out by the engine they were made from
+        """An engine sharing this one's weights (read-only on the device) and nothing a call writes: built from the explicit list
+        of shared attributes, so a per-call attribute added later cannot be shared between threads by accident."""
+        other = object.__new__(type(self))
+        for name in self._SHARED_ATTRS:
+            setattr(other, name, getattr(self, name))
+        other._init_call_state()
+        other._lanes, other._free_lanes, other._lanes_lock = [other], None, None  # lanes are handed out by the engine they were made from
+        other._root = self
         return other
 
     @contextlib.contextmanager
@@ -174,14 +202,105 @@ class _MatcherBase:
         finally:
             self._free_lanes.put(eng)
 
+    def release_lanes(self) -> None:
+        """Give back what the per-call path holds between calls: the idle sibling lanes (workspace, staging buffers, descriptor-block
+        caches), this engine's own workspace and staging buffers, and the per-image cache. Lanes serving a call at this moment survive;
+        descriptor blocks pinned by captured hipGraphs stay (the graphs hold their addresses). The next call rebuilds what it needs."""
+        with self._lanes_lock:
+            idle = []
+            while True:
+                try:
+                    idle.append(self._free_lanes.get_nowait())
+                except queue.Empty:
+                    break
+            for eng in idle:
+                if eng is not self:
+                    self._lanes.remove(eng)
+            if self in idle:
+                self._workspace = self._staging = None
+                for key in [k for k in self._desc_cache if k not in self._desc_pinned]:
+                    del self._desc_cache[key]
+                self._free_lanes.put(self)
+        with self._image_cache_lock:
+            self._image_cache.clear()
+
+    # -- per-call path: every image once ------------------------------------------------------------------------------------------
+
+    @staticmethod
+    def _image_key(arrays: Sequence[np.ndarray], shape: Tuple[int, int]) -> tuple:
+        """Identity of one image's host arrays as a ``match()`` call hands them over: address, shape, dtype and strides of every array
+        plus a hash over a sample of rows (the first and last 10 and 16 evenly spaced ones) -- the reference's own MatcherCacher keys
+        a pair on the first 10 rows alone (gtsfm/frontend/cacher/matcher_cacher.py:24,46-80). An array that is overwritten in place
+        between two calls AND keeps all sampled rows would be taken for the old one; GTSFM_PLUGIN_IMAGE_CACHE=0 turns the cache off."""
+        n = len(arrays[0])
+        rows = np.unique(np.concatenate([np.arange(min(10, n)), np.arange(max(0, n - 10), n), np.linspace(0, n - 1, 16).astype(np.int64)])) if n else np.zeros(0, np.int64)
+        h = hashlib.blake2b(digest_size=16)
+        ident = []
+        for a in arrays:
+            a = np.asarray(a)
+            ident.append((a.__array_interface__["data"][0], a.shape, a.dtype.str, a.strides))
+            h.update(np.ascontiguousarray(a[rows]).tobytes())
+        return (tuple(ident), (int(shape[0]), int(shape[1])), h.digest())
+
+    def _image_entries(self, images: Sequence[Tuple[Sequence[np.ndarray], Tuple[int, int]]]) -> List[_ImageEntry]:
+        """Device-resident inputs of the images of one ``match_pair`` call, on the CURRENT lane (self) and stream. The reference's
+        wrappers upload both images' features for every pair (superglue_matcher.py:75-102, lightglue_matcher.py:75-100) and the
+        matcher's first block then runs per pair side; an image that appears in k pairs is uploaded and taken through that block ONCE
+        here (``prepare_images``: bit-identical to the per-pair form, tests/test_matchers_gpu.py) and found in the cache k - 1 times.
+        The cache belongs to the engine the lanes were made from; an entry made on another lane's stream is ordered by its event."""
+        root = self._root
+        keys = [self._image_key(arrs, shape) for arrs, shape in images]
+        stream = torch.cuda.current_stream(self.device)
+        with root._image_cache_lock:
+            found = [root._image_cache.get(k) for k in keys]
+            for k, e in zip(keys, found):
+                if e is not None:
+                    root._image_cache.move_to_end(k)
+        miss = [i for i, e in enumerate(found) if e is None and keys[i] not in keys[:i]]
+        if miss:
+            staged = self._stage_sets([images[i][0] for i in miss])
+            counts = [len(images[i][0][0]) for i in miss]
+            x = self._prepare_staged(staged, counts, [images[i][1] for i in miss])
+            ready = torch.cuda.Event()
+            ready.record(stream)
+            off = 0
+            for i, c in zip(miss, counts):
+                kp = staged[0][off : off + c].clone()
+                sc = staged[1][off : off + c].reshape(-1).clone() if len(staged) == 3 else None
+                found[i] = _ImageEntry(kp, sc, x[off : off + c], ready, stream)
+                off += c
+            with root._image_cache_lock:
+                for i in miss:
+                    root._image_cache[keys[i]] = found[i]
+                while len(root._image_cache) > root.image_cache_capacity:
+                    root._image_cache.popitem(last=False)  # consumers hold their own references; the allocator waits for recorded streams
+                root.image_cache_misses += len(miss)
+                root.image_cache_hits += len(images) - len(miss)
+        else:
+            with root._image_cache_lock:
+                root.image_cache_hits += len(images)
+        for i, e in enumerate(found):
+            if e is None:  # the same image twice in one call
+                found[i] = e = found[keys.index(keys[i])]
+            if e.stream != stream:
+                stream.wait_event(e.ready)
+                for t in (e.kpts, e.scores, e.x):
+                    if t is not None:
+                        t.record_stream(stream)
+        return found
+
     def _stage_pair(self, arrays0: Sequence[np.ndarray], arrays1: Sequence[np.ndarray]) -> List[torch.Tensor]:
-        """Host arrays of the two images of ONE pair -> device tensors [n0 + n1, ...], one per array: converted to float32 straight
+        """Host arrays of the two images of ONE pair -> device tensors [n0 + n1, ...], one per array (see ``_stage_sets``)."""
+        return self._stage_sets([arrays0, arrays1])
+
+    def _stage_sets(self, sets: Sequence[Sequence[np.ndarray]]) -> List[torch.Tensor]:
+        """Host arrays of one or more images -> device tensors [sum of rows, ...], one per array kind: converted to float32 straight
         into page-locked staging buffers that live as long as the engine (grown geometrically), then one asynchronous copy each
         into equally persistent device buffers. The per-call plugin API (``match(...)`` with numpy in / numpy out, once per pair of
         the Dask graph) pays no allocation, no pageable-memory bounce and no intermediate concatenation this way."""
-        n0, n1 = len(arrays0[0]), len(arrays1[0])
-        t = n0 + n1
-        widths = [int(np.prod(a.shape[1:])) for a in arrays0]
+        rows_of = [len(arrs[0]) for arrs in sets]
+        t = int(sum(rows_of))
+        widths = [int(np.prod(np.shape(a)[1:])) for a in sets[0]]
         st = self._staging
         if st is None or st["rows"] < t or st["widths"] != widths:
             rows = max(t, int(1.5 * st["rows"]) if st is not None and st["widths"] == widths else 0, 256)
@@ -195,9 +314,11 @@ class _MatcherBase:
         else:
             st["done"].synchronize()  # the previous call's copies have left the staging buffers
         out = []
-        for view, host, dev, a0, a1, w in zip(st["views"], st["host"], st["dev"], arrays0, arrays1, widths):
-            view[:n0] = np.asarray(a0).reshape(n0, w)  # numpy casts (float64 / integer inputs of the reference's own tests) while copying
-            view[n0:t] = np.asarray(a1).reshape(n1, w)
+        for j, (view, host, dev, w) in enumerate(zip(st["views"], st["host"], st["dev"], widths)):
+            off = 0
+            for arrs, n in zip(sets, rows_of):
+                view[off : off + n] = np.asarray(arrs[j]).reshape(n, w)  # numpy casts (float64 / integer inputs of the reference's own tests) while copying
+                off += n
             dev[:t].copy_(host[:t], non_blocking=True)
             out.append(dev[:t])
         st["done"].record(torch.cuda.current_stream(self.device))
@@ -249,6 +370,11 @@ class _MatcherBase:
 
 class SuperGlueEngine(_MatcherBase):
     """Device-resident SuperGlue (superglue.py:228-283) for ragged batches of pairs."""
+
+    _SHARED_ATTRS = _MatcherBase._SHARED_ATTRS + ("bin_score",)
+
+    def _prepare_staged(self, staged, counts, shapes):
+        return self.prepare_images(staged[0], staged[1].reshape(-1), staged[2], counts, shapes)
 
     def __init__(self, state_dict: Mapping[str, torch.Tensor], device: Optional[torch.device] = None):
         super().__init__(device)
@@ -348,11 +474,14 @@ class SuperGlueEngine(_MatcherBase):
                 "matching_scores0": np.zeros(n0, dtype=np.float32), "matching_scores1": np.zeros(n1, dtype=np.float32),
             }
         with self._lane() as eng:
-            kp, sc, de = eng._stage_pair((k0, s0, d0), (k1, s1, d1))
-            out = eng.match_batch(
-                kp, sc.reshape(-1), de, [n0], [n1], [[shape0[0], shape0[1], shape1[0], shape1[1]]],
-                sinkhorn_iterations, match_threshold, return_ot,
-            )
+            hw = [[shape0[0], shape0[1], shape1[0], shape1[1]]]
+            if self.image_cache_capacity > 0 and self.num_layers >= 1:
+                e0, e1 = eng._image_entries([((k0, s0, d0), shape0), ((k1, s1, d1), shape1)])
+                out = eng.match_batch(torch.cat([e0.kpts, e1.kpts]), torch.cat([e0.scores, e1.scores]), torch.cat([e0.x, e1.x]), [n0], [n1], hw,
+                                      sinkhorn_iterations, match_threshold, return_ot, first_layer_done=True)
+            else:
+                kp, sc, de = eng._stage_pair((k0, s0, d0), (k1, s1, d1))
+                out = eng.match_batch(kp, sc.reshape(-1), de, [n0], [n1], hw, sinkhorn_iterations, match_threshold, return_ot)
             m = out["matches"].cpu().numpy().astype(np.int64)
             ms = out["mscores"].cpu().numpy()
             ot = out["ot"].cpu().numpy() if return_ot else None
@@ -437,6 +566,11 @@ def lightglue_entries(sd: Mapping[str, torch.Tensor]) -> Tuple[List[Entry], np.n
 class LightGlueEngine(_MatcherBase):
     """Device-resident LightGlue(features="superpoint") for ragged batches of pairs; adaptive depth and width are
     evaluated on the device (no host synchronisation inside the layer loop)."""
+
+    _SHARED_ATTRS = _MatcherBase._SHARED_ATTRS + ("match_bias", "conf_bias")
+
+    def _prepare_staged(self, staged, counts, shapes):
+        return self.prepare_images(staged[0], staged[1], counts, shapes)
 
     def __init__(self, state_dict: Mapping[str, torch.Tensor], device: Optional[torch.device] = None):
         super().__init__(device)
@@ -536,8 +670,13 @@ class LightGlueEngine(_MatcherBase):
                 "matching_scores0": np.zeros(n0, dtype=np.float32), "matching_scores1": np.zeros(n1, dtype=np.float32), "stop": 1,
             }
         with self._lane() as eng:
-            kp, de = eng._stage_pair((k0, d0), (k1, d1))
-            out = eng.match_batch(kp, de, [n0], [n1], [[shape0[0], shape0[1], shape1[0], shape1[1]]], **kwargs)
+            hw = [[shape0[0], shape0[1], shape1[0], shape1[1]]]
+            if self.image_cache_capacity > 0 and not kwargs.get("first_layer_done", False):
+                e0, e1 = eng._image_entries([((k0, d0), shape0), ((k1, d1), shape1)])
+                out = eng.match_batch(torch.cat([e0.kpts, e1.kpts]), torch.cat([e0.x, e1.x]), [n0], [n1], hw, **dict(kwargs, first_layer_done=True))
+            else:
+                kp, de = eng._stage_pair((k0, d0), (k1, d1))
+                out = eng.match_batch(kp, de, [n0], [n1], hw, **kwargs)
             m = out["matches"].cpu().numpy().astype(np.int64)
             ms = out["mscores"].cpu().numpy()
             out = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in out.items() if k in ("stop", "kept", "sim")}

@@ -6,8 +6,12 @@ PyTorch is used for device memory and streams only; all arithmetic runs in libgt
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import os
+import queue
 import threading
+from collections import OrderedDict
 from typing import Dict, Mapping, Optional
 
 import numpy as np
@@ -49,6 +53,19 @@ def pack_superpoint_weights(state_dict: Mapping[str, torch.Tensor]) -> np.ndarra
     return out
 
 
+WORKSPACE_SHAPES_KEPT = 6  # workspaces cached per lane, least recently used evicted one at a time (mixed portrait / landscape scenes)
+
+
+class _DetectLane:
+    """What one in-flight ``detect_lazy`` call owns: page-locked staging buffers, workspaces, a HIP stream. The weights are shared."""
+
+    def __init__(self) -> None:
+        self.pinned: Dict[str, torch.Tensor] = {}
+        self.workspaces: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()
+        self.stream: Optional[torch.cuda.Stream] = None
+        self.lock = threading.Lock()  # the staging buffers serve the call AND its later fetch(): one at a time
+
+
 class SuperPointEngine:
     """Device-resident SuperPoint: packed weights in HBM + cached workspaces."""
 
@@ -56,7 +73,7 @@ class SuperPointEngine:
         self.device = require_gpu(device)
         self._lib = _lib.load()
         self.weights = torch.from_numpy(pack_superpoint_weights(state_dict)).to(self.device)
-        self._workspaces: Dict[tuple, torch.Tensor] = {}
+        self._init_lanes()
 
     @classmethod
     def from_packed(cls, packed: torch.Tensor) -> "SuperPointEngine":
@@ -65,18 +82,64 @@ class SuperPointEngine:
         self.device = packed.device
         self._lib = _lib.load()
         self.weights = packed
-        self._workspaces = {}
+        self._init_lanes()
         return self
 
-    def _workspace(self, b: int, h: int, w: int) -> torch.Tensor:
+    def _init_lanes(self) -> None:
+        # batched callers (the pipeline: one thread, the caller's stream) use the main lane's workspaces; detect_lazy() -- the
+        # per-call plugin API, possibly from several worker threads (GTSfM's --threads_per_worker) -- takes a free lane, creating
+        # up to GTSFM_PLUGIN_LANES of them, like the matcher engines (matcher_engine._MatcherBase._lane)
+        self.max_lanes = max(1, int(os.environ.get("GTSFM_PLUGIN_LANES", "3")))
+        self._main = _DetectLane()
+        self._lanes = [self._main]
+        self._free_lanes: "queue.LifoQueue" = queue.LifoQueue()
+        self._free_lanes.put(self._main)
+        self._lanes_lock = threading.Lock()
+
+    @contextlib.contextmanager
+    def _lane(self):
+        try:
+            lane = self._free_lanes.get_nowait()
+        except queue.Empty:
+            lane = None
+            with self._lanes_lock:
+                if len(self._lanes) < self.max_lanes:
+                    lane = _DetectLane()
+                    self._lanes.append(lane)
+            if lane is None:
+                lane = self._free_lanes.get()
+        try:
+            yield lane
+        finally:
+            self._free_lanes.put(lane)
+
+    def release_lanes(self) -> None:
+        """Drop the extra lanes (their pinned buffers and workspaces) and the main lane's cached workspaces; lanes in use survive."""
+        with self._lanes_lock:
+            idle = []
+            while True:
+                try:
+                    idle.append(self._free_lanes.get_nowait())
+                except queue.Empty:
+                    break
+            for lane in idle:
+                if lane is not self._main:
+                    self._lanes.remove(lane)
+            self._main.workspaces.clear()
+            if self._main in idle:
+                self._free_lanes.put(self._main)
+
+    def _workspace(self, b: int, h: int, w: int, lane: Optional[_DetectLane] = None) -> torch.Tensor:
+        cache = (lane or self._main).workspaces
         key = (b, h, w)
-        ws = self._workspaces.get(key)
+        ws = cache.get(key)
         if ws is None:
             nbytes = self._lib.gtsfm_sp_workspace_bytes(b, h, w)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            if len(self._workspaces) > 4:
-                self._workspaces.clear()
-            self._workspaces[key] = ws
+            while len(cache) >= WORKSPACE_SHAPES_KEPT:
+                cache.popitem(last=False)  # the least recently used shape only (round 3 dropped all of them at the 6th shape)
+            ws = cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        else:
+            cache.move_to_end(key)
         return ws
 
     @staticmethod
@@ -95,6 +158,7 @@ class SuperPointEngine:
         return_score_maps: bool = False,
         top_k: int = 0,
         valid_masks: Optional[torch.Tensor] = None,
+        _lane: Optional[_DetectLane] = None,
     ) -> Dict[str, torch.Tensor]:
         """images: device tensor [B,H,W], uint8 or float32 in [0,1]; valid_masks (optional): device uint8 [B,H,W], 1 = valid --
         keypoints on other pixels are dropped before the top-k (``Keypoints.filter_by_mask``). Returns device tensors:
@@ -116,7 +180,7 @@ class SuperPointEngine:
             h8, w8 = (h // 8) * 8, (w // 8) * 8
             dense = torch.empty((b, h8, w8), dtype=torch.float32, device=dev)
             nms = torch.empty((b, h8, w8), dtype=torch.float32, device=dev)
-        ws = self._workspace(b, h, w)
+        ws = self._workspace(b, h, w, _lane)
         if valid_masks is not None:
             assert valid_masks.shape == images.shape and valid_masks.dtype == torch.uint8 and valid_masks.is_cuda and valid_masks.is_contiguous()
         rc = self._lib.gtsfm_sp_forward_masked(
@@ -131,51 +195,55 @@ class SuperPointEngine:
             out["dense_scores"], out["nms_scores"] = dense, nms
         return out
 
-    def _pinned(self, name: str, shape, dtype) -> torch.Tensor:
-        """A page-locked host buffer that lives as long as the engine (grown geometrically): the per-call plugin API moves an image
+    @staticmethod
+    def _pinned(lane: _DetectLane, name: str, shape, dtype) -> torch.Tensor:
+        """A page-locked host buffer that lives as long as its lane (grown geometrically): the per-call plugin API moves an image
         in and keypoints / descriptors out on every call, and must not depend on how fast the host maps fresh pageable memory."""
-        pool = self.__dict__.setdefault("_pinned_pool", {})
         need = int(np.prod(shape))
-        buf = pool.get(name)
+        buf = lane.pinned.get(name)
         if buf is None or buf.numel() < need or buf.dtype != dtype:
-            buf = pool[name] = torch.empty(max(need, int(1.5 * (0 if buf is None else buf.numel()))), dtype=dtype, pin_memory=True)
+            buf = lane.pinned[name] = torch.empty(max(need, int(1.5 * (0 if buf is None else buf.numel()))), dtype=dtype, pin_memory=True)
         return buf[:need].view(*shape)
 
     def detect_lazy(self, gray: np.ndarray, **kwargs):
         """Single host image -> (coordinates [K,2], scores [K], fetch): the keypoint list in the model's row-major order on the
         host, the descriptors still on the device; ``fetch(indices)`` returns descriptor rows ``indices`` as a fresh [len,256] numpy
         array. The plugin selects on the host with the reference's own ``Keypoints`` methods and downloads only what it keeps
-        (5000 of ~8000 rows at GTSfM's cap)."""
+        (5000 of ~8000 rows at GTSfM's cap). Calls from several threads run side by side, each on a lane of its own (staging
+        buffers, workspace, stream); round 3 serialised them behind one lock."""
         assert gray.ndim == 2
-        lock = self.__dict__.setdefault("_detect_lock", threading.Lock())  # the pinned staging buffers are the engine's: one call at a time
-        with lock:
-            return self._detect_lazy_locked(gray, **kwargs)
+        with self._lane() as lane:
+            if lane.stream is None:
+                lane.stream = torch.cuda.Stream(self.device)
+            with lane.lock, torch.cuda.stream(lane.stream):
+                return self._detect_lazy_on(lane, gray, **kwargs)
 
-    def _detect_lazy_locked(self, gray: np.ndarray, **kwargs):
-        stage = self._pinned("image", gray.shape, torch.uint8 if gray.dtype == np.uint8 else torch.float32)
+    def _detect_lazy_on(self, lane: _DetectLane, gray: np.ndarray, **kwargs):
+        stage = self._pinned(lane, "image", gray.shape, torch.uint8 if gray.dtype == np.uint8 else torch.float32)
         stage.numpy()[...] = gray
         img = stage.to(self.device, non_blocking=True)[None]
-        out = self.forward(img, **kwargs)
+        out = self.forward(img, _lane=lane, **kwargs)
         k_raw = int(out["count_raw"][0].item())  # synchronises: the staged image has been consumed
         if k_raw > out["xy"].shape[1]:  # ties can exceed the NMS packing bound; rerun with an exact capacity
-            out = self.forward(img, **dict(kwargs, capacity=k_raw))
+            out = self.forward(img, _lane=lane, **dict(kwargs, capacity=k_raw))
         k = int(out["count"][0].item())
-        small = self._pinned("xy_scores", (k, 3), torch.float32)
+        small = self._pinned(lane, "xy_scores", (k, 3), torch.float32)
         small[:, :2].copy_(out["xy"][0, :k], non_blocking=True)
         small[:, 2].copy_(out["scores"][0, :k], non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        lane.stream.synchronize()
         host = small.numpy()
         desc = out["descriptors"][0]
+        stream = lane.stream
 
         def fetch(indices: np.ndarray) -> np.ndarray:
             indices = np.asarray(indices, dtype=np.int64)
-            with self.__dict__["_detect_lock"]:
-                rows = self._pinned("descriptors", (len(indices), 256), torch.float32)
+            with lane.lock, torch.cuda.stream(stream):  # the lane may serve another call by now: its buffers one at a time
+                rows = self._pinned(lane, "descriptors", (len(indices), 256), torch.float32)
                 if len(indices):
-                    idx = self._pinned("indices", (len(indices),), torch.int64)
+                    idx = self._pinned(lane, "indices", (len(indices),), torch.int64)
                     idx.numpy()[...] = indices
                     rows.copy_(desc.index_select(0, idx.to(self.device, non_blocking=True)), non_blocking=True)
-                    torch.cuda.current_stream(self.device).synchronize()
+                    stream.synchronize()
                 return rows.numpy().copy()
 
         return host[:, :2].copy(), host[:, 2].copy(), fetch

@@ -275,19 +275,112 @@ def check_lund_door(write: bool) -> None:
         )
 
 
+LUND_DOOR_MAX_RESOLUTION = 760  # gtsfm/configs/loader/olsson.yaml:5
+LUND_DOOR_MAX_KEYPOINTS = 5000  # gtsfm/configs/deep_front_end.yaml:29
+LUND_DOOR_DESC_HEAD = 64        # descriptor rows stored per image (the full 5000 x 256 block would be 61 MB for 12 images)
+
+
+def check_lund_door_config1(write: bool, max_pairs: int | None = None) -> None:
+    """BASELINE config 1 LITERALLY: all 12 frames of tests/data/set1_lund_door (1296x1936 RGB JPEG) as the Olsson loader hands
+    them to the front end -- short side reduced to ``max_resolution = 760`` (gtsfm/configs/loader/olsson.yaml:5,
+    gtsfm/loader/loader_base.py:160-200 -> 760 x 1135) with the restated ``cv.INTER_CUBIC`` (cv2 is absent here: that one step
+    is oracle/imageprep_oracle.py, PARITY UNPINNED), ``cv.cvtColor(RGB2GRAY)`` (gtsfm/utils/images.py:15-42), then
+
+    * the REFERENCE SuperPoint on every frame, followed by the wrapper's post-processing restated from
+      gtsfm/frontend/detector_descriptor/superpoint.py:76-91: ``Keypoints.get_top_k(5000)`` = ``np.argpartition(-responses, k)[:k]``
+      (the order the reference hands to the matcher), and
+    * the REFERENCE SuperGlue (GTSfM's 20 Sinkhorn iterations, gtsfm/frontend/matcher/superglue_matcher.py:47-52) on all 66
+      exhaustive pairs of those 5000-keypoint sets, followed by the wrapper's output marshalling (:104-113).
+
+    The reduced gray frames travel with the outputs (/root/reference does not exist on the GPU box)."""
+    from PIL import Image as PILImage
+
+    from oracle import imageprep_oracle
+
+    folder = REFERENCE / "tests" / "data" / "set1_lund_door" / "images"
+    names = sorted(p.name for p in folder.glob("*.JPG"))
+    assert len(names) == 12, names
+    sp_sd = synthetic.synthetic_superpoint_state_dict()
+    sg_sd = synthetic.synthetic_superglue_state_dict()
+    sp = reference_superpoint(sp_sd)
+    out = {}
+    grays, feats = [], []
+    for i, name in enumerate(names):
+        rgb = np.asarray(PILImage.open(folder / name).convert("RGB"), dtype=np.uint8)
+        new_h, new_w = imageprep_oracle.downsampled_size(rgb.shape[0], rgb.shape[1], LUND_DOOR_MAX_RESOLUTION)
+        small = imageprep_oracle.resize_inter_cubic_u8(rgb, new_h, new_w)
+        gray = imageprep_oracle.rgb_to_gray_u8(small)
+        img = superpoint_oracle.gray_u8_to_tensor(gray)
+        with torch.no_grad(), _force_align_corners():
+            ref = sp({"image": img})
+            ora = superpoint_oracle.superpoint_forward(sp_sd, img)
+        kp, sc, de = ref["keypoints"][0], ref["scores"][0], ref["descriptors"][0]
+        assert torch.equal(kp, ora["keypoints"]) and torch.equal(sc, ora["scores"]) and torch.equal(de, ora["descriptors"])
+        # wrapper post-processing (superpoint.py:76-91): numpy, (K, 256) descriptors, top-k by response in argpartition order
+        coords, resp, desc = kp.numpy(), sc.numpy(), de.numpy().T
+        k_raw = coords.shape[0]
+        sel = np.argpartition(-resp, LUND_DOOR_MAX_KEYPOINTS)[:LUND_DOOR_MAX_KEYPOINTS] if k_raw > LUND_DOOR_MAX_KEYPOINTS else np.arange(k_raw)
+        coords, resp, desc = coords[sel], resp[sel], desc[sel]
+        print(f"lund door {name}: {gray.shape[0]}x{gray.shape[1]}, K_raw={k_raw} -> {len(sel)}; restatement bit-exact with reference")
+        grays.append(gray)
+        feats.append((coords, resp, desc))
+        out[f"k_raw_{i}"] = k_raw
+        out[f"sel_{i}"] = sel.astype(np.uint16 if k_raw < 65536 else np.uint32)  # index into the row-major detection list
+        out[f"keypoints_{i}"] = coords.astype(np.int16)
+        out[f"scores_{i}"] = resp
+        out[f"descriptors_head_{i}"] = desc[:LUND_DOOR_DESC_HEAD].copy()
+    sg = reference_superglue(sg_sd, 20)
+    pairs = [(i, j) for i in range(12) for j in range(i + 1, 12)]
+    if max_pairs is not None:
+        pairs = pairs[:max_pairs]
+    total = 0
+    for i, j in pairs:
+        (k0, s0, d0), (k1, s1, d1) = feats[i], feats[j]
+        T = torch.from_numpy
+        data = {  # superglue_matcher.py:75-102
+            "keypoints0": T(k0)[None].float(), "keypoints1": T(k1)[None].float(), "scores0": T(s0)[None].float(), "scores1": T(s1)[None].float(),
+            "descriptors0": T(np.ascontiguousarray(d0.T))[None].float(), "descriptors1": T(np.ascontiguousarray(d1.T))[None].float(),
+            "image0": torch.empty((1, 1) + grays[i].shape), "image1": torch.empty((1, 1) + grays[j].shape),
+        }
+        with torch.no_grad():
+            ref = sg(data)
+        m0 = ref["matches0"][0].numpy()
+        valid = m0 > -1
+        idxs = np.hstack([np.arange(len(m0)).reshape(-1, 1)[valid], m0.reshape(-1, 1)[valid]]).astype(np.uint32)  # :104-113
+        total += len(idxs)
+        print(f"lund door superglue ({i},{j}): {len(idxs)} matches", flush=True)
+        out[f"match_indices_{i}_{j}"] = idxs.astype(np.uint16)
+        out[f"matches0_{i}_{j}"] = m0.astype(np.int16)
+        out[f"matching_scores0_{i}_{j}"] = ref["matching_scores0"][0].numpy()
+    print(f"lund door config 1: {len(pairs)} pairs, {total} matches")
+    if write:
+        np.savez_compressed(
+            GOLDEN / "lund_door_config1.npz", names=np.array(names), gray=np.stack(grays), num_pairs=len(pairs),
+            max_resolution=LUND_DOOR_MAX_RESOLUTION, max_keypoints=LUND_DOOR_MAX_KEYPOINTS, **out,
+        )
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", action="store_true", help="(re)write tests/golden/*.npz")
+    ap.add_argument("--only-config1", action="store_true", help="only BASELINE config 1 (12 Lund-door frames, 66 SuperGlue pairs: ~15 min of CPU)")
+    ap.add_argument("--skip-config1", action="store_true", help="skip the 12-frame / 66-pair Lund-door run")
     ap.add_argument("--skip-bench-shapes", action="store_true", help="skip the 1024x1024 / N = 2048 / N = 5000 cases (minutes of CPU)")
     args = ap.parse_args()
     if not MODELS.exists():
         raise SystemExit(f"reference model files not found under {MODELS}")
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     GOLDEN.mkdir(parents=True, exist_ok=True)
+    if args.only_config1:
+        check_lund_door_config1(args.write)
+        print("OK")
+        return
     check_superpoint(args.write)
     check_superpoint_large(args.write)
     check_superglue(args.write)
     check_lund_door(args.write)
+    if not args.skip_config1 and not args.skip_bench_shapes:
+        check_lund_door_config1(args.write)
     if not args.skip_bench_shapes:
         check_superpoint_bench(args.write)
         check_superglue(args.write, bench=True)

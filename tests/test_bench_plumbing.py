@@ -37,6 +37,24 @@ def test_bench_self_launches_and_shards_a_scene_over_two_ranks():
     assert r["value"] > 0 and r["unit"] == "image-pairs/s"
 
 
+def test_bench_eight_ranks_scene_with_idle_ranks():
+    """The launch the driver makes on an 8-GPU node (`bench.py --gpus 8`, here self-launched on gloo with stand-in kernels): a small
+    scene on the 2 x 4 process grid leaves ranks without a pair -- they still take part in the feature all-gather and the ragged
+    match gather -- and every pair of the scene comes back exactly once."""
+    p, lines = _run_bench("--gpus", "8", "--mode", "scene", "--plumbing-only", "--images", "5", "--pairs", "7", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    r = json.loads(lines[0])
+    pairs = parallel.exhaustive_pairs(5)[:7]
+    parts = [parallel.partition_pairs_2d(pairs, rank, 8) for rank in range(8)]
+    idle = sum(1 for part in parts if not part)
+    assert idle >= 1 and sorted(q for part in parts for q in part) == sorted(pairs)
+    assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["plumbing_only"] is True
+    assert r["scene_check"] == {"pairs_gathered": 7, "pairs_of_the_scene": 7, "each_pair_exactly_once": True, "ranks_without_pairs": idle}
+    assert r["distributed"]["world_size"] == 8 and "all_gather (ragged match lists)" in r["distributed"]["collectives"]
+    assert r["config"]["pairs_per_gpu_per_step"] == len(parts[0])
+
+
 def test_bench_replica_mode_self_launch_weak_scaling():
     p, lines = _run_bench("--gpus", "2", "--plumbing-only", "--images", "5", "--pairs", "8", "--steps", "1", "--warmup", "0")
     assert p.returncode == 0, p.stderr[-2000:]

@@ -112,3 +112,38 @@ def test_matcher_cacher_round_trip_and_corrupted_entry(tmp_path):
     assert np.array_equal(cacher.match(**args), m) and FakeMatcher.calls == 1
     path.write_bytes(b"not a bz2 stream")  # io.py:444-448: a corrupted entry is dropped and recomputed
     assert np.array_equal(cacher.match(**args), m) and FakeMatcher.calls == 2 and path.exists()
+
+
+class _RaisesOnRebuild:
+    """Unpickles through ``__setstate__``, which fails with an AttributeError: a damaged / incompatible entry, NOT a foreign class."""
+
+    def __setstate__(self, state):
+        raise AttributeError("incompatible entry")
+
+
+def test_foreign_class_entry_is_kept_but_a_failing_rebuild_removes_the_file(tmp_path, caplog):
+    """gtsfm/utils/io.py:442-447 removes an entry that fails to load. The one exception here: an entry naming a class this
+    installation cannot import (``find_class`` fails) is valid for its writer -- kept, logged, reported as a miss. An
+    AttributeError / ImportError raised while an object is REBUILT is a damaged entry and goes the reference's way."""
+    import logging
+
+    # (1) a class that does not exist here: GLOBAL 'no_such_module_xyz NoSuchClass'
+    foreign = tmp_path / "foreign.pbz2"
+    with BZ2File(foreign, "wb") as f:
+        f.write(b"\x80\x04\x8c\x12no_such_module_xyz\x8c\x0bNoSuchClass\x93)\x81.")
+    with caplog.at_level(logging.WARNING, logger=cache_format.__name__):
+        assert cache_format.read_from_bz2_file(foreign) is None
+    assert foreign.exists() and any("cannot be imported" in r.message for r in caplog.records)
+    # (2) the class exists, rebuilding the object raises AttributeError: removed
+    damaged = tmp_path / "damaged.pbz2"
+    obj = _RaisesOnRebuild()
+    obj.x = 1
+    with BZ2File(damaged, "wb") as f:
+        pickle.dump(obj, f)
+    assert cache_format.read_from_bz2_file(damaged) is None
+    assert not damaged.exists()
+    # (3) an attribute that does not exist in an importable module is a find_class failure too: kept
+    missing_attr = tmp_path / "missing_attr.pbz2"
+    with BZ2File(missing_attr, "wb") as f:
+        f.write(b"\x80\x04\x8c\x05numpy\x8c\x10NoSuchNumpyThing\x93)\x81.")
+    assert cache_format.read_from_bz2_file(missing_attr) is None and missing_attr.exists()

@@ -219,10 +219,9 @@ def test_matcher_engine_lanes_host_logic(monkeypatch):
     monkeypatch.setattr(ME.torch.cuda, "stream", lambda s: contextlib.nullcontext())
     monkeypatch.setenv("GTSFM_PLUGIN_LANES", "2")
     eng = object.__new__(ME._MatcherBase)
-    eng.device, eng._workspace, eng._staging = None, None, None
-    eng._desc_cache, eng._desc_pinned, eng._pinning = OrderedDict(), set(), False
-    eng.weights = object()
-    eng._init_lanes()
+    eng.device, eng._lib, eng.weights, eng.num_layers = None, None, object(), 9
+    eng._init_host_state()
+    eng.some_per_call_attribute_added_later = []  # not in _SHARED_ATTRS: a lane must not inherit it (round 3 used copy.copy)
     assert eng.max_lanes == 2
     for _ in range(3):  # one caller: always the engine itself
         with eng._lane() as lane:
@@ -252,4 +251,27 @@ def test_matcher_engine_lanes_host_logic(monkeypatch):
     assert len(eng._lanes) == 2 and len(seen) == 2
     sibling = next(lane for lane in eng._lanes if lane is not eng)
     assert sibling.weights is eng.weights and sibling._desc_cache is not eng._desc_cache and sibling._workspace is None
+    assert not hasattr(sibling, "some_per_call_attribute_added_later") and sibling._root is eng
     assert eng._free_lanes.qsize() == 2
+    # release_lanes(): idle siblings go, the engine keeps serving
+    eng._workspace, eng._image_cache["k"] = object(), object()
+    eng.release_lanes()
+    assert eng._lanes == [eng] and eng._workspace is None and not eng._image_cache and eng._free_lanes.qsize() == 1
+    with eng._lane() as lane:
+        assert lane is eng
+
+
+def test_image_key_tells_arrays_apart():
+    """The per-call path's image cache key (matcher_engine._MatcherBase._image_key): same arrays -> same key; another buffer, another
+    image shape or changed sampled rows -> another key."""
+    from gtsfm_amd.runtime.matcher_engine import _MatcherBase
+
+    rng = np.random.default_rng(0)
+    k, d = rng.random((500, 2), dtype=np.float32), rng.random((500, 256), dtype=np.float32)
+    key = _MatcherBase._image_key((k, d), (480, 640))
+    assert key == _MatcherBase._image_key((k, d), (480, 640))
+    assert key != _MatcherBase._image_key((k, d), (640, 480))
+    assert key != _MatcherBase._image_key((k, d.copy()), (480, 640))
+    d[-1, 3] += 1.0  # in-place change of a sampled row
+    assert key != _MatcherBase._image_key((k, d), (480, 640))
+    assert _MatcherBase._image_key((k[:0], d[:0]), (8, 8))  # empty sets do not break it

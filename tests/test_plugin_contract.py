@@ -49,6 +49,17 @@ def test_superpoint_plugin_has_no_cpu_fallback(sp_weights):
             det.detect_and_describe(img)
 
 
+def test_strict_use_cuda_switch(monkeypatch):
+    """GTSFM_AMD_STRICT_USE_CUDA=1 turns ``use_cuda=False`` into an error before any device is touched (a caller
+    that uses the flag to keep a worker off the GPU must be able to rely on it)."""
+    from gtsfm_amd.frontend.registry import warn_if_cpu_requested
+
+    monkeypatch.setenv("GTSFM_AMD_STRICT_USE_CUDA", "1")
+    warn_if_cpu_requested(True, "SuperPointDetectorDescriptor")  # use_cuda=True: nothing to say
+    with pytest.raises(RuntimeError, match="STRICT_USE_CUDA"):
+        warn_if_cpu_requested(False, "SuperPointDetectorDescriptor")
+
+
 def test_keypoints_top_k_and_mask():
     coords = np.array([[1, 1], [2, 3], [5, 5], [7, 2]], dtype=np.float32)
     resp = np.array([0.1, 0.9, 0.5, 0.7], dtype=np.float32)
