@@ -6,10 +6,12 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input resident in HBM.
 
-``--mode replica`` (default; BASELINE config 3): every rank owns ``--images`` seeded 1024x1024 gray views, detects +
-describes them (SuperPoint) and matches the first ``--pairs`` exhaustive (i<j) pairs (``--matcher``) at the REFERENCE'S
-keypoint cap: ``max_keypoints = 5000`` (gtsfm/configs/deep_front_end.yaml:29; the synthetic views yield ~8 200 raw
-detections, so every image is matched at N = 5000). Weak scaling, no data-path collective (images and pairs are
+``--mode replica`` (default = BASELINE config 3 AS WRITTEN: SuperPoint+LightGlue, 46 synthetic 1024x1024 views, the first 1000 of their
+1035 exhaustive pairs): every rank owns ``--images`` seeded 1024x1024 gray views, detects + describes them (SuperPoint) and matches
+the first ``--pairs`` exhaustive (i<j) pairs (``--matcher``) at the REFERENCE'S keypoint cap: ``max_keypoints = 5000``
+(gtsfm/configs/deep_front_end.yaml:29; the synthetic views yield ~8 200 raw detections, so every image is matched at N = 5000).
+The other BASELINE configs ride in the same line under ``secondary``: config 2 (``config2_superpoint_480x640``) and one GPU's share
+of config 4 at the cap (``config4_scene_share_cap5000``), each with its own timed region and parity check. Weak scaling, no data-path collective (images and pairs are
 independent units); the packed weights are broadcast from rank 0 over RCCL. SURVEY.md section 8(d)'s
 "additionally reported" N = 2048 rate, SuperGlue with 20 / 100 Sinkhorn iterations, independent pairs and the per-call
 plugin API are timed in the same line under ``secondary``.
@@ -398,8 +400,8 @@ def parse_args(argv=None):
                          "sharded over the ranks (BASELINE config 4, strong scaling)")
     ap.add_argument("--images", type=int, default=None, help="images per step: per rank (replica, default: the fewest whose exhaustive pairs cover --pairs) or of the scene (default 101)")
     ap.add_argument("--pairs", type=int, default=None,
-                    help="exhaustive (i<j) pairs matched per step: per rank (replica, default 250 at the 5000-keypoint cap -- a ~2 s step -- and 1000 "
-                         "below 2500 keypoints) or of the scene (default 5000)")
+                    help="exhaustive (i<j) pairs matched per step: per rank (replica, default 1000 = BASELINE config 3 as written: the first 1000 of "
+                         "the 1035 exhaustive pairs of 46 views, an ~8.5 s step at the 5000-keypoint cap) or of the scene (default 5000)")
     ap.add_argument("--size", type=int, default=1024, help="square image side (overridden by --height / --width)")
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--width", type=int, default=0)
@@ -427,7 +429,7 @@ def parse_args(argv=None):
                          "and timing protocol can be exercised on CPU (gloo); the printed line is marked and is NOT a measurement")
     args = ap.parse_args(argv)
     scene = args.mode == "scene"
-    args.pairs = args.pairs if args.pairs is not None else (5000 if scene else (250 if args.keypoints > 2500 else 1000))
+    args.pairs = args.pairs if args.pairs is not None else (5000 if scene else 1000)  # BASELINE config 3: 1000 exhaustive pairs <=> 46 views
     if args.images is None:
         args.images = 101 if scene else fewest_images_for(args.pairs)
     if args.pair_chunk <= 0:
@@ -736,6 +738,9 @@ def main() -> None:
                     result["secondary"]["lightglue_adaptive_depth"] = leg("adaptive", adaptive_depth_rate, args, detector, device, images, pairs, shapes)
                 result["secondary"]["verifier_stage"] = leg("verifier", verifier_rate, pipe, feats, res, h, w, ms_per_step, device, not args.no_cpu_baseline)
                 result["secondary"]["plugin_api"] = leg("plugin_api", plugin_api_rate, args, pipe, views_np, device, h, w)
+                result["secondary"]["config2_superpoint_480x640"] = leg("config2", config2_superpoint_rate, lib, detector, device, not args.no_cpu_baseline)
+                if args.keypoints > 2500 and (h, w) == (1024, 1024):
+                    result["secondary"]["config4_scene_share_cap5000"] = leg("config4", config4_scene_share_rate, args, detector, device, h, w, not args.no_cpu_baseline)
             if world == 1 and not args.no_cpu_baseline:  # rank 0 at N = 1 only
                 first = all_pairs[0] if all_pairs else (0, min(1, len(views_np) - 1))
                 view_of = (lambda s: (5 * s) % args.images) if independent else (lambda s: s)  # noqa: E731
@@ -822,6 +827,9 @@ def verifier_rate(pipe, feats, res, h, w, ms_per_step, device, with_oracle: bool
     return out
 
 
+SIDE_LEG_PAIRS = 250  # pairs of the side legs that re-run the headline's pair list under another setting (its first 250 pairs = 23 views)
+
+
 def unshared_rate(args, detector, matcher, images, pairs, shapes, mk):
     """The headline workload with every pair running the matcher's full forward (the per-image first block NOT shared between
     the pairs of an image: what the reference's per-pair match() calls amount to), own timed region, for comparison."""
@@ -829,17 +837,12 @@ def unshared_rate(args, detector, matcher, images, pairs, shapes, mk):
 
     pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams,
                             use_graphs=bool(args.graphs), share_first_layer=False)
-    steps, warmup = 1, 1
-    for _ in range(warmup):
-        pipe.match(pipe.detect(images), pairs, shapes, **mk)
-    torch.cuda.synchronize(images.device)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        pipe.match(pipe.detect(images), pairs, shapes, **mk)
-    torch.cuda.synchronize(images.device)
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    return {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
-            "pairs_per_step": len(pairs), "workload": "the headline workload with --share-first-layer 0 (first matcher block once per pair side)"}
+    pairs = pairs[:SIDE_LEG_PAIRS]
+    images = images[: max(max(p) for p in pairs) + 1]
+    _, timing = _time_steps(lambda: pipe.match(pipe.detect(images), pairs, shapes, **mk), SECONDARY_STEPS, 1, images.device)
+    return {"value": round(len(pairs) / (timing["ms_per_step"] * 1e-3), 2), "unit": "image-pairs/s", **timing,
+            "pairs_per_step": len(pairs), "images_per_step": int(images.shape[0]),
+            "workload": f"the first {len(pairs)} pairs of the headline workload with --share-first-layer 0 (first matcher block once per pair side)"}
 
 
 def adaptive_depth_rate(args, detector, device, images, pairs, shapes):
@@ -854,22 +857,39 @@ def adaptive_depth_rate(args, detector, device, images, pairs, shapes):
     matcher = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(conf_bias=1.0, conf_gain=4.0), device)
     pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams,
                             use_graphs=bool(args.graphs), share_first_layer=bool(args.share_first_layer))
-    steps, warmup = 1, 1
-    for _ in range(warmup):
-        res = pipe.match(pipe.detect(images), pairs, shapes)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        res = pipe.match(pipe.detect(images), pairs, shapes)
-    torch.cuda.synchronize(device)
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    pairs = pairs[:SIDE_LEG_PAIRS]
+    images = images[: max(max(p) for p in pairs) + 1]
+    res, timing = _time_steps(lambda: pipe.match(pipe.detect(images), pairs, shapes), SECONDARY_STEPS, 1, device)
+    ms = timing["ms_per_step"]
     layers = torch.cat([r["stop"] for r in res]).float()
     kept = torch.cat([r["kept"] for r in res]).float()
     nm = int(sum(int((r["matches"] > -1).sum()) for r in res)) // 2
-    return {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+    return {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", **timing,
             "pairs_per_step": len(pairs), "matcher_layers_run": {"mean": round(float(layers.mean()), 2), "min": int(layers.min()), "max": int(layers.max())},
             "keypoints_alive_at_assignment": round(float(kept.mean()), 1), "matches_per_pair": round(nm / max(1, len(pairs)), 1),
-            "workload": "the headline workload with synthetic token-confidence heads that fire (conf_bias 1, conf_gain 4): adaptive depth / width on the device"}
+            "workload": f"the first {len(pairs)} pairs of the headline workload with synthetic token-confidence heads that fire (conf_bias 1, conf_gain 4): adaptive depth / width on the device"}
+
+
+SECONDARY_STEPS = 3  # timed steps of every secondary leg (each step bracketed by a device synchronisation; the MEDIAN is reported, min / max beside it)
+
+
+def _time_steps(step, steps: int, warmup: int, device):
+    """Run `step` warmup + steps times; every timed step is bracketed by torch.cuda.synchronize (a secondary leg is its own timed
+    region, and a step lasts 0.1 - 9 s, so the synchronisation costs nothing measurable). Returns (last result, timing dict): the
+    median step time decides the rate; min / max show the spread, so that a round-to-round change can be told from noise."""
+    out = None
+    for _ in range(warmup):
+        out = step()
+    times = []
+    for _ in range(steps):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        out = step()
+        torch.cuda.synchronize(device)
+        times.append((time.perf_counter() - t0) * 1e3)
+    med = float(np.median(times))
+    return out, {"ms_per_step": round(med, 3), "ms_per_step_min_max": [round(min(times), 3), round(max(times), 3)], "steps": steps, "warmup": warmup,
+                 "statistic": "median over the timed steps"}
 
 
 def _timed_pipeline(pipe, images, pairs, shapes, steps, warmup, device, mk):
@@ -877,17 +897,11 @@ def _timed_pipeline(pipe, images, pairs, shapes, steps, warmup, device, mk):
         feats = pipe.detect(images)
         return feats, pipe.match(feats, pairs, shapes, **mk)
 
-    for _ in range(warmup):
-        feats, res = step()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        feats, res = step()
-    torch.cuda.synchronize(device)
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    (feats, res), timing = _time_steps(step, steps, warmup, device)
+    ms = timing["ms_per_step"]
     kc = feats["count"].tolist()
     nm = int(sum(int((r["matches"] > -1).sum()) for r in res)) // 2
-    out = {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+    out = {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", **timing,
            "pairs_per_step": len(pairs), "images_per_step": int(images.shape[0]), "keypoints_per_image": [int(min(kc)), int(max(kc))],
            "matches_per_pair": round(nm / max(1, len(pairs)), 1)}
     return out, feats, res
@@ -918,7 +932,7 @@ def secondary_rates(args, detector, matcher, device, h, w, mk, with_oracle: bool
     # (1) the other keypoint counts SURVEY.md section 8(d) names: fixed N = 2048 and 1024 next to the cap of 5000 (the cap when the headline
     # was asked for another count)
     for other_k, other_pairs in (((2048, 1000), (1024, 1000)) if args.keypoints > 2500 else ((5000, 200),)):
-        r, *_ = exhaustive(matcher, other_k, other_pairs, 2000, 2, mk)
+        r, *_ = exhaustive(matcher, other_k, other_pairs, 2000, SECONDARY_STEPS, mk)
         note = {2048: " (SURVEY.md section 8d: additionally reported; round 2's headline)", 1024: " (SURVEY.md section 8d: additionally reported)", 5000: " (GTSfM's default cap)"}[other_k]
         out[f"exhaustive_top{other_k}"] = dict(r, workload=f"SuperPoint+{args.matcher}: {other_pairs} exhaustive pairs of {r['images_per_step']} synthetic {h}x{w} views, "
                                                             f"top-{other_k} keypoints per image" + note)
@@ -926,11 +940,11 @@ def secondary_rates(args, detector, matcher, device, h, w, mk, with_oracle: bool
     if args.matcher == "lightglue":
         sg = ME.SuperGlueEngine(synthetic.synthetic_superglue_state_dict(), device)
         for iters in (20, 100):
-            r, *_ = exhaustive(sg, args.keypoints, 100, 3000, 1, {"sinkhorn_iterations": iters})
+            r, *_ = exhaustive(sg, args.keypoints, 100, 3000, SECONDARY_STEPS, {"sinkhorn_iterations": iters})
             out[f"superglue_sinkhorn{iters}"] = dict(r, sinkhorn_iterations=iters, workload=(
                 f"SuperPoint+superglue, {iters} Sinkhorn iterations: 100 exhaustive pairs of {r['images_per_step']} synthetic {h}x{w} views, top-{args.keypoints} keypoints per image"))
         if args.keypoints != 2048:
-            r, feats, res, views_np, pairs = exhaustive(sg, 2048, 500, 3000, 1, {"sinkhorn_iterations": 100})
+            r, feats, res, views_np, pairs = exhaustive(sg, 2048, 500, 3000, SECONDARY_STEPS, {"sinkhorn_iterations": 100})
             entry = dict(r, sinkhorn_iterations=100, workload=f"SuperPoint+superglue, 100 Sinkhorn iterations: 500 exhaustive pairs of {r['images_per_step']} synthetic "
                                                               f"{h}x{w} views, top-2048 keypoints per image (round 2's BASELINE-config-4 figure)")
             if with_oracle:  # its own parity check: the oracle on the first pair of this leg
@@ -946,8 +960,94 @@ def secondary_rates(args, detector, matcher, device, h, w, mk, with_oracle: bool
     images = base[(5 * torch.arange(2 * p, device=device)) % 46].contiguous()
     pairs = [(2 * q, 2 * q + 1) for q in range(p)]
     pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=nstreams, use_graphs=graphs, share_first_layer=share)
-    r, *_ = _timed_pipeline(pipe, images, pairs, [(h, w)] * (2 * p), 1, 1, device, mk)
+    r, *_ = _timed_pipeline(pipe, images, pairs, [(h, w)] * (2 * p), SECONDARY_STEPS, 1, device, mk)
     out["independent_pairs"] = dict(r, workload=f"SuperPoint+{args.matcher}: {p} independent pairs = {2 * p} fresh detections of synthetic {h}x{w} views, top-{args.keypoints} keypoints per image")
+    return out
+
+
+def config2_superpoint_rate(lib, detector, device, with_oracle: bool):
+    """BASELINE config 2 exactly: SuperPoint only, 256 synthetic 640x480 gray images on one GPU, keypoints against the CPU oracle.
+    Own timed region; carries the conv stack's roofline at this shape and its own parity check (image 0 through the oracle)."""
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+
+    h, w, n, cap = 480, 640, 256, 5000
+    views_np = synthetic.synthetic_overlapping_views(n, h, w, 4000)
+    images = torch.from_numpy(views_np).to(device)
+    pipe = FrontEndPipeline(detector, None, max_keypoints=cap)
+    feats, timing = _time_steps(lambda: pipe.detect(images), SECONDARY_STEPS, 1, device)
+    ms = timing["ms_per_step"]
+    kc = np.asarray(feats["count"].tolist())
+    out = {"value": round(n / (ms * 1e-3), 1), "unit": "images/s", **timing, "images_per_step": n, "dtype": "f32",
+           "keypoints_per_image": {"min": int(kc.min()), "median": int(np.median(kc)), "max": int(kc.max())},
+           "tflops": round(superpoint_flops(h, w) * n / (ms * 1e-3) / 1e12, 2),
+           "workload": f"BASELINE config 2: SuperPoint detect+describe over {n} synthetic {w}x{h} gray uint8 images resident in HBM, batches of 16, top-{cap} keypoints kept on the device",
+           "roofline": measure_conv_roofline(lib, device, 16, h, w)}
+    if with_oracle:
+        base, ora = cpu_baseline(views_np[:1], "none", cap, 0)
+        out["cpu_baseline"] = base
+        out["parity_check"] = parity_check(ora, feats, [0], None)
+    return out
+
+
+def config4_scene_share_rate(args, detector, device, h, w, with_oracle: bool):
+    """BASELINE config 4 on the one GPU bench.py is given at N = 1: the HEAVIEST rank's share of the 8-rank job -- 101 views, the
+    first 5000 exhaustive pairs, SuperGlue with 100 Sinkhorn iterations, AT THE 5000-KEYPOINT CAP -- exactly as ``--mode scene --gpus 8``
+    assigns it (gtsfm_amd.parallel: cyclic image ownership, 2-D cyclic pair ownership on the 2 x 4 process grid). A timed step = this
+    rank's detections + its pairs matched from the scene's feature table; the rows of the table that the other seven ranks would
+    deliver through the all-gather are detected here beforehand, outside the timed region. With balanced ranks (the heaviest holds 3 %
+    more pairs than the mean) the 8-GPU job takes this step's time plus the all-gather (523 MB in total, MB-scale per xGMI link)."""
+    from gtsfm_amd import parallel
+    from gtsfm_amd.runtime import matcher_engine as ME
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+
+    n, world, scene_pairs, iters = 101, 8, 5000, 100
+    all_pairs = parallel.exhaustive_pairs(n)[:scene_pairs]
+    shares = [parallel.partition_pairs_2d(all_pairs, r, world) for r in range(world)]
+    rank = int(np.argmax([len(p) for p in shares]))
+    my_pairs, my_images = shares[rank], parallel.partition_images(n, rank, world)
+    touched = sorted(parallel.images_touched(my_pairs))
+    views_np = synthetic.synthetic_overlapping_views(n, h, w, 1000)
+    sg = ME.SuperGlueEngine(synthetic.synthetic_superglue_state_dict(), device)
+    pipe = FrontEndPipeline(detector, sg, max_keypoints=args.keypoints, pair_chunk=default_pair_chunk(args.keypoints), num_streams=args.streams,
+                            use_graphs=bool(args.graphs), share_first_layer=bool(args.share_first_layer))
+    k = args.keypoints
+    table = {"count": torch.zeros(n, dtype=torch.int32, device=device), "xy": torch.zeros((n, k, 2), device=device),
+             "scores": torch.zeros((n, k), device=device), "descriptors": torch.zeros((n, k, 256), device=device)}
+    others = [i for i in touched if i not in set(my_images)]
+    for c0 in range(0, len(others), 16):  # the all-gather's stand-in: the other ranks' rows of the table, untimed
+        idx = others[c0 : c0 + 16]
+        f = pipe.detect(torch.from_numpy(views_np[idx]).to(device))
+        ii = torch.tensor(idx, dtype=torch.long, device=device)
+        for key in table:
+            table[key][ii] = f[key]
+    own = torch.from_numpy(views_np[my_images]).to(device)
+    own_idx = torch.tensor(my_images, dtype=torch.long, device=device)
+    shapes = [(h, w)] * n
+
+    def step():
+        f = pipe.detect(own)
+        for key in table:
+            table[key][own_idx] = f[key]
+        return pipe.match(table, my_pairs, shapes, sinkhorn_iterations=iters)
+
+    res, timing = _time_steps(step, SECONDARY_STEPS, 1, device)
+    ms = timing["ms_per_step"]
+    nm = int(sum(int((r["matches"] > -1).sum()) for r in res)) // 2
+    kc = table["count"][torch.tensor(touched, device=device)].tolist()
+    out = {"value": round(len(my_pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", **timing, "dtype": "f32",
+           "pairs_per_step": len(my_pairs), "images_detected_per_step": len(my_images), "images_touched": len(touched), "rank": rank,
+           "pairs_by_rank": [len(p) for p in shares], "sinkhorn_iterations": iters, "keypoints_per_image": [int(min(kc)), int(max(kc))],
+           "matches_per_pair": round(nm / max(1, len(my_pairs)), 1),
+           "scene_pairs_per_s_if_8_ranks_take_this_long": round(scene_pairs / (ms * 1e-3), 1),
+           "workload": (f"BASELINE config 4, one GPU's share: rank {rank} (the heaviest) of 8 on the 2x4 process grid of `--mode scene`: {len(my_images)} of {n} synthetic {h}x{w} views "
+                        f"detected + {len(my_pairs)} of the scene's {scene_pairs} exhaustive pairs matched per step, SuperPoint+superglue, {iters} Sinkhorn iterations, top-{k} keypoints "
+                        "per image; the other ranks' feature rows are resident before the timed region (the all-gather's stand-in)")}
+    if with_oracle:  # its own parity check: the oracle on the first pair of this share (~20 s of CPU at the cap)
+        i, j = res[0]["pairs"][0]
+        base, ora = cpu_baseline(np.stack([views_np[i], views_np[j]]), "superglue", k, iters)
+        a = res[0]["n0"][0]
+        out["cpu_baseline"] = base
+        out["parity_check"] = parity_check(ora, table, [i, j], (res[0]["matches"][:a].cpu().numpy(), res[0]["mscores"][:a].cpu().numpy()))
     return out
 
 

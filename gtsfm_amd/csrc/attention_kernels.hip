@@ -565,6 +565,364 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(AttnParams p) {
     *reinterpret_cast<f32x4*>(p.out + row * p.ldo + h * 64 + c * 4) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Opt-in arithmetic (GTSFM_ATTENTION_MATH=bf16x3, AttnParams::math = 1): the two products of attention, S^T = K Q^T and
+// O^T += V^T P^T, on v_mfma_f32_32x32x16_bf16 with every fp32 operand split into THREE bf16 pieces and fp32 accumulation.
+//
+//   x = hi + mid + lo EXACTLY: hi = x truncated to its top 8 significant bits (a bf16), mid = (x - hi) truncated, lo = the rest
+//   (8 + 8 + 8 = the 24 bits of an fp32 significand; bf16 shares fp32's exponent range). A product x y is then the sum of nine
+//   bf16 x bf16 products, each EXACT in fp32; six of them are executed -- hi hi, hi mid, mid hi, mid mid, hi lo, lo hi -- and the
+//   three dropped ones (mid lo, lo mid: 2^-24 |x y| each; lo lo: 2^-32) are below one fp32 rounding of the product. The sums
+//   accumulate in fp32 inside the MFMA. So every score and every output element carries fp32-class error (the same 2^-24-per-term
+//   class as the fmaf chain of v_mfma_f32_32x32x2_f32), but NOT the same bits: this mode is not bit-identical to the exact-fp32
+//   kernel above, which stays the default and the one every parity statement is made with.
+//   Cost: 6 bf16 MFMAs of 32 cycles (32x32x16) replace 8 fp32 MFMAs of 64 cycles (32x32x2 x 8 k) per 32 x 32 x 16 block: 3/8.
+//
+// Layout. K and V are split ONCE per launch by attention_x3_split_kernel into tiles of 64 keys that the main kernel moves into
+// LDS by DMA exactly as they lie: per (tensor, piece, head, problem, key tile) 64 rows x 64 bf16 = 8 KiB.
+//   K tile:   row = key, columns = channels                      (A operand of S^T = K Q^T: lane (key, kh) reads 8 channels = 16 B)
+//   V^T tile: row = channel d, columns = key SLOTS               (A operand of O^T += V^T P^T: lane (d, kh) reads 8 slots = 16 B)
+// A slot is the position a key has in the B operand P^T that the S^T accumulators form WITHOUT any data movement: accumulator
+// register r of key block T holds key 32 T + (r & 3) + 8 (r >> 2) + 4 kh; registers 8 c .. 8 c + 7 of block T, converted and
+// packed in pairs, are the B operand of k-step s = 2 T + c, whose lane half kh supplies k = 8 kh .. 8 kh + 7. Hence
+//   slot 16 s + 8 kh + i  <->  key 32 (s >> 1) + 16 (s & 1) + 4 kh + (i & 3) + 8 (i >> 2),
+// the permutation the split kernel applies when it transposes V. In LDS the 16-byte chunks of a row (128 B) are XOR-swizzled by
+// (row >> 1) & 7: the 16 lanes of a ds_read_b128 group read 16 consecutive rows at one logical chunk -> 16 distinct (bank group,
+// chunk) positions, conflict-free; the DMA applies the swizzle on the global side (lane-linear LDS image).
+// Keys beyond a problem's count are written as zeros by the split kernel (their scores are masked to -inf, P = 0 meets V = 0).
+// ---------------------------------------------------------------------------------------------------------------------
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define X3_PIECE_BYTES 8192               // one bf16 piece of a 64 x 64 tile
+#define X3_TILE_BYTES (3 * X3_PIECE_BYTES)  // hi | mid | lo
+#define X3_LDS_BYTES (2 * X3_TILE_BYTES)    // K tile + V^T tile, single-buffered
+
+struct X3Split {
+    unsigned hi, mid, lo;  // fp32 bit patterns whose top 16 bits are the bf16 pieces
+};
+__device__ __forceinline__ X3Split x3_split(float x) {
+    X3Split r;
+    r.hi = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(r.hi);  // exact
+    r.mid = __float_as_uint(r1) & 0xffff0000u;
+    r.lo = __float_as_uint(r1 - __uint_as_float(r.mid));  // exact; truncated to 8 bits when packed
+    return r;
+}
+// two bf16 (the top halves of a and b) in one register, a in the low half
+__device__ __forceinline__ unsigned x3_pack(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__device__ __forceinline__ bf16x8 x3_frag(const u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f32x16 x3_mfma(const u32x4 a, const u32x4 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_frag(a), x3_frag(b), c, 0, 0, 0);
+}
+// acc += A B with A = ah + am + al, B = bh + bm + bl: the six products, smallest first
+__device__ __forceinline__ void x3_product(f32x16& acc0, f32x16& acc1, const u32x4 (&a0)[3], const u32x4 (&a1)[3], const u32x4 (&b)[3]) {
+    acc0 = x3_mfma(a0[2], b[0], acc0), acc1 = x3_mfma(a1[2], b[0], acc1);  // lo hi
+    acc0 = x3_mfma(a0[0], b[2], acc0), acc1 = x3_mfma(a1[0], b[2], acc1);  // hi lo
+    acc0 = x3_mfma(a0[1], b[1], acc0), acc1 = x3_mfma(a1[1], b[1], acc1);  // mid mid
+    acc0 = x3_mfma(a0[1], b[0], acc0), acc1 = x3_mfma(a1[1], b[0], acc1);  // mid hi
+    acc0 = x3_mfma(a0[0], b[1], acc0), acc1 = x3_mfma(a1[0], b[1], acc1);  // hi mid
+    acc0 = x3_mfma(a0[0], b[0], acc0), acc1 = x3_mfma(a1[0], b[0], acc1);  // hi hi
+}
+
+// Byte offset of tile (tensor ten = 0: K, 1: V^T; piece; head h; problem g; key tile t) in the split buffer.
+__device__ __forceinline__ size_t x3_tile_offset(const AttnParams& p, int ten, int piece, int h, int g, int t) {
+    return ((((size_t)(ten * 3 + piece) * p.heads + h) * p.nproblems + g) * p.x3_tiles + t) * X3_PIECE_BYTES;
+}
+
+// grid (key tiles, problems, heads), 256 threads: one 64-key tile of K and of V of one head -> three bf16 pieces each.
+__global__ __launch_bounds__(256) void attention_x3_split_kernel(AttnParams p) {
+    __shared__ float vt[64 * 65];
+    const int t = blockIdx.x, g = blockIdx.y, h = blockIdx.z;
+    const AttnProblem pr = p.problems[g];
+    const int nk = p.counts[pr.k_cnt_idx];
+    if (t * AT_KT >= nk) return;
+    const int valid = nk - t * AT_KT;  // rows of this tile that are keys (>= 64: all)
+    const int tid = threadIdx.x;
+    unsigned char* xb = reinterpret_cast<unsigned char*>(p.x3);
+    {   // K: thread = (key row, 16 channels)
+        const int r = tid >> 2, c0 = (tid & 3) * 16;
+        const float* src = p.k + (size_t)(pr.k_off + t * AT_KT + (r < valid ? r : 0)) * p.ldk + h * 64 + c0;
+        unsigned hi[16], mid[16], lo[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q4);
+            if (r >= valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const X3Split sp = x3_split(v[e]);
+                hi[4 * q4 + e] = sp.hi, mid[4 * q4 + e] = sp.mid, lo[4 * q4 + e] = sp.lo;
+            }
+        }
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) {
+            const unsigned* w = piece == 0 ? hi : piece == 1 ? mid : lo;
+            unsigned char* dst = xb + x3_tile_offset(p, 0, piece, h, g, t) + r * 128 + c0 * 2;
+            *reinterpret_cast<u32x4*>(dst) = u32x4{x3_pack(w[0], w[1]), x3_pack(w[2], w[3]), x3_pack(w[4], w[5]), x3_pack(w[6], w[7])};
+            *reinterpret_cast<u32x4*>(dst + 16) = u32x4{x3_pack(w[8], w[9]), x3_pack(w[10], w[11]), x3_pack(w[12], w[13]), x3_pack(w[14], w[15])};
+        }
+    }
+    {   // V: through LDS (rows = keys, padded), then thread = (channel d, two slot octets): the transposed, slot-permuted tile
+        const int r = tid >> 2, c0 = (tid & 3) * 16;
+        const float* src = p.v + (size_t)(pr.k_off + t * AT_KT + (r < valid ? r : 0)) * p.ldv + h * 64 + c0;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q4);
+            if (r >= valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vt[r * 65 + c0 + 4 * q4 + e] = v[e];
+        }
+        __syncthreads();
+        const int d = tid & 63;
+#pragma unroll
+        for (int oo = 0; oo < 2; ++oo) {
+            const int oct = (tid >> 6) * 2 + oo;  // slots 8 oct .. 8 oct + 7 = k-step s = oct >> 1, lane half kh = oct & 1
+            const int s = oct >> 1, kh = oct & 1;
+            unsigned hi[8], mid[8], lo[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int key = 32 * (s >> 1) + 16 * (s & 1) + 4 * kh + (i & 3) + 8 * (i >> 2);
+                const X3Split sp = x3_split(vt[key * 65 + d]);
+                hi[i] = sp.hi, mid[i] = sp.mid, lo[i] = sp.lo;
+            }
+#pragma unroll
+            for (int piece = 0; piece < 3; ++piece) {
+                const unsigned* w = piece == 0 ? hi : piece == 1 ? mid : lo;
+                unsigned char* dst = xb + x3_tile_offset(p, 1, piece, h, g, t) + d * 128 + oct * 16;
+                *reinterpret_cast<u32x4*>(dst) = u32x4{x3_pack(w[0], w[1]), x3_pack(w[2], w[3]), x3_pack(w[4], w[5]), x3_pack(w[6], w[7])};
+            }
+        }
+    }
+}
+
+// The attention kernel on the split tiles: same problem / segment / schedule structure as attention_dma_kernel (128 queries of one
+// head per workgroup of 4 waves, a wave owns 32 queries, 64-key tiles, 1024-key segments merged by at_merge, fused or split
+// schedule), ONE transposed score tile per wave. Per tile and wave: 48 + 48 v_mfma_f32_32x32x16_bf16. The fused schedule parks its
+// merged state in the caller's workspace (48 KiB of LDS tiles + a 34 KiB LDS slab would leave one workgroup per CU).
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
+    constexpr int NT = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_x3[];
+    unsigned char* Kl = lds_x3;
+    unsigned char* Vl = lds_x3 + X3_TILE_BYTES;
+    const int b = blockIdx.x;
+    const int groups = p.heads * p.nproblems;
+    const int k_in_xcd = b >> 3;
+    const int per_group = SPLIT ? p.qtiles * p.nseg : p.qtiles;
+    const int g = (k_in_xcd / per_group) * 8 + (b & 7);
+    if (g >= groups) return;
+    const int within = k_in_xcd % per_group;
+    const int seg_of_wg = SPLIT ? within / p.qtiles : 0;
+    const int h = g % p.heads, prob = g / p.heads;
+    const AttnProblem pr = p.problems[prob];
+    const int nq = p.counts[pr.q_cnt_idx], nk = p.counts[pr.k_cnt_idx];
+    const int q0 = (SPLIT ? within % p.qtiles : within) * AT_QB;
+    if (q0 >= nq) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kh = lane >> 5;
+    const int qrow = q0 + wave * 32 + j;
+    const bool qvalid = qrow < nq;
+    const int ntiles = (nk + AT_KT - 1) / AT_KT;
+    const int t_begin = SPLIT ? seg_of_wg * AT_SEG_TILES : 0;
+    const int t_end = SPLIT ? (ntiles < t_begin + AT_SEG_TILES ? ntiles : t_begin + AT_SEG_TILES) : ntiles;
+    if (SPLIT && t_begin >= ntiles) return;
+    float* Oc = p.park + (size_t)blockIdx.x * (34 * NT);  // fused schedule, more than one segment: this thread's merged (O, m, l)
+    if (!SPLIT && !p.park && ntiles > AT_SEG_TILES) __builtin_trap();
+
+    if (!SPLIT && nk <= 0) {  // no keys: the output rows are zero; uniform for the workgroup
+        if (qvalid) {
+            float* op = p.out + (size_t)(pr.q_off + qrow) * p.ldo + h * 64 + kh * 32;
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(op + 4 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+
+    // Q^T fragment (B operand of S^T = K Q^T): lane (q = j, kh), k-step u: channels 16 u + 8 kh .. + 7, pre-scaled by scale * log2(e)
+    u32x4 qf[4][3];
+    {
+        const float* qp = p.q + (size_t)(pr.q_off + (qvalid ? qrow : 0)) * p.ldq + h * 64 + kh * 8;
+        const float scale2 = p.scale * 1.44269504088896340736f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned hi[8], mid[8], lo[8];
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(qp + 16 * u + 4 * q4);
+                if (!qvalid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const X3Split sp = x3_split(v[e] * scale2);
+                    hi[4 * q4 + e] = sp.hi, mid[4 * q4 + e] = sp.mid, lo[4 * q4 + e] = sp.lo;
+                }
+            }
+            qf[u][0] = u32x4{x3_pack(hi[0], hi[1]), x3_pack(hi[2], hi[3]), x3_pack(hi[4], hi[5]), x3_pack(hi[6], hi[7])};
+            qf[u][1] = u32x4{x3_pack(mid[0], mid[1]), x3_pack(mid[2], mid[3]), x3_pack(mid[4], mid[5]), x3_pack(mid[6], mid[7])};
+            qf[u][2] = u32x4{x3_pack(lo[0], lo[1]), x3_pack(lo[2], lo[3]), x3_pack(lo[4], lo[5]), x3_pack(lo[6], lo[7])};
+        }
+    }
+
+    // DMA of one tile of one tensor: 24 pieces of 1 KiB (3 bf16 pieces x 8 x [8 rows x 128 B]); wave w moves pieces w, w + 4, ..:
+    // their first row is 8 (w + 4 i) -> ((row >> 1) & 7) = ((lane >> 4) + 4 w) & 7 for all six: one swizzled source offset per lane.
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x3);
+    const int dma_src = ((lane >> 3) * 128) + ((((lane & 7) ^ (((lane >> 4) + 4 * wave) & 7))) << 4);
+    auto tile_dma = [&](int ten, int t, unsigned char* dst) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int pc = wave + 4 * i, piece = pc >> 3, pp = pc & 7;
+            const unsigned char* src = xb + x3_tile_offset(p, ten, piece, h, prob, t) + pp * 1024 + dma_src;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(src), reinterpret_cast<unsigned*>(dst + piece * X3_PIECE_BYTES + pp * 1024), 16, 0, 0);
+        }
+    };
+    // A-operand reads: lane (row = j [+ 32], kh), k-step u -> logical chunk 2 u + kh of its row, swizzled by (row >> 1) & 7 (equal for j and j + 32)
+    int frag_off[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) frag_off[u] = j * 128 + (((2 * u + kh) ^ ((j >> 1) & 7)) << 4);
+    auto frag = [&](const unsigned char* tile, int piece, int blk, int u) {
+        return *reinterpret_cast<const u32x4*>(tile + piece * X3_PIECE_BYTES + blk * 4096 + frag_off[u]);
+    };
+
+    f32x16 o0, o1;  // O^T of the current segment: rows d 0..31 / 32..63, column q
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    float m = 0.f, l = 0.f;
+
+    tile_dma(0, t_begin, Kl);
+    tile_dma(1, t_begin, Vl);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int k0 = t * AT_KT;
+        const int ts = t % AT_SEG_TILES;
+        const bool more = t + 1 < t_end;
+        // ---- S^T = K Q^T - m
+        f32x16 s0, s1;
+        {
+            const float neg_m = -m;  // 0 at the start of a segment
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s0[r] = s1[r] = neg_m;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            u32x4 a0[3], a1[3];
+#pragma unroll
+            for (int piece = 0; piece < 3; ++piece) a0[piece] = frag(Kl, piece, 0, u), a1[piece] = frag(Kl, piece, 1, u);
+            x3_product(s0, s1, a0, a1, qf[u]);
+        }
+        if (!more && k0 + AT_KT > nk) {  // only the last tile of the keys can be partial
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (key >= nk) s0[r] = -__builtin_inff();
+                if (key + 32 >= nk) s1[r] = -__builtin_inff();
+            }
+        }
+        // ---- online softmax with a lazy reference maximum (as in attention_dma_kernel)
+        float mloc = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
+        mloc = at_halves_max(mloc);
+        const bool rebase = (ts == 0) || (mloc > AT_REBASE);
+        if (__any(rebase)) {
+            const float d = rebase ? mloc : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s0[r] -= d, s1[r] -= d;
+            if (ts > 0) {
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                l *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o0[r] *= alpha, o1[r] *= alpha;
+            }
+            m += d;
+        }
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+            lsum += s0[r] + s1[r];
+        }
+        l += at_halves_sum(lsum);
+        // B1: every wave is done with K(t) and V(t) has landed (own pieces: vmcnt, the others': the barrier) -> the K buffer takes
+        // tile t + 1, which has the whole P V phase to land
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (more) tile_dma(0, t + 1, Kl);
+        // ---- O^T += V^T P^T: k-step s = 2 T + c takes registers 8 c .. 8 c + 7 of score block T, split into three bf16 pieces on the fly
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4 pb[3];
+            {
+                unsigned hi[8], mid[8], lo[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const X3Split sp = x3_split((s >> 1) ? s1[8 * (s & 1) + i] : s0[8 * (s & 1) + i]);
+                    hi[i] = sp.hi, mid[i] = sp.mid, lo[i] = sp.lo;
+                }
+                pb[0] = u32x4{x3_pack(hi[0], hi[1]), x3_pack(hi[2], hi[3]), x3_pack(hi[4], hi[5]), x3_pack(hi[6], hi[7])};
+                pb[1] = u32x4{x3_pack(mid[0], mid[1]), x3_pack(mid[2], mid[3]), x3_pack(mid[4], mid[5]), x3_pack(mid[6], mid[7])};
+                pb[2] = u32x4{x3_pack(lo[0], lo[1]), x3_pack(lo[2], lo[3]), x3_pack(lo[4], lo[5]), x3_pack(lo[6], lo[7])};
+            }
+            u32x4 a0[3], a1[3];
+#pragma unroll
+            for (int piece = 0; piece < 3; ++piece) a0[piece] = frag(Vl, piece, 0, s), a1[piece] = frag(Vl, piece, 1, s);
+            x3_product(o0, o1, a0, a1, pb);
+        }
+        // B2: every wave is done with V(t), K(t + 1) has landed -> the V buffer takes tile t + 1 (it lands under the next S phase + softmax)
+        if (more) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+            tile_dma(1, t + 1, Vl);
+        }
+        // ---- fused schedule, end of a segment: fold (O, m, l) into the merged state parked in the workspace
+        const bool seg_end = more && ts == AT_SEG_TILES - 1;
+        if (!SPLIT && (seg_end || (!more && t >= AT_SEG_TILES))) {
+            if (t >= AT_SEG_TILES) {
+                const AtMergeWeights w = at_merge_weights(Oc[32 * NT + tid], m);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o0[r] = at_merge(Oc[r * NT + tid], o0[r], w);
+                    o1[r] = at_merge(Oc[(16 + r) * NT + tid], o1[r], w);
+                }
+                l = at_merge(Oc[33 * NT + tid], l, w);
+                m = w.m;
+            }
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    Oc[r * NT + tid] = o0[r];
+                    Oc[(16 + r) * NT + tid] = o1[r];
+                    o0[r] = o1[r] = 0.f;
+                }
+                Oc[32 * NT + tid] = m;
+                Oc[33 * NT + tid] = l;
+                m = 0.f, l = 0.f;
+            }
+        }
+    }
+    if (!qvalid) return;
+    if (SPLIT) {
+        const size_t row = (size_t)seg_of_wg * p.part_rows + pr.q_off + qrow;
+        float* po = p.part_o + row * (p.heads * 64) + h * 64 + kh * 4;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            *reinterpret_cast<f32x4*>(po + 8 * gq) = f32x4{o0[4 * gq], o0[4 * gq + 1], o0[4 * gq + 2], o0[4 * gq + 3]};
+            *reinterpret_cast<f32x4*>(po + 32 + 8 * gq) = f32x4{o1[4 * gq], o1[4 * gq + 1], o1[4 * gq + 2], o1[4 * gq + 3]};
+        }
+        if (kh == 0) *reinterpret_cast<float2*>(p.part_ml + (row * p.heads + h) * 2) = float2{m, l};
+        return;
+    }
+    const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+    float* op = p.out + (size_t)(pr.q_off + qrow) * p.ldo + h * 64 + kh * 4;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        *reinterpret_cast<f32x4*>(op + 8 * gq) = f32x4{o0[4 * gq] * inv, o0[4 * gq + 1] * inv, o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv};
+        *reinterpret_cast<f32x4*>(op + 32 + 8 * gq) = f32x4{o1[4 * gq] * inv, o1[4 * gq + 1] * inv, o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv};
+    }
+}
+
 static int at_segments(int max_k) { return ceil_div(ceil_div(max_k < 1 ? 1 : max_k, AT_KT), AT_SEG_TILES); }
 int attention_segments(int max_k) { return at_segments(max_k); }
 
@@ -590,20 +948,80 @@ static int at_fused_waves() {  // GTSFM_ATTENTION_WAVES = 4 | 8 (read per launch
 }
 static int at_fused_grid(int nproblems, int heads, int max_q) { return ceil_div(heads * nproblems, 8) * 8 * ceil_div(max_q, 32 * at_fused_waves()); }
 
+int attention_math_from_env() {  // read per call: GTSFM_ATTENTION_MATH = "bf16x3" selects the split-bf16 products, anything else exact fp32
+    const char* env = getenv("GTSFM_ATTENTION_MATH");
+    return (env && env[0] == 'b') ? ATTN_MATH_BF16X3 : ATTN_MATH_F32;
+}
+
+static size_t x3_split_floats(int nproblems, int heads, int max_k) {  // K and V^T, three bf16 pieces each, whole 64-key tiles
+    return (size_t)6 * heads * nproblems * ceil_div(max_k < 1 ? 1 : max_k, AT_KT) * (X3_PIECE_BYTES / sizeof(float));
+}
+
 // Sized from the launch GEOMETRY, never from GTSFM_ATTENTION_SPLIT: a workspace is held across calls (the pipeline's per-stream
 // workspaces, captured graphs, callers' own) while the switch is read per launch. A launch that wants the split schedule and finds
 // the workspace too small (the switch was turned on after sizing) runs the fused schedule instead -- the two are bit-identical.
-size_t attention_workspace_floats(int nproblems, int heads, int max_q, int max_k, size_t rows) {
-    if (nproblems <= 0 || at_segments(max_k) < 2) return 0;  // one segment: neither schedule needs memory
+// The arithmetic mode is the caller's statement (it changes results): bf16x3 adds the split K / V^T tiles and always parks the fused
+// schedule's merged state in the workspace.
+size_t attention_workspace_floats(int nproblems, int heads, int max_q, int max_k, size_t rows, int math) {
+    if (nproblems <= 0) return 0;
+    const bool x3 = math == ATTN_MATH_BF16X3;
+    const size_t base = x3 ? x3_split_floats(nproblems, heads, max_k) : 0;
+    if (at_segments(max_k) < 2) return base;  // one segment: neither schedule needs memory
     const size_t split = (size_t)at_segments(max_k) * rows * ((size_t)heads * 64 + (size_t)heads * 2);
-    const size_t park = ATD_PARK_GLOBAL ? (size_t)at_fused_grid(nproblems, heads, max_q) * (ATD_OC_FLOATS / 4 * at_fused_waves()) : 0;  // single buffers: parked in LDS
-    return at_geometry_wants_split(nproblems, heads, max_q, max_k) ? (split > park ? split : park) : park;
+    const size_t park = x3 ? (size_t)ceil_div(heads * nproblems, 8) * 8 * ceil_div(max_q, AT_QB) * ATD_OC_FLOATS  // bf16x3: 4 waves, always in the workspace
+                           : (ATD_PARK_GLOBAL ? (size_t)at_fused_grid(nproblems, heads, max_q) * (ATD_OC_FLOATS / 4 * at_fused_waves()) : 0);  // exact fp32, single buffers: parked in LDS
+    return base + (at_geometry_wants_split(nproblems, heads, max_q, max_k) ? (split > park ? split : park) : park);
+}
+
+static int launch_attention_x3(const AttnParams& p, int nproblems, int max_q, hipStream_t stream) {
+    AttnParams q = p;
+    const int max_k = p.max_k > 0 ? p.max_k : max_q;
+    GTSFM_CHECK_ARG(p.max_k > 0, "attention (bf16x3): the caller must state the largest key count");
+    q.qtiles = ceil_div(max_q, AT_QB);
+    q.nproblems = nproblems;
+    q.x3_tiles = ceil_div(max_k, AT_KT);
+    const size_t x3_floats = x3_split_floats(nproblems, p.heads, max_k);
+    GTSFM_CHECK_ARG(p.workspace && p.workspace_floats >= x3_floats, "attention (bf16x3): workspace too small for the split K / V tiles (%zu < %zu floats)",
+                    p.workspace_floats, x3_floats);
+    q.x3 = p.workspace;
+    float* rest = p.workspace + x3_floats;
+    const size_t rest_floats = p.workspace_floats - x3_floats;
+    hipLaunchKernelGGL(attention_x3_split_kernel, dim3(q.x3_tiles, nproblems, p.heads), dim3(256), 0, stream, q);
+    const int groups = p.heads * nproblems;
+    const int nseg = at_segments(max_k);
+    const size_t need_split = (size_t)nseg * p.part_rows * ((size_t)p.heads * 64 + (size_t)p.heads * 2);
+    bool split = p.force_split > 0 || (p.force_split == 0 && at_wants_split(nproblems, p.heads, max_q, max_k));
+    if (nseg < 2) split = false;
+    if (split && p.force_split <= 0 && (p.part_rows == 0 || rest_floats < need_split)) split = false;
+    q.park = nullptr, q.lds_has_oc = 0;
+    if (split) {
+        q.nseg = nseg;
+        GTSFM_CHECK_ARG(p.part_rows > 0 && rest_floats >= need_split, "attention (bf16x3): workspace too small for the split schedule (%zu < %zu floats)", rest_floats, need_split);
+        q.part_o = rest;
+        q.part_ml = rest + (size_t)nseg * p.part_rows * p.heads * 64;
+        dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles * q.nseg);
+        hipLaunchKernelGGL((attention_x3_kernel<true>), grid, dim3(256), X3_LDS_BYTES, stream, q);
+        hipLaunchKernelGGL(attention_combine_kernel, dim3(ceil_div(max_q, 4), nproblems), dim3(256), 0, stream, q);
+    } else {
+        q.nseg = 1;
+        dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles);
+        if (nseg > 1) {
+            const size_t need_park = (size_t)grid.x * (ATD_OC_FLOATS);
+            GTSFM_CHECK_ARG(rest_floats >= need_park, "attention (bf16x3): workspace too small for the merged states of the fused schedule (%zu < %zu floats)", rest_floats, need_park);
+            q.park = rest;
+        }
+        hipLaunchKernelGGL((attention_x3_kernel<false>), grid, dim3(256), X3_LDS_BYTES, stream, q);
+    }
+    GTSFM_CHECK_LAUNCH("attention kernel (bf16x3)");
+    return GTSFM_OK;
 }
 
 int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t stream) {
     GTSFM_CHECK_ARG(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, "attention: leading dimensions must be multiples of 4");
     GTSFM_CHECK_ARG(p.heads > 0 && p.heads <= 4, "attention: 1 to 4 heads");
+    GTSFM_CHECK_ARG(p.math == ATTN_MATH_F32 || p.math == ATTN_MATH_BF16X3, "attention: math is 0 (exact fp32) or 1 (bf16x3)");
     if (nproblems <= 0 || max_q <= 0) return GTSFM_OK;
+    if (p.math == ATTN_MATH_BF16X3) return launch_attention_x3(p, nproblems, max_q, stream);
     AttnParams q = p;
     q.qtiles = ceil_div(max_q, AT_QB);
     q.nproblems = nproblems;

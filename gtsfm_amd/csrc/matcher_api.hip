@@ -216,12 +216,30 @@ extern "C" size_t gtsfm_attention_split_workspace_bytes(int nproblems, int max_q
 extern "C" int gtsfm_attention_split_f32(const float* q_dev, int ldq, const float* k_dev, int ldk, const float* v_dev, int ldv, float* out_dev,
                                          int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems, int max_q, int max_k,
                                          int heads, float scale, int mode, size_t rows, void* workspace_dev, size_t workspace_bytes, void* stream) {
+    return gtsfm_attention_math_f32(q_dev, ldq, k_dev, ldk, v_dev, ldv, out_dev, ldo, problems_dev, counts_dev, nproblems, max_q, max_k, heads, scale, mode,
+                                    0, rows, workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" size_t gtsfm_attention_math_workspace_bytes(int nproblems, int max_q, int max_k, int heads, size_t rows, int math) {
+    // either schedule of the chosen arithmetic: the larger of the split schedule's partial states and the fused schedule's parking space,
+    // plus (bf16x3) the split K / V^T tiles
+    if (math != ATTN_MATH_BF16X3) return gtsfm_attention_split_workspace_bytes(nproblems, max_q, max_k, heads, rows);
+    const size_t key_tiles = (size_t)((max_k < 1 ? 1 : max_k) + 63) / 64;
+    const size_t tiles = (size_t)6 * heads * nproblems * key_tiles * 8192;
+    return tiles + gtsfm_attention_split_workspace_bytes(nproblems, max_q, max_k, heads, rows);
+}
+
+extern "C" int gtsfm_attention_math_f32(const float* q_dev, int ldq, const float* k_dev, int ldk, const float* v_dev, int ldv, float* out_dev,
+                                        int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems, int max_q, int max_k,
+                                        int heads, float scale, int mode, int math, size_t rows, void* workspace_dev, size_t workspace_bytes, void* stream) {
     GTSFM_CHECK_ARG(q_dev && k_dev && v_dev && out_dev && problems_dev && counts_dev, "attention: null pointer");
     GTSFM_CHECK_ARG(mode >= -1 && mode <= 1, "attention: mode is -1 (fused), 0 (by launch geometry) or 1 (split)");
+    GTSFM_CHECK_ARG(math == 0 || math == 1, "attention: math is 0 (exact fp32) or 1 (bf16x3)");
     AttnParams p = {};
     p.q = q_dev, p.ldq = ldq, p.k = k_dev, p.ldk = ldk, p.v = v_dev, p.ldv = ldv, p.out = out_dev, p.ldo = ldo;
     p.problems = (const AttnProblem*)problems_dev, p.counts = counts_dev, p.scale = scale, p.heads = heads;
     p.max_k = max_k, p.force_split = mode, p.workspace = (float*)workspace_dev, p.workspace_floats = workspace_bytes / sizeof(float), p.part_rows = rows;
+    p.math = math;
     return launch_attention(p, nproblems, max_q, (hipStream_t)stream);
 }
 
@@ -259,7 +277,7 @@ struct SgWorkspace {
     size_t enc_in, ka, kb, x, qkv, mlp, md, pack, z, part, uv_row, uv_col, max0, idx0, idx1, attn, attn_floats, total;
 };
 
-SgWorkspace sg_workspace_layout(const BatchDims& d) {
+SgWorkspace sg_workspace_layout(const BatchDims& d, int attn_math) {
     SgWorkspace w;
     size_t o = 0;
     auto take = [&](size_t floats) {
@@ -283,7 +301,7 @@ SgWorkspace sg_workspace_layout(const BatchDims& d) {
     w.max0 = take(T);
     w.idx0 = take(T);
     w.idx1 = take(T);
-    w.attn_floats = attention_workspace_floats(2 * d.P, 4, d.max_n, d.max_n, T);  // split partials (small batches) or fused parking space; 0 below 1025 keypoints
+    w.attn_floats = attention_workspace_floats(2 * d.P, 4, d.max_n, d.max_n, T, attn_math);  // split partials (small batches) or fused parking space; 0 below 1025 keypoints
     w.attn = take(w.attn_floats);
     w.total = o;
     return w;
@@ -293,7 +311,7 @@ SgWorkspace sg_workspace_layout(const BatchDims& d) {
 
 extern "C" size_t gtsfm_sg_workspace_bytes(int npairs, const int32_t* n0, const int32_t* n1) {
     if (npairs <= 0 || !n0 || !n1) return 256;
-    return sg_workspace_layout(batch_dims(npairs, n0, n1, 1)).total;
+    return sg_workspace_layout(batch_dims(npairs, n0, n1, 1), attention_math_from_env()).total;
 }
 
 // phase 0: the whole forward. phase 1: only what depends on ONE image -- keypoint encoder and the first (self) GNN layer --
@@ -311,7 +329,8 @@ static int sg_forward_phased(const float* wts, int num_layers, float bin_score, 
     GTSFM_CHECK_ARG(phase >= 0 && phase <= 2 && (phase == 0 || num_layers >= 1), "sg_forward: bad phase");
     GTSFM_CHECK_ARG(npairs > 0 && num_layers >= 0 && sinkhorn_iters >= 0, "sg_forward: bad arguments");
     const BatchDims d = batch_dims(npairs, n0, n1, 1);
-    const SgWorkspace ws = sg_workspace_layout(d);
+    const int attn_math = attention_math_from_env();  // GTSFM_ATTENTION_MATH, read per call (sizing and launches of one call agree)
+    const SgWorkspace ws = sg_workspace_layout(d, attn_math);
     if (workspace_bytes < ws.total) {
         gtsfm_set_error("sg_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.total);
         return GTSFM_ERR_WORKSPACE;
@@ -377,6 +396,7 @@ static int sg_forward_phased(const float* wts, int num_layers, float bin_score, 
         ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = X + 256, ap.ldo = 512;
         ap.problems = (l % 2 == 0) ? self_p : cross_p, ap.counts = counts, ap.scale = 0.125f, ap.heads = 4;
         ap.max_k = d.max_n, ap.workspace = ws.attn_floats ? (float*)(wsp + ws.attn) : nullptr, ap.workspace_floats = ws.attn_floats, ap.part_rows = T;
+        ap.math = attn_math;
         TRY(launch_attention(ap, 2 * npairs, d.max_n, stream));
         TRY(gemm(X, 512, 512, 512, MLP, 512, 0, nullptr, 0, 1));       // mlp.0 (+BN, merge folded) + ReLU
         TRY(gemm(MLP, 512, 512, 256, X, 512, 0, X, 512, 0));           // mlp.3, desc += delta
@@ -552,7 +572,7 @@ struct LgWorkspace {
         m_int, ms_int, attn, attn_floats, total;
 };
 
-LgWorkspace lg_workspace_layout(const LgDims& d) {
+LgWorkspace lg_workspace_layout(const LgDims& d, int attn_math) {
     LgWorkspace w;
     size_t o = 0;
     auto take = [&](size_t floats) {
@@ -567,7 +587,7 @@ LgWorkspace lg_workspace_layout(const LgDims& d) {
     w.pack = take(d.pack_floats), w.z = take(d.z_floats), w.part = take(d.part_floats);
     w.uv_row = take(T + 16 * d.P + 8), w.uv_col = take(T + 16 * d.P + 8);
     w.max0 = take(T), w.idx0 = take(T), w.idx1 = take(T), w.m_int = take(T), w.ms_int = take(T);
-    w.attn_floats = attention_workspace_floats(2 * d.P, 4, d.max_n, d.max_n, T);  // split partials (small batches) or fused parking space; 0 below 1025 keypoints
+    w.attn_floats = attention_workspace_floats(2 * d.P, 4, d.max_n, d.max_n, T, attn_math);  // split partials (small batches) or fused parking space; 0 below 1025 keypoints
     w.attn = take(w.attn_floats);
     w.total = o;
     return w;
@@ -577,7 +597,7 @@ LgWorkspace lg_workspace_layout(const LgDims& d) {
 
 extern "C" size_t gtsfm_lg_workspace_bytes(int npairs, const int32_t* n0, const int32_t* n1) {
     if (npairs <= 0 || !n0 || !n1) return 256;
-    return lg_workspace_layout(lg_dims(npairs, n0, n1)).total;
+    return lg_workspace_layout(lg_dims(npairs, n0, n1), attention_math_from_env()).total;
 }
 
 // Phases as for SuperGlue: 1 = only the first layer's SELF block (the part of LightGlue that sees one image), x to x_out_dev
@@ -592,7 +612,8 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
     GTSFM_CHECK_ARG(phase >= 0 && phase <= 2 && (phase == 1 ? x_out_dev != nullptr : (matches_dev && mscores_dev)), "lg_forward: bad phase / null output");
     GTSFM_CHECK_ARG(npairs > 0 && num_layers > 0 && (num_layers == 1 || conf_bias_host), "lg_forward: bad arguments");
     const LgDims d = lg_dims(npairs, n0, n1);
-    const LgWorkspace ws = lg_workspace_layout(d);
+    const int attn_math = attention_math_from_env();  // GTSFM_ATTENTION_MATH, read per call (sizing and launches of one call agree)
+    const LgWorkspace ws = lg_workspace_layout(d, attn_math);
     if (workspace_bytes < ws.total) {
         gtsfm_set_error("lg_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.total);
         return GTSFM_ERR_WORKSPACE;
@@ -690,6 +711,7 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
         ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = X + 256, ap.ldo = 512;
         ap.counts = live, ap.scale = 0.125f, ap.heads = 4;
         ap.max_k = d.max_n, ap.workspace = ws.attn_floats ? (float*)(wsp + ws.attn) : nullptr, ap.workspace_floats = ws.attn_floats, ap.part_rows = d.Tp;
+        ap.math = attn_math;
         if (l == 0 && phase == 2) {  // the first self block was run per image (phase 1): step over its weights
             const float *w, *b, *raw;
             cur.linear(768, 256, &w, &b, &raw), cur.linear(512, 512, &w, &b, &raw);

@@ -91,6 +91,12 @@ SIGNATURES = {
         [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
          C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "gtsfm_attention_math_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int]),
+    "gtsfm_attention_math_f32": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+         C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
     "gtsfm_sg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p]),
     "gtsfm_sg_forward": (
         C.c_int,

@@ -203,6 +203,18 @@ int gtsfm_attention_split_f32(const float* q_dev, int ldq, const float* k_dev, i
                               float* out_dev, int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems,
                               int max_q, int max_k, int heads, float scale, int mode, size_t rows, void* workspace_dev,
                               size_t workspace_bytes, void* stream);
+/* The same attention with its ARITHMETIC selectable as well. math 0 = exact fp32 (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain:
+ * the default everywhere and the arithmetic every parity statement of this package is made with). math 1 = "bf16x3": both products
+ * (K Q^T and P V) on v_mfma_f32_32x32x16_bf16 with each fp32 operand split EXACTLY into three bf16 pieces (8 + 8 + 8 significand
+ * bits) and six of the nine piece products executed, fp32 accumulation -- fp32-class error per product term (the dropped terms are
+ * below 2^-23 of it), NOT the same bits as math 0, 3/8 of its matrix-pipe time. Opt-in: the matchers take it from the environment
+ * variable GTSFM_ATTENTION_MATH=bf16x3 (read per call). max_k must be given (> 0); the workspace additionally holds the split K / V
+ * tiles (6 x heads x nproblems x ceil(max_k / 64) x 8 KiB). */
+size_t gtsfm_attention_math_workspace_bytes(int nproblems, int max_q, int max_k, int heads, size_t rows, int math);
+int gtsfm_attention_math_f32(const float* q_dev, int ldq, const float* k_dev, int ldk, const float* v_dev, int ldv,
+                             float* out_dev, int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems,
+                             int max_q, int max_k, int heads, float scale, int mode, int math, size_t rows, void* workspace_dev,
+                             size_t workspace_bytes, void* stream);
 
 /* ---- input step in front of SuperPoint (uint8, OpenCV's 8-bit fixed-point arithmetic) ----
  * RGB(A) -> gray.          replaces gtsfm/utils/images.py:15-42 (cv.cvtColor COLOR_RGB2GRAY / COLOR_RGBA2GRAY), called from

@@ -354,10 +354,25 @@ def check_lund_door_config1(write: bool, max_pairs: int | None = None) -> None:
         out[f"matching_scores0_{i}_{j}"] = ref["matching_scores0"][0].numpy()
     print(f"lund door config 1: {len(pairs)} pairs, {total} matches")
     if write:
+        # the frames as lossless PNG streams (6.9 MB; deflate on the raw array: 9.2 MB) -- tests/test_config1_lund_door_gpu.py decodes them with PIL
+        for i, gray in enumerate(grays):
+            out[f"gray_png_{i}"] = _png_bytes(gray)
         np.savez_compressed(
-            GOLDEN / "lund_door_config1.npz", names=np.array(names), gray=np.stack(grays), num_pairs=len(pairs),
+            GOLDEN / "lund_door_config1.npz", names=np.array(names), height=grays[0].shape[0], width=grays[0].shape[1], num_pairs=len(pairs),
             max_resolution=LUND_DOOR_MAX_RESOLUTION, max_keypoints=LUND_DOOR_MAX_KEYPOINTS, **out,
         )
+
+
+def _png_bytes(gray: np.ndarray) -> np.ndarray:
+    import io
+
+    from PIL import Image as PILImage
+
+    buf = io.BytesIO()
+    PILImage.fromarray(gray).save(buf, format="PNG", optimize=True)
+    back = np.asarray(PILImage.open(io.BytesIO(buf.getvalue())))
+    assert back.dtype == np.uint8 and np.array_equal(back, gray)
+    return np.frombuffer(buf.getvalue(), dtype=np.uint8)
 
 
 def main() -> None:

@@ -92,7 +92,8 @@ def test_default_workload_helpers():
     assert (bench.fewest_images_for(250), bench.fewest_images_for(1000), bench.fewest_images_for(5000)) == (23, 46, 101)
     assert (bench.default_pair_chunk(5000), bench.default_pair_chunk(2048), bench.default_pair_chunk(512), bench.default_pair_chunk(20000)) == (16, 32, 32, 4)
     args = bench.parse_args([])
-    assert (args.keypoints, args.pairs, args.images, args.pair_chunk, args.matcher, args.mode) == (5000, 250, 23, 16, "lightglue", "replica")
+    # the default IS BASELINE config 3 as written: the first 1000 exhaustive pairs of 46 views, at the reference's 5000-keypoint cap
+    assert (args.keypoints, args.pairs, args.images, args.pair_chunk, args.matcher, args.mode) == (5000, 1000, 46, 16, "lightglue", "replica")
     args = bench.parse_args(["--keypoints", "2048"])
     assert (args.pairs, args.images, args.pair_chunk) == (1000, 46, 32)
     args = bench.parse_args(["--mode", "scene"])

@@ -1,0 +1,204 @@
+"""-m gpu: BASELINE config 1 LITERALLY -- all 12 frames of the reference's own fixture ``tests/data/set1_lund_door`` at the Olsson
+loader's resolution (``max_resolution: 760``, gtsfm/configs/loader/olsson.yaml:5 -> 760 x 1135), GTSfM's 5000-keypoint cap
+(gtsfm/configs/deep_front_end.yaml:29), all 66 exhaustive pairs -- through the plugin classes and their cachers, and through the
+batched correspondence generator, against golden vectors WRITTEN BY THE REFERENCE'S OWN MODEL FILES
+(``oracle/validate_against_reference.py::check_lund_door_config1``: reference SuperPoint + the wrapper's ``get_top_k`` restated,
+reference SuperGlue with GTSfM's 20 Sinkhorn iterations + the wrapper's output marshalling). The reduced gray frames travel in the
+fixture (/root/reference does not exist on the GPU box); the loader's ``cv.INTER_CUBIC`` reduction in front of them is the one step
+restated without a pin (cv2 absent).
+
+Mirrors ``tests/frontend/detector_descriptor/test_superpoint.py:12-21`` (the plugin on the fixture's images) and the per-image /
+per-pair calls of ``gtsfm/frontend/correspondence_generator/det_desc_correspondence_generator.py:57-87``."""
+
+import numpy as np
+import pytest
+import torch
+
+from gtsfm_amd.common.image import Image
+from gtsfm_amd.common.keypoints import Keypoints
+from gtsfm_amd.utils import synthetic
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4              # scores / descriptors / match scores (BASELINE.json north_star)
+MATCH_THRESHOLD = 0.2   # superglue.py default match_threshold (GTSfM does not override it)
+NUM_IMAGES = 12
+
+
+@pytest.fixture(scope="module")
+def golden():
+    path = GOLDEN / "lund_door_config1.npz"
+    if not path.exists():
+        pytest.fail("tests/golden/lund_door_config1.npz is missing: run oracle/validate_against_reference.py --only-config1 --write in the build container")
+    import io
+
+    from PIL import Image as PILImage
+
+    g = dict(np.load(path))
+    g["gray"] = np.stack([np.asarray(PILImage.open(io.BytesIO(g[f"gray_png_{i}"].tobytes()))) for i in range(NUM_IMAGES)])  # lossless PNG streams
+    assert g["gray"].dtype == np.uint8 and g["gray"].shape == (NUM_IMAGES, int(g["height"]), int(g["width"]))
+    return g
+
+
+@pytest.fixture(scope="module")
+def images(golden):
+    # the loader hands RGB uint8 images over; the frames are stored gray (R = G = B: the fixed-point gray conversion is the identity)
+    return [Image(value_array=np.repeat(golden["gray"][i][:, :, None], 3, axis=2), file_name=str(golden["names"][i])) for i in range(NUM_IMAGES)]
+
+
+@pytest.fixture(scope="module")
+def plugins(tmp_path_factory, gpu_device):
+    from gtsfm_amd.frontend.cacher.detector_descriptor_cacher import DetectorDescriptorCacher
+    from gtsfm_amd.frontend.cacher.matcher_cacher import MatcherCacher
+    from gtsfm_amd.frontend.detector_descriptor.superpoint import SuperPointDetectorDescriptor
+    from gtsfm_amd.frontend.matcher.superglue_matcher import SuperGlueMatcher
+
+    tmp = tmp_path_factory.mktemp("config1")
+    torch.save(synthetic.synthetic_superpoint_state_dict(), str(tmp / "sp.pth"))
+    torch.save(synthetic.synthetic_superglue_state_dict(), str(tmp / "sg.pth"))
+    det = SuperPointDetectorDescriptor(max_keypoints=5000, weights_path=tmp / "sp.pth")
+    sg = SuperGlueMatcher(weights_path=tmp / "sg.pth")
+    return {"det": det, "sg": sg, "det_cacher": DetectorDescriptorCacher(det, cache_root=tmp / "cache"), "sg_cacher": MatcherCacher(sg, cache_root=tmp / "cache"),
+            "calls": {"det": 0, "sg": 0}}
+
+
+def _pixel_key(xy, width):
+    xy = np.asarray(xy)
+    return xy[:, 1].astype(np.int64) * width + xy[:, 0].astype(np.int64)
+
+
+@pytest.fixture(scope="module")
+def detections(golden, images, plugins):
+    """Every frame once through DetectorDescriptorCacher(SuperPointDetectorDescriptor)."""
+    det = plugins["det"]
+    real = det.detect_and_describe
+
+    def counted(image):
+        plugins["calls"]["det"] += 1
+        return real(image)
+
+    det.detect_and_describe = counted
+    out = [plugins["det_cacher"].detect_and_describe(im) for im in images]
+    assert plugins["calls"]["det"] == NUM_IMAGES
+    return out
+
+
+def test_detections_equal_the_reference_on_all_12_frames(golden, images, detections):
+    """Keypoints identical to the reference's 5000 (as a set: ``np.argpartition``'s order is implementation-defined, and scores that
+    differ in the last bits order differently), responses and descriptors within 1e-4."""
+    width = images[0].width
+    for i, (kps, desc) in enumerate(detections):
+        ref_xy, ref_sc, ref_head = golden[f"keypoints_{i}"].astype(np.float32), golden[f"scores_{i}"], golden[f"descriptors_head_{i}"]
+        assert isinstance(kps, Keypoints) and len(kps) == 5000 == desc.shape[0] and desc.shape[1] == 256 and kps.scales is None
+        assert kps.coordinates.dtype == np.float32 and desc.dtype == np.float32
+        got_key, ref_key = _pixel_key(kps.coordinates, width), _pixel_key(ref_xy, width)
+        assert len(np.unique(got_key)) == 5000
+        stray = np.setxor1d(got_key, ref_key)
+        if len(stray):  # a top-k boundary decided by the last bits of two scores: tolerated only within the score tolerance of the cut
+            cut = ref_sc.min()
+            sc_of = dict(zip(ref_key.tolist(), ref_sc.tolist()))
+            sc_of.update({k: s for k, s in zip(got_key.tolist(), kps.responses.tolist()) if k not in sc_of})
+            assert len(stray) <= 4 and all(abs(sc_of[k] - cut) < 2e-5 for k in stray.tolist()), (i, len(stray))
+        common, gi, ri = np.intersect1d(got_key, ref_key, return_indices=True)
+        assert len(common) >= 4998
+        np.testing.assert_allclose(kps.responses[gi], ref_sc[ri], rtol=0, atol=TOL)
+        head = np.flatnonzero(ri < len(ref_head))  # the stored descriptor rows: the first 64 of the reference's order
+        np.testing.assert_allclose(desc[gi[head]], ref_head[ri[head]], rtol=0, atol=TOL)
+
+
+def _in_reference_order(golden, images, plugins, detections, i):
+    """Image i's plugin output rearranged into the order the REFERENCE handed to its matcher (``sel_i``: its argpartition order)."""
+    width = images[0].width
+    kps, desc = detections[i]
+    ref_xy = golden[f"keypoints_{i}"].astype(np.float32)
+    got_key, ref_key = _pixel_key(kps.coordinates, width), _pixel_key(ref_xy, width)
+    order = np.argsort(got_key)
+    pos = np.searchsorted(got_key[order], ref_key)
+    pos = np.clip(pos, 0, len(order) - 1)
+    rows = order[pos]
+    if not np.array_equal(got_key[rows], ref_key):  # a top-k boundary flip (see above): take the reference's rows from the full detection
+        xy, sc, fetch = plugins["det"]._model.detect_lazy(np.ascontiguousarray(golden["gray"][i]))
+        sel = golden[f"sel_{i}"].astype(np.int64)
+        return Keypoints(xy[sel], scales=None, responses=sc[sel]), fetch(sel)
+    return Keypoints(kps.coordinates[rows], scales=None, responses=kps.responses[rows]), np.ascontiguousarray(desc[rows])
+
+
+def test_all_66_pairs_through_the_matcher_plugin_equal_the_reference(golden, images, plugins, detections):
+    """``MatcherCacher(SuperGlueMatcher).match`` on every exhaustive pair, keypoints in the order the reference used: the (K, 2) uint32
+    arrays are the reference's. A match whose score sits within 2e-4 of the 0.2 threshold may fall on either side (scores agree to
+    1e-4, not to the bit); the match scores of every sixth pair are compared in full."""
+    sg = plugins["sg"]
+    real = sg.match
+
+    def counted(*a, **k):
+        plugins["calls"]["sg"] += 1
+        return real(*a, **k)
+
+    sg.match = counted
+    feats = [_in_reference_order(golden, images, plugins, detections, i) for i in range(NUM_IMAGES)]
+    shape = (images[0].height, images[0].width, 3)
+    pairs = [(i, j) for i in range(NUM_IMAGES) for j in range(i + 1, NUM_IMAGES)]
+    assert int(golden["num_pairs"]) == len(pairs) == 66
+    total, borderline, results = 0, 0, {}
+    for q, (i, j) in enumerate(pairs):
+        got = plugins["sg_cacher"].match(feats[i][0], feats[j][0], feats[i][1], feats[j][1], im_shape_i1=shape, im_shape_i2=shape)
+        results[(i, j)] = got
+        ref = golden[f"match_indices_{i}_{j}"].astype(np.uint32)
+        ref_scores = golden[f"matching_scores0_{i}_{j}"]
+        assert got.dtype == np.uint32 and got.ndim == 2 and got.shape[1] == 2
+        total += len(ref)
+        if not np.array_equal(got, ref):
+            diff = set(map(tuple, got.tolist())) ^ set(map(tuple, ref.tolist()))
+            res = sg._model.match_pair(feats[i][0].coordinates, feats[i][0].responses, feats[i][1], feats[j][0].coordinates, feats[j][0].responses, feats[j][1],
+                                       shape[:2], shape[:2], sinkhorn_iterations=20)
+            for a, _ in diff:
+                assert abs(float(ref_scores[a]) - MATCH_THRESHOLD) < 2e-4 or abs(float(res["matching_scores0"][a]) - MATCH_THRESHOLD) < 2e-4, ((i, j), a)
+            borderline += len(diff)
+        if q % 6 == 0:
+            res = sg._model.match_pair(feats[i][0].coordinates, feats[i][0].responses, feats[i][1], feats[j][0].coordinates, feats[j][0].responses, feats[j][1],
+                                       shape[:2], shape[:2], sinkhorn_iterations=20)
+            same = res["matches0"] == golden[f"matches0_{i}_{j}"].astype(np.int64)
+            assert same.mean() > 0.999
+            np.testing.assert_allclose(res["matching_scores0"][same], ref_scores[same], rtol=0, atol=TOL)
+    assert plugins["calls"]["sg"] == 66 and total > 3000
+    assert borderline <= 3, f"{borderline} threshold-borderline matches differ over {total}"
+    # second pass: cache hits only (matcher_cacher.py:46-126, detector_descriptor_cacher.py:48-69) -- neither plugin runs again
+    for (i, j) in pairs[::5]:
+        again = plugins["sg_cacher"].match(feats[i][0], feats[j][0], feats[i][1], feats[j][1], im_shape_i1=shape, im_shape_i2=shape)
+        np.testing.assert_array_equal(again, results[(i, j)])
+    for im, (kps, desc) in zip(images, detections):
+        kps2, desc2 = plugins["det_cacher"].detect_and_describe(im)
+        assert kps2 == kps and np.array_equal(desc2, desc)
+    assert plugins["calls"] == {"det": NUM_IMAGES, "sg": 66}
+
+
+def test_batched_correspondence_generator_on_config1(golden, images, plugins):
+    """``BatchedDetDescCorrespondenceGenerator.generate_correspondences`` over the same 12 frames / 66 pairs (features resident in HBM,
+    ragged multi-pair launches): its keypoints are the reference's 5000 per frame in detection order, and its matches -- compared as
+    coordinate pairs, the index order differs by design -- are the reference's up to matches at the 0.2 threshold (the keypoint ORDER
+    enters the fp32 sums of attention and Sinkhorn: scores move in the sixth digit)."""
+    from gtsfm_amd.frontend.correspondence_generator.batched_det_desc_correspondence_generator import BatchedDetDescCorrespondenceGenerator
+
+    gen = BatchedDetDescCorrespondenceGenerator(plugins["sg"], plugins["det"])
+    pairs = [(i, j) for i in range(NUM_IMAGES) for j in range(i + 1, NUM_IMAGES)]
+    keypoints, putative = gen.generate_correspondences(None, images, pairs)
+    width = images[0].width
+    assert len(keypoints) == NUM_IMAGES and sorted(putative) == pairs
+    for i, kps in enumerate(keypoints):
+        stray = np.setxor1d(_pixel_key(kps.coordinates, width), _pixel_key(golden[f"keypoints_{i}"], width))
+        assert len(kps) == 5000 and len(stray) <= 4, (i, len(stray))
+    total = differing = 0
+    for (i, j) in pairs:
+        got = putative[(i, j)]
+        assert got.dtype == np.uint32
+        ref = golden[f"match_indices_{i}_{j}"].astype(np.int64)
+        ki, kj = _pixel_key(golden[f"keypoints_{i}"], width), _pixel_key(golden[f"keypoints_{j}"], width)
+        ref_set = set(zip(ki[ref[:, 0]].tolist(), kj[ref[:, 1]].tolist()))
+        gi, gj = _pixel_key(keypoints[i].coordinates, width), _pixel_key(keypoints[j].coordinates, width)
+        got_set = set(zip(gi[got[:, 0].astype(np.int64)].tolist(), gj[got[:, 1].astype(np.int64)].tolist()))
+        total += len(ref_set)
+        differing += len(ref_set ^ got_set)
+        assert len(ref_set ^ got_set) <= max(2, 0.01 * len(ref_set)), ((i, j), len(ref_set ^ got_set), len(ref_set))
+    assert differing <= 0.002 * total + 2, (differing, total)

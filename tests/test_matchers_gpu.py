@@ -942,6 +942,56 @@ def test_graph_replay_survives_descriptor_cache_eviction_and_empty_pair_lists(gp
     assert int((first[0]["matches"] > -1).sum()) > 0
 
 
+def test_attention_bf16x3_arithmetic(lib, gpu_device):
+    """The opt-in arithmetic (``gtsfm_attention_math_f32`` with math = 1, GTSFM_ATTENTION_MATH=bf16x3): K Q^T and P V on bf16 MFMA with
+    every fp32 operand split exactly into three bf16 pieces, fp32 accumulation. Against a FLOAT64 reference its error must be of the
+    class of the exact-fp32 kernel's (both are measured; bf16x3 may carry at most twice the exact kernel's error + 2e-6), its fused and
+    split schedules must agree bit for bit with each other (same segment merge), rows beyond a count stay untouched, and a problem
+    without keys writes zeros. Same ragged problem set as the schedule test: 1, 2, 3 and 5 key segments, cross problems, late dominant keys."""
+    counts = [300, 1024, 1025, 2048, 2500, 5000, 0, 70]
+    caps = [384, 1024, 1152, 2048, 2560, 5120, 128, 128]
+    offs = np.concatenate([[0], np.cumsum(caps)])[:-1]
+    total = int(sum(caps))
+    gen = torch.Generator().manual_seed(3)
+    qkv = torch.randn((total, 768), generator=gen)
+    qkv[:, :512] *= 1.5
+    qkv[offs[5] + 4990, 256:320] = qkv[offs[5] : offs[5] + 5000, :64].mean(0) * 40
+    qkv[offs[3] + 3, 256 + 64 : 256 + 128] = qkv[offs[3] : offs[3] + 2048, 64:128].mean(0) * 40
+    problems = [(0, 0), (1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (7, 6), (7, 5), (4, 2), (2, 4)]
+    d = qkv.to(gpu_device)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=gpu_device)
+    ws = torch.empty(int(lib.gtsfm_attention_math_workspace_bytes(len(problems), max(counts), max(counts), 4, total, 1)), dtype=torch.uint8, device=gpu_device)
+
+    def run(sel, mode, math):
+        prob = torch.tensor([[offs[a], a, offs[b], b] for a, b in sel], dtype=torch.int32, device=gpu_device)
+        out = torch.full((total, 256), float("nan"), device=gpu_device)
+        rc = lib.gtsfm_attention_math_f32(d.data_ptr(), 768, d.data_ptr() + 256 * 4, 768, d.data_ptr() + 512 * 4, 768, out.data_ptr(), 256, prob.data_ptr(),
+                                          cnt.data_ptr(), len(sel), max(counts[a] for a, _ in sel), max(counts), 4, 0.125, mode, math, total, ws.data_ptr(), ws.numel(),
+                                          _stream())
+        assert rc == 0, lib.gtsfm_last_error()
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    q64 = qkv.double()
+    worst = {"exact": 0.0, "x3": 0.0}
+    for sel in ([problems[0], problems[3], problems[5]], [problems[1], problems[2], problems[4], problems[6]], [problems[7]], [problems[8]], [problems[9]]):
+        exact, fused, split = run(sel, -1, 0), run(sel, -1, 1), run(sel, 1, 1)
+        touched = torch.zeros(total, dtype=torch.bool)
+        for a, b in sel:
+            rows = slice(offs[a], offs[a] + counts[a])
+            touched[rows] = True
+            assert torch.equal(fused[rows], split[rows]), (a, b)
+            if counts[b] == 0:
+                assert float(fused[rows].abs().max()) == 0.0
+                continue
+            ref = _ref_attention(q64[rows, :256], q64[offs[b] : offs[b] + counts[b], 256:512], q64[offs[b] : offs[b] + counts[b], 512:], 0.125)
+            e_exact, e_x3 = float((exact[rows].double() - ref).abs().max()), float((fused[rows].double() - ref).abs().max())
+            worst["exact"], worst["x3"] = max(worst["exact"], e_exact), max(worst["x3"], e_x3)
+            assert e_x3 <= 2.0 * e_exact + 2e-6, ((a, b), e_x3, e_exact)
+        assert torch.isnan(fused[~touched]).all() and torch.isnan(split[~touched]).all()
+    print(f"attention max |error| against float64: exact fp32 {worst['exact']:.3e}, bf16x3 {worst['x3']:.3e}")
+
+
 @pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
 def test_single_pair_schedules_are_bit_identical_to_the_batch_schedules(gpu_device, monkeypatch, matcher):
     """One pair on its own takes the schedules that fill the chip -- 64 x 64 GEMM tiles, attention split over key segments -- while a

@@ -117,3 +117,28 @@ def test_bench_work_formulas_match_survey():
     assert abs(bench.matcher_flops("superglue", 2048, 18, 100) / 1e9 - 254.8) < 0.1
     assert abs(bench.matcher_flops("lightglue", 2048, 9.0, 0) / 1e9 - 229.8) < 0.1
     assert abs(bench.matcher_flops("superglue", 5000, 18, 100) / 1e9 - 1173.8) < 0.5
+
+
+def test_config1_fixture_oracle_reproduces_the_reference_on_a_frame():
+    """BASELINE config 1 literally (12 Lund-door frames at 1135x760, 5000-keypoint cap, 66 SuperGlue pairs: written by the reference's
+    own model files, oracle/validate_against_reference.py::check_lund_door_config1): the SuperPoint oracle + the restated wrapper
+    top-k reproduce frame 11's stored keypoints in the reference's order; the fixture is complete."""
+    import io
+
+    from PIL import Image as PILImage
+
+    g = np.load(GOLDEN / "lund_door_config1.npz")
+    assert int(g["num_pairs"]) == 66 and int(g["max_keypoints"]) == 5000 and (int(g["height"]), int(g["width"])) == (1135, 760)
+    assert all(f"match_indices_{i}_{j}" in g.files for i in range(12) for j in range(i + 1, 12))
+    gray = np.asarray(PILImage.open(io.BytesIO(g["gray_png_11"].tobytes())))
+    assert gray.dtype == np.uint8 and gray.shape == (1135, 760)
+    sd = synthetic.synthetic_superpoint_state_dict()
+    with torch.no_grad():
+        out = superpoint_oracle.superpoint_forward(sd, superpoint_oracle.gray_u8_to_tensor(gray))
+    assert out["keypoints"].shape[0] == int(g["k_raw_11"])
+    sel = g["sel_11"].astype(np.int64)
+    np.testing.assert_array_equal(out["keypoints"].numpy()[sel].astype(np.int16), g["keypoints_11"])
+    np.testing.assert_allclose(out["scores"].numpy()[sel], g["scores_11"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out["descriptors"].numpy().T[sel[:64]], g["descriptors_head_11"], rtol=0, atol=1e-6)
+    # the wrapper's selection (gtsfm/common/keypoints.py:89-110): the 5000 strongest responses
+    assert set(np.argpartition(-out["scores"].numpy(), 5000)[:5000].tolist()) == set(sel.tolist())
