@@ -47,6 +47,7 @@ sys.path.insert(0, str(REPO))
 from gtsfm_amd.utils import synthetic  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16: 16 x the fp32 rate)
 HBM_PEAK_GBS = 8000.0          # same guide: HBM3E spec peak (6.3 TB/s is what a streaming copy reaches)
 
 
@@ -161,10 +162,11 @@ def measure_conv_roofline(lib, device, batch: int, h: int, w: int, reps: int = 5
     }
 
 
-def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5):
+def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5, math: int = 0):
     """Dominant kernel of the detect+match workload (~50 % of GPU time): one launch = the self attention of `npairs`
     pairs (2 sequences x 4 heads each) at N = n. Algorithmic work: 1024 * N^2 FLOP per sequence per layer (SURVEY.md
-    section 8a rows a23 / a36)."""
+    section 8a rows a23 / a36). math 1 = the opt-in bf16x3 arithmetic (6 bf16 MFMAs per 32 x 32 x 16 block of either product):
+    the same algorithmic FLOPs, priced against the same fp32 roof AND as executed bf16 work against the bf16 MFMA roof."""
     from gtsfm_amd.runtime import lib as L
 
     stream = torch.cuda.current_stream(device)
@@ -175,12 +177,20 @@ def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5):
     probs = torch.tensor([[s * cap, s, s * cap, s] for s in range(nseq)], dtype=torch.int32, device=device)
     counts = torch.full((nseq,), n, dtype=torch.int32, device=device)
     # the matchers' call: workspace for the schedule the launch geometry picks (mode 0) -- fused with the merged state parked in the workspace here
-    ws = torch.empty(max(256, int(lib.gtsfm_attention_split_workspace_bytes(nseq, n, n, 4, nseq * cap))), dtype=torch.uint8, device=device)
+    ws = torch.empty(max(256, int(lib.gtsfm_attention_math_workspace_bytes(nseq, n, n, 4, nseq * cap, math))), dtype=torch.uint8, device=device)
     args = (qkv.data_ptr(), 768, qkv.data_ptr() + 256 * 4, 768, qkv.data_ptr() + 512 * 4, 768, out.data_ptr(), 256, probs.data_ptr(),
-            counts.data_ptr(), nseq, n, n, 4, 0.125, 0, nseq * cap, ws.data_ptr(), ws.numel(), stream.cuda_stream)
-    ms = _time_launches(lambda: L.check(lib.gtsfm_attention_split_f32(*args), "attention"), stream, reps)
+            counts.data_ptr(), nseq, n, n, 4, 0.125, 0, math, nseq * cap, ws.data_ptr(), ws.numel(), stream.cuda_stream)
+    ms = _time_launches(lambda: L.check(lib.gtsfm_attention_math_f32(*args), "attention"), stream, reps)
     flops = 1024.0 * n * n * nseq
     achieved = flops / (ms * 1e-3) / 1e12
+    if math == 1:
+        executed = 6.0 * flops  # six bf16 products per fp32 product term
+        return {
+            "bound": "mfma", "kernel": "attention_x3_split_kernel + attention_x3_kernel", "achieved": round(executed / (ms * 1e-3) / 1e12, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s (executed bf16)", "frac": round(executed / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
+            "algorithmic_tflops": round(achieved, 2), "algorithmic_frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "flops_per_launch": flops,
+            "launch_shape": f"{nseq} sequences x 4 heads, N = {n} queries = keys, head_dim 64 (K / V split pass + attention)", "traffic": None,
+        }
     t = pmc_traffic(f"attention_dma_kernel@{nseq}x4x{n}")
     return {
         "bound": "mfma", "kernel": "attention_dma_kernel", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -721,26 +731,7 @@ def main() -> None:
                     other.append(guarded(measure_score_gemm_roofline, lib, device, args.keypoints, chunk_pairs))
                     other.append(guarded(measure_sinkhorn_roofline, lib, device, args.keypoints, chunk_pairs))  # SuperGlue legs (headline or secondary)
                     result["roofline_other"] = [r for r in other if r is not None] + [conv_roof]
-            if world == 1 and not args.no_secondary and not detect_only and not scene and args.pair_definition == "exhaustive":
-                # every leg has its own timed region and must not be able to take the headline line down with it
-                def leg(name, fn, *fargs):
-                    try:
-                        return fn(*fargs)
-                    except Exception as exc:  # noqa: BLE001
-                        torch.cuda.synchronize(device)
-                        return {"error": f"{type(exc).__name__}: {str(exc)[:300]}", "leg": name}
-
-                sec = leg("secondary_rates", secondary_rates, args, detector, matcher, device, h, w, mk, not args.no_cpu_baseline)
-                result["secondary"] = sec if "error" not in sec else {"rates": sec}
-                if getattr(pipe, "last_shared_images", 0):
-                    result["secondary"]["headline_per_pair_first_layer"] = leg("unshared", unshared_rate, args, detector, matcher, images, pairs, shapes, mk)
-                if args.matcher == "lightglue":
-                    result["secondary"]["lightglue_adaptive_depth"] = leg("adaptive", adaptive_depth_rate, args, detector, device, images, pairs, shapes)
-                result["secondary"]["verifier_stage"] = leg("verifier", verifier_rate, pipe, feats, res, h, w, ms_per_step, device, not args.no_cpu_baseline)
-                result["secondary"]["plugin_api"] = leg("plugin_api", plugin_api_rate, args, pipe, views_np, device, h, w)
-                result["secondary"]["config2_superpoint_480x640"] = leg("config2", config2_superpoint_rate, lib, detector, device, not args.no_cpu_baseline)
-                if args.keypoints > 2500 and (h, w) == (1024, 1024):
-                    result["secondary"]["config4_scene_share_cap5000"] = leg("config4", config4_scene_share_rate, args, detector, device, h, w, not args.no_cpu_baseline)
+            base = ora = None
             if world == 1 and not args.no_cpu_baseline:  # rank 0 at N = 1 only
                 first = all_pairs[0] if all_pairs else (0, min(1, len(views_np) - 1))
                 view_of = (lambda s: (5 * s) % args.images) if independent else (lambda s: s)  # noqa: E731
@@ -756,6 +747,28 @@ def main() -> None:
                     gpu_match = (res[0]["matches"][:a].cpu().numpy(), res[0]["mscores"][:a].cpu().numpy())
                 rows_ = [pairs[0][0], pairs[0][1]] if pairs else [0, min(1, n - 1)]
                 result["parity_check"] = parity_check(ora, feats, rows_, gpu_match)
+            if world == 1 and not args.no_secondary and not detect_only and not scene and args.pair_definition == "exhaustive":
+                # every leg has its own timed region and must not be able to take the headline line down with it
+                def leg(name, fn, *fargs):
+                    try:
+                        return fn(*fargs)
+                    except Exception as exc:  # noqa: BLE001
+                        torch.cuda.synchronize(device)
+                        return {"error": f"{type(exc).__name__}: {str(exc)[:300]}", "leg": name}
+
+                sec = leg("secondary_rates", secondary_rates, args, detector, matcher, device, h, w, mk, not args.no_cpu_baseline)
+                result["secondary"] = sec if "error" not in sec else {"rates": sec}
+                if args.matcher == "lightglue" and args.keypoints > 1024:
+                    result["secondary"]["attention_bf16x3"] = leg("bf16x3", attention_bf16x3_rate, args, lib, detector, matcher, images, pairs, shapes, device, ora)
+                if getattr(pipe, "last_shared_images", 0):
+                    result["secondary"]["headline_per_pair_first_layer"] = leg("unshared", unshared_rate, args, detector, matcher, images, pairs, shapes, mk)
+                if args.matcher == "lightglue":
+                    result["secondary"]["lightglue_adaptive_depth"] = leg("adaptive", adaptive_depth_rate, args, detector, device, images, pairs, shapes)
+                result["secondary"]["verifier_stage"] = leg("verifier", verifier_rate, pipe, feats, res, h, w, ms_per_step, device, not args.no_cpu_baseline)
+                result["secondary"]["plugin_api"] = leg("plugin_api", plugin_api_rate, args, pipe, views_np, device, h, w)
+                result["secondary"]["config2_superpoint_480x640"] = leg("config2", config2_superpoint_rate, lib, detector, device, not args.no_cpu_baseline)
+                if args.keypoints > 2500 and (h, w) == (1024, 1024):
+                    result["secondary"]["config4_scene_share_cap5000"] = leg("config4", config4_scene_share_rate, args, detector, device, h, w, not args.no_cpu_baseline)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
@@ -1048,6 +1061,61 @@ def config4_scene_share_rate(args, detector, device, h, w, with_oracle: bool):
         a = res[0]["n0"][0]
         out["cpu_baseline"] = base
         out["parity_check"] = parity_check(ora, table, [i, j], (res[0]["matches"][:a].cpu().numpy(), res[0]["mscores"][:a].cpu().numpy()))
+    return out
+
+
+def attention_bf16x3_rate(args, lib, detector, matcher, images, pairs, shapes, device, oracle_out):
+    """The opt-in arithmetic GTSFM_ATTENTION_MATH=bf16x3 on the first pairs of the headline workload: both products of every attention
+    launch on v_mfma_f32_32x32x16_bf16 with each fp32 operand split exactly into three bf16 pieces (six of the nine piece products, fp32
+    accumulation: fp32-class error per product, NOT the exact-fp32 kernel's bits); SuperPoint, the GEMMs, the sweeps stay exact fp32. Own
+    timed region; compared pair by pair with the exact-fp32 pipeline on the same input and, for the first pair, with the oracle."""
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+
+    pairs = pairs[:SIDE_LEG_PAIRS]
+    images = images[: max(max(p) for p in pairs) + 1]
+
+    def make_pipe():
+        return FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams,
+                                use_graphs=bool(args.graphs), share_first_layer=bool(args.share_first_layer))
+
+    feats = make_pipe().detect(images)
+    exact = make_pipe().match(feats, pairs, shapes)
+    torch.cuda.synchronize(device)
+    old = os.environ.get("GTSFM_ATTENTION_MATH")
+    os.environ["GTSFM_ATTENTION_MATH"] = "bf16x3"  # read per call by the matcher's C entry points; graphs are captured under it
+    try:
+        pipe = make_pipe()
+        res, timing = _time_steps(lambda: pipe.match(pipe.detect(images), pairs, shapes), SECONDARY_STEPS, 1, device)
+        roof = measure_attention_roofline(lib, device, args.keypoints, min(args.pair_chunk, len(pairs)), math=1)
+    finally:
+        if old is None:
+            os.environ.pop("GTSFM_ATTENTION_MATH", None)
+        else:
+            os.environ["GTSFM_ATTENTION_MATH"] = old
+    ms = timing["ms_per_step"]
+    same_pairs, dmax, nmatch = 0, 0.0, 0
+    for a, b in zip(exact, res):
+        n0 = a["n0"]
+        ma, mb = a["matches"].cpu().numpy(), b["matches"].cpu().numpy()
+        sa, sb = a["mscores"].cpu().numpy(), b["mscores"].cpu().numpy()
+        off = 0
+        for q in range(len(a["pairs"])):
+            t = int(n0[q]) + int(a["n1"][q])
+            eq = bool(np.array_equal(ma[off : off + t], mb[off : off + t]))
+            same_pairs += int(eq)
+            if eq:
+                dmax = max(dmax, float(np.abs(sa[off : off + t] - sb[off : off + t]).max()))
+            nmatch += int((ma[off : off + int(n0[q])] > -1).sum())
+            off += t
+    out = {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", **timing, "pairs_per_step": len(pairs), "images_per_step": int(images.shape[0]),
+           "dtype": "f32 via 3 x bf16 split of both attention products, f32 accumulate (SuperPoint, GEMMs, sweeps: exact f32)",
+           "matcher_layers_run": float(torch.cat([r["stop"] for r in res]).float().mean()) if res and "stop" in res[0] else None,
+           "against_exact_fp32_pipeline": {"pairs_with_identical_match_arrays": same_pairs, "pairs": len(pairs), "max_dscore_on_those": dmax, "matches": nmatch},
+           "roofline": roof,
+           "workload": f"the first {len(pairs)} pairs of the headline workload with GTSFM_ATTENTION_MATH=bf16x3 (opt-in; the headline stays exact fp32)"}
+    if oracle_out is not None and res:
+        a = res[0]["n0"][0]
+        out["parity_check"] = parity_check(oracle_out, feats, [pairs[0][0], pairs[0][1]], (res[0]["matches"][:a].cpu().numpy(), res[0]["mscores"][:a].cpu().numpy()))
     return out
 
 

@@ -700,6 +700,13 @@ __global__ __launch_bounds__(256) void attention_x3_split_kernel(AttnParams p) {
 // head per workgroup of 4 waves, a wave owns 32 queries, 64-key tiles, 1024-key segments merged by at_merge, fused or split
 // schedule), ONE transposed score tile per wave. Per tile and wave: 48 + 48 v_mfma_f32_32x32x16_bf16. The fused schedule parks its
 // merged state in the caller's workspace (48 KiB of LDS tiles + a 34 KiB LDS slab would leave one workgroup per CU).
+// Measured on MI355X, round 4 (tools/bench_attention.py, 32 sequences x 4 heads at N = 5000; exact fp32: 6.17 - 6.22 ms): 3.99 - 4.02 ms
+// including the 0.17 ms split pass = 1.55 x (N = 2048, 64 sequences: 2.03 -> 1.39 ms). Four more elaborate loops were built and measured
+// within +-3 % of this one (operand reads and the P split software-pipelined under the MFMAs with sched_group_barrier; three workgroups
+// per CU at <= 168 VGPRs; two score tiles with the softmax under the next tile's S MFMAs, 242 VGPRs -- that one also differed from run to
+// run in the sixth digit when two streams shared the chip, cause not found, and was dropped): the SQ counters show the matrix pipe busy
+// 67 - 71 % of the cycles but the clock at 1.6 GHz under the counters (1.8 GHz free-running) where the exact-fp32 kernel holds
+// 2.2 - 2.3 GHz. At this duty cycle the bf16 pipe is power-limited: 3 / 8 of the matrix-pipe cycles buy 1.55 x, not 2.67 x.
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
     constexpr int NT = 256;

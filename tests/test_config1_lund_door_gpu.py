@@ -159,9 +159,15 @@ def test_all_66_pairs_through_the_matcher_plugin_equal_the_reference(golden, ima
         if q % 6 == 0:
             res = sg._model.match_pair(feats[i][0].coordinates, feats[i][0].responses, feats[i][1], feats[j][0].coordinates, feats[j][0].responses, feats[j][1],
                                        shape[:2], shape[:2], sinkhorn_iterations=20)
-            same = res["matches0"] == golden[f"matches0_{i}_{j}"].astype(np.int64)
+            ref_m0 = golden[f"matches0_{i}_{j}"].astype(np.int64)
+            same = res["matches0"] == ref_m0
             assert same.mean() > 0.999
-            np.testing.assert_allclose(res["matching_scores0"][same], ref_scores[same], rtol=0, atol=TOL)
+            matched = same & (ref_m0 > -1)
+            np.testing.assert_allclose(res["matching_scores0"][matched], ref_scores[matched], rtol=0, atol=TOL)
+            # unmatched keypoints carry exp(max) where they are mutual nearest neighbours and 0 where not (superglue.py:270-272): a
+            # score may differ only where that flag flipped between two negligible candidates, never near the threshold
+            off = np.abs(res["matching_scores0"] - ref_scores) > TOL
+            assert off.sum() <= 5 and np.all(np.maximum(res["matching_scores0"][off], ref_scores[off]) < 0.5 * MATCH_THRESHOLD), ((i, j), int(off.sum()))
     assert plugins["calls"]["sg"] == 66 and total > 3000
     assert borderline <= 3, f"{borderline} threshold-borderline matches differ over {total}"
     # second pass: cache hits only (matcher_cacher.py:46-126, detector_descriptor_cacher.py:48-69) -- neither plugin runs again

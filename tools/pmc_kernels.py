@@ -1,5 +1,5 @@
 """PMC workload (GPU box, run under rocprofv3 --pmc ...): a few launches of ONE kernel at its workload shape.
-    python tools/pmc_kernels.py attention [N pairs] | gemm ROWS K N | sinkhorn [N pairs] | conv | all"""
+    python tools/pmc_kernels.py attention [N pairs] | attention_x3 [N pairs] | gemm ROWS K N | sinkhorn [N pairs] | conv | all"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -10,6 +10,8 @@ what = sys.argv[1] if len(sys.argv) > 1 else "all"
 num = [int(a) for a in sys.argv[2:]]
 if what in ("attention", "all"):
     bench.measure_attention_roofline(lib, dev, *(num or [5000, 16]), reps=4)
+if what == "attention_x3":
+    bench.measure_attention_roofline(lib, dev, *(num or [5000, 16]), reps=4, math=1)
 if what == "gemm":
     bench.measure_gemm_roofline(lib, dev, *num, reps=4)
 if what == "all":
