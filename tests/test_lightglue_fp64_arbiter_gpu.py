@@ -4,7 +4,8 @@ the arithmetic half of the question: wherever the HIP path and the fp32 oracle d
 round-off it is. Cases: N = 2048 after 1 / 3 / 5 / 7 / 9 layers (error growth with depth), 5000 x 4800 at full depth (GTSfM's cap), and
 5000 x 4800 with a peaked assignment. Both arithmetics of the attention kernel are held to it: exact fp32 (the default) and the opt-in
 bf16x3. Requirements: matches equal to the float64 matches except where the float64 score sits within 1e-4 of the 0.1 filter threshold;
-scores within 1e-4 of float64; and the HIP error no larger than 3 x the fp32 oracle's own error + 2e-5. The table it prints is quoted
+scores within 1e-4 of float64 (within twice the fp32 oracle's own distance where that alone exceeds 1e-4: the peaked case); and the
+HIP error no larger than 3 x the fp32 oracle's own error + 2e-5. The table it prints is quoted
 in DESIGN.md section 5 (profiles/r04_lightglue_fp64_arbiter.txt)."""
 
 import json
@@ -65,5 +66,7 @@ def test_hip_lightglue_against_float64(gpu_device, arbiter, monkeypatch, name, m
     nm = int((g[f"{name}_matches0_f64"] > -1).sum())
     print(f"ARBITER {name:24s} {math:7s} matches {nm:5d}  threshold flips {flips}  max |score - float64|: HIP {err_hip:.2e}   fp32 oracle {err_f32:.2e}")
     assert nm > 50
-    assert err_hip < TOL
+    # the contract's 1e-4 -- unless the fp32 restatement ITSELF is further than that from float64 (the peaked case: 1.4e-4 on the
+    # CPU), where no fp32 implementation can be held to it: then twice the restatement's own error
+    assert err_hip < max(TOL, 2.0 * err_f32), (err_hip, err_f32)
     assert err_hip <= 3.0 * err_f32 + 2e-5, (err_hip, err_f32)
