@@ -92,7 +92,7 @@ def first_block_flops(matcher: str, n: int) -> float:
 def pmc_traffic(kernel: str):
     """HBM bytes per launch measured with rocprofv3 PMC passes and committed under profiles/ (bench.py cannot collect
     counters itself); None when no file holds the kernel."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             entry = json.loads((REPO / "profiles" / name).read_text()).get(kernel)
         except (OSError, ValueError):
