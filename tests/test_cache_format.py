@@ -147,3 +147,38 @@ def test_foreign_class_entry_is_kept_but_a_failing_rebuild_removes_the_file(tmp_
     with BZ2File(missing_attr, "wb") as f:
         f.write(b"\x80\x04\x8c\x05numpy\x8c\x10NoSuchNumpyThing\x93)\x81.")
     assert cache_format.read_from_bz2_file(missing_attr) is None and missing_attr.exists()
+
+
+def test_entries_written_by_the_reference_cachers_are_hits(tmp_path):
+    """``tests/golden/reference_cache/`` holds two cache entries WRITTEN BY THE REFERENCE'S OWN CODE -- its ``DetectorDescriptorCacher`` and
+    ``MatcherCacher`` (gtsfm/frontend/cacher/*.py), its ``Keypoints`` class, key scheme and ``write_to_bz2_file`` -- run in the build container
+    by ``oracle/validate_cache_against_reference.py`` (which also shows the opposite direction: the reference's cachers reading entries this
+    package wrote). Through this package's cachers both must be HITS (the wrapped plugins raise when called) and return the stored arrays."""
+    import shutil
+
+    from oracle.validate_cache_against_reference import sample_inputs
+    from tests.conftest import GOLDEN
+
+    root = tmp_path / "cache"
+    shutil.copytree(GOLDEN / "reference_cache", root)  # a read-only checkout must not be needed: corrupted entries are removed on read
+    a = sample_inputs(1)
+
+    class SuperPointDetectorDescriptor(DetectorDescriptorBase):  # the class name is the cache namespace
+        def detect_and_describe(self, image):
+            raise AssertionError("cache miss on an entry the reference wrote")
+
+    class SuperGlueMatcher(MatcherBase):
+        def match(self, **kw):
+            raise AssertionError("cache miss on an entry the reference wrote")
+
+    kps, desc = DetectorDescriptorCacher(SuperPointDetectorDescriptor(max_keypoints=5000), cache_root=root).detect_and_describe(
+        Image(value_array=a["image"], file_name=a["file_name"]))
+    assert isinstance(kps, Keypoints) and kps.scales is None
+    np.testing.assert_array_equal(kps.coordinates, a["c1"])
+    np.testing.assert_array_equal(kps.responses, a["r1"])
+    np.testing.assert_array_equal(desc, a["d1"])
+    m = MatcherCacher(SuperGlueMatcher(), cache_root=root).match(
+        Keypoints(a["c1"], responses=a["r1"]), Keypoints(a["c2"], responses=a["r2"]), a["d1"], a["d2"], (48, 64, 3), (48, 64, 3))
+    assert m.dtype == np.uint32
+    np.testing.assert_array_equal(m, a["matches"])
+    assert len(list(root.rglob("*.pbz2"))) == 2  # nothing was rewritten or removed
