@@ -210,19 +210,25 @@ def test_batched_correspondence_generator_on_config1(golden, images, plugins):
     assert differing <= 0.002 * total + 2, (differing, total)
 
 
-def test_per_pair_generator_on_config1(golden, images, plugins, detections):
+def test_per_pair_generator_on_config1(golden, images, plugins, detections, tmp_path_factory):
     """The reference's own flow, ``DetDescCorrespondenceGenerator(matcher=MatcherCacher(SuperGlueMatcher), detector_descriptor=
     DetectorDescriptorCacher(SuperPointDetectorDescriptor)).generate_correspondences(client, images, visibility_graph)``
     (gtsfm/configs/deep_front_end.yaml:22-35, det_desc_correspondence_generator.py:57-87), without a scheduler: keypoints in the plugin's own
     ``get_top_k`` order, matches -- as coordinate pairs -- the reference's, on the first 22 edges."""
+    from gtsfm_amd.frontend.cacher.matcher_cacher import MatcherCacher
     from gtsfm_amd.frontend.correspondence_generator.det_desc_correspondence_generator import DetDescCorrespondenceGenerator
 
-    gen = DetDescCorrespondenceGenerator(matcher=plugins["sg_cacher"], detector_descriptor=plugins["det_cacher"])
+    # a matcher cache of its own: the reference's key scheme hashes the FIRST 10 rows of each image's features (matcher_cacher.py:24,46-80), and the
+    # test above matched the same frames with their 5000 rows in the reference's order -- equal in the first rows, permuted further down for some
+    # frames (np.argpartition on scores that differ in the last bits): a shared directory would serve those entries for these calls
+    fresh = MatcherCacher(plugins["sg"], cache_root=tmp_path_factory.mktemp("config1_generator_cache"))
+    gen = DetDescCorrespondenceGenerator(matcher=fresh, detector_descriptor=plugins["det_cacher"])
     pairs = [(i, j) for i in range(NUM_IMAGES) for j in range(i + 1, NUM_IMAGES)][:22]
     keypoints, putative = gen.generate_correspondences(None, images, pairs)
     width = images[0].width
     assert len(keypoints) == NUM_IMAGES and all(keypoints[i] == detections[i][0] for i in range(NUM_IMAGES))  # served from the detector cache
     total = differing = 0
+    per_pair = []
     for (i, j) in pairs:
         got = putative[(i, j)].astype(np.int64)
         ref = golden[f"match_indices_{i}_{j}"].astype(np.int64)
@@ -232,4 +238,5 @@ def test_per_pair_generator_on_config1(golden, images, plugins, detections):
         got_set = set(zip(gi[got[:, 0]].tolist(), gj[got[:, 1]].tolist()))
         total += len(ref_set)
         differing += len(ref_set ^ got_set)
-    assert total > 1000 and differing <= 0.002 * total + 2, (differing, total)
+        per_pair.append(((i, j), len(ref_set), len(ref_set ^ got_set)))
+    assert total > 1000 and differing <= 0.002 * total + 2, (differing, total, [p for p in per_pair if p[2]])

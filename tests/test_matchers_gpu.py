@@ -621,6 +621,44 @@ def test_lightglue_plugin_contract(gpu_device, tmp_path):
 
 
 @pytest.mark.parametrize("which", ["superglue", "lightglue"])
+def test_per_call_image_cache_is_bit_identical_and_counts_hits(gpu_device, sg_sd, which):
+    """The per-call path keeps every image's uploaded keypoints and the output of the matcher's per-image first block on the device
+    (``_MatcherBase._image_entries``): pairs (A,B), (A,C), (B,C) cost 2 + 1 + 0 uploads instead of the reference's 6
+    (superglue_matcher.py:75-102 uploads both images per pair). Results must equal the uncached calls bit for bit; an array that is
+    modified in place (a sampled row) is a new image; ``release_lanes()`` empties the cache."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+
+    imgs = []
+    for seed, n in enumerate((900, 1100, 640)):
+        k, s, d, *_ = synthetic.synthetic_pair_features(n, 8, (480, 640), (480, 640), seed=200 + seed)
+        imgs.append((k, s, d))
+    if which == "superglue":
+        cached, plain = ME.SuperGlueEngine(sg_sd, gpu_device), ME.SuperGlueEngine(sg_sd, gpu_device)
+        call = lambda e, a, b: e.match_pair(a[0], a[1], a[2], b[0], b[1], b[2], (480, 640), (480, 640))  # noqa: E731
+    else:
+        sd = synthetic.synthetic_lightglue_state_dict()
+        cached, plain = ME.LightGlueEngine(sd, gpu_device), ME.LightGlueEngine(sd, gpu_device)
+        call = lambda e, a, b: e.match_pair(a[0], a[2], b[0], b[2], (480, 640), (480, 640))  # noqa: E731
+    plain.image_cache_capacity = 0
+    assert cached.image_cache_capacity == 64
+    expect = [(2, 0), (3, 1), (3, 3)]  # cumulative (misses, hits)
+    for (i, j), (miss, hit) in zip([(0, 1), (0, 2), (1, 2)], expect):
+        a, b = call(cached, imgs[i], imgs[j]), call(plain, imgs[i], imgs[j])
+        for key in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+            np.testing.assert_array_equal(a[key], b[key])
+        assert (cached.image_cache_misses, cached.image_cache_hits) == (miss, hit)
+    assert (plain.image_cache_misses, plain.image_cache_hits) == (0, 0)
+    # the same buffer with other content is another image
+    imgs[0][2][-1, 5] += 0.25
+    a, b = call(cached, imgs[0], imgs[1]), call(plain, imgs[0], imgs[1])
+    np.testing.assert_array_equal(a["matching_scores0"], b["matching_scores0"])
+    assert cached.image_cache_misses == 4 and len(cached._image_cache) == 4
+    cached.release_lanes()
+    assert len(cached._image_cache) == 0 and cached._workspace is None
+    np.testing.assert_array_equal(call(cached, imgs[1], imgs[2])["matches0"], call(plain, imgs[1], imgs[2])["matches0"])
+
+
+@pytest.mark.parametrize("which", ["superglue", "lightglue"])
 def test_plugin_match_from_several_threads_equals_one_at_a_time(gpu_device, sg_sd, tmp_path, which):
     """GTSfM's ``--threads_per_worker`` (gtsfm/runner.py:155,436) lets several Dask threads call ``match`` on ONE scattered matcher
     object at once. The engine hands every concurrent call a lane of its own (workspace, staging buffers, stream; shared weights):

@@ -587,3 +587,43 @@ def test_device_mask_equals_filter_by_mask_then_top_k(gpu_device):
         assert ct == len(order)
         np.testing.assert_array_equal(top["xy"][b, :ct].cpu().numpy(), kept.coordinates[order])
         np.testing.assert_array_equal(top["descriptors"][b, :ct].cpu().numpy(), de[idx][order])
+
+
+def test_detect_and_describe_from_several_threads_equals_one_at_a_time(gpu_device, sd, tmp_path):
+    """Several Dask threads of one worker (``--threads_per_worker``, gtsfm/runner.py:155,436) call ``detect_and_describe`` on ONE scattered
+    plugin object: the engine serves them on lanes of their own (staging buffers, workspace, stream; round 3 took turns behind one lock).
+    Images of three different sizes from three threads, twice: exactly the keypoints / descriptors of the same calls made one after the other."""
+    import threading
+
+    from gtsfm_amd.common.image import Image
+    from gtsfm_amd.frontend.detector_descriptor.superpoint import SuperPointDetectorDescriptor
+
+    path = tmp_path / "superpoint_v1.pth"
+    torch.save(sd, str(path))
+    det = SuperPointDetectorDescriptor(max_keypoints=400, weights_path=path)
+    images = [Image(value_array=synthetic.synthetic_gray_image(h, w, 60 + q)) for q, (h, w) in enumerate([(240, 320), (200, 264), (123, 157), (240, 320), (264, 200), (192, 256)])]
+    serial = [det.detect_and_describe(im) for im in images]
+    results, errors = {}, []
+
+    def worker(tid):
+        try:
+            for rep in range(2):
+                for q in range(tid, len(images), 3):
+                    results[(rep, q)] = det.detect_and_describe(images[q])
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 2 * len(images) and 1 <= len(det._model._lanes) <= det._model.max_lanes
+    for (rep, q), (kps, desc) in results.items():
+        assert kps == serial[q][0]
+        np.testing.assert_array_equal(desc, serial[q][1])
+    det._model.release_lanes()
+    assert len(det._model._lanes) == 1
+    kps, desc = det.detect_and_describe(images[0])
+    assert kps == serial[0][0] and np.array_equal(desc, serial[0][1])
