@@ -769,6 +769,8 @@ def main() -> None:
                 result["secondary"]["config2_superpoint_480x640"] = leg("config2", config2_superpoint_rate, lib, detector, device, not args.no_cpu_baseline)
                 if args.keypoints > 2500 and (h, w) == (1024, 1024):
                     result["secondary"]["config4_scene_share_cap5000"] = leg("config4", config4_scene_share_rate, args, detector, device, h, w, not args.no_cpu_baseline)
+                    result["secondary"]["config4_scene_share_cap5000_bf16x3"] = leg("config4_bf16x3", config4_scene_share_rate, args, detector, device, h, w,
+                                                                                            not args.no_cpu_baseline, "bf16x3")
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
@@ -1002,7 +1004,7 @@ def config2_superpoint_rate(lib, detector, device, with_oracle: bool):
     return out
 
 
-def config4_scene_share_rate(args, detector, device, h, w, with_oracle: bool):
+def config4_scene_share_rate(args, detector, device, h, w, with_oracle: bool, math: str = "f32"):
     """BASELINE config 4 on the one GPU bench.py is given at N = 1: the HEAVIEST rank's share of the 8-rank job -- 101 views, the
     first 5000 exhaustive pairs, SuperGlue with 100 Sinkhorn iterations, AT THE 5000-KEYPOINT CAP -- exactly as ``--mode scene --gpus 8``
     assigns it (gtsfm_amd.parallel: cyclic image ownership, 2-D cyclic pair ownership on the 2 x 4 process grid). A timed step = this
@@ -1013,6 +1015,19 @@ def config4_scene_share_rate(args, detector, device, h, w, with_oracle: bool):
     from gtsfm_amd.runtime import matcher_engine as ME
     from gtsfm_amd.runtime.pipeline import FrontEndPipeline
 
+    if math != "f32":  # the same leg under the opt-in attention arithmetic (read per call by the C entry points; graphs are captured under it)
+        old = os.environ.get("GTSFM_ATTENTION_MATH")
+        os.environ["GTSFM_ATTENTION_MATH"] = math
+        try:
+            out = config4_scene_share_rate(args, detector, device, h, w, with_oracle, "f32")
+        finally:
+            if old is None:
+                os.environ.pop("GTSFM_ATTENTION_MATH", None)
+            else:
+                os.environ["GTSFM_ATTENTION_MATH"] = old
+        out["dtype"] = "f32 via 3 x bf16 split of both attention products, f32 accumulate (SuperPoint, GEMMs, Sinkhorn: exact f32)"
+        out["workload"] += f"; GTSFM_ATTENTION_MATH={math} (opt-in)"
+        return out
     n, world, scene_pairs, iters = 101, 8, 5000, 100
     all_pairs = parallel.exhaustive_pairs(n)[:scene_pairs]
     shares = [parallel.partition_pairs_2d(all_pairs, r, world) for r in range(world)]
