@@ -760,6 +760,7 @@ def main() -> None:
                 result["secondary"] = sec if "error" not in sec else {"rates": sec}
                 if args.matcher == "lightglue" and args.keypoints > 1024:
                     result["secondary"]["attention_bf16x3"] = leg("bf16x3", attention_bf16x3_rate, args, lib, detector, matcher, images, pairs, shapes, device, ora)
+                    result["secondary"]["matcher_bf16x3"] = leg("matcher_bf16x3", attention_bf16x3_rate, args, lib, detector, matcher, images, pairs, shapes, device, ora, True)
                 if getattr(pipe, "last_shared_images", 0):
                     result["secondary"]["headline_per_pair_first_layer"] = leg("unshared", unshared_rate, args, detector, matcher, images, pairs, shapes, mk)
                 if args.matcher == "lightglue":
@@ -1079,7 +1080,7 @@ def config4_scene_share_rate(args, detector, device, h, w, with_oracle: bool, ma
     return out
 
 
-def attention_bf16x3_rate(args, lib, detector, matcher, images, pairs, shapes, device, oracle_out):
+def attention_bf16x3_rate(args, lib, detector, matcher, images, pairs, shapes, device, oracle_out, gemm_too: bool = False):
     """The opt-in arithmetic GTSFM_ATTENTION_MATH=bf16x3 on the first pairs of the headline workload: both products of every attention
     launch on v_mfma_f32_32x32x16_bf16 with each fp32 operand split exactly into three bf16 pieces (six of the nine piece products, fp32
     accumulation: fp32-class error per product, NOT the exact-fp32 kernel's bits); SuperPoint, the GEMMs, the sweeps stay exact fp32. Own
@@ -1096,17 +1097,24 @@ def attention_bf16x3_rate(args, lib, detector, matcher, images, pairs, shapes, d
     feats = make_pipe().detect(images)
     exact = make_pipe().match(feats, pairs, shapes)
     torch.cuda.synchronize(device)
-    old = os.environ.get("GTSFM_ATTENTION_MATH")
-    os.environ["GTSFM_ATTENTION_MATH"] = "bf16x3"  # read per call by the matcher's C entry points; graphs are captured under it
+    switches = ["GTSFM_ATTENTION_MATH"] + (["GTSFM_GEMM_MATH"] if gemm_too else [])
+    old = {k: os.environ.get(k) for k in switches}
+    for k in switches:
+        os.environ[k] = "bf16x3"  # read per call / per launch by the C entry points; graphs are captured under them
     try:
         pipe = make_pipe()
         res, timing = _time_steps(lambda: pipe.match(pipe.detect(images), pairs, shapes), SECONDARY_STEPS, 1, device)
         roof = measure_attention_roofline(lib, device, args.keypoints, min(args.pair_chunk, len(pairs)), math=1)
+        if gemm_too:
+            rows = 2 * min(args.pair_chunk, len(pairs)) * (-(-args.keypoints // 128) * 128)
+            roof = {"attention": roof, "gemm": [dict(measure_gemm_roofline(lib, device, rows, k, nn), kernel="gemm_dma_walk_kernel<X3>", arithmetic="bf16x3: frac is algorithmic fp32 FLOP/s over the fp32 MFMA roof")
+                                                for k, nn in ((256, 768), (512, 512), (512, 256))]}
     finally:
-        if old is None:
-            os.environ.pop("GTSFM_ATTENTION_MATH", None)
-        else:
-            os.environ["GTSFM_ATTENTION_MATH"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     ms = timing["ms_per_step"]
     same_pairs, dmax, nmatch = 0, 0.0, 0
     for a, b in zip(exact, res):
@@ -1123,11 +1131,12 @@ def attention_bf16x3_rate(args, lib, detector, matcher, images, pairs, shapes, d
             nmatch += int((ma[off : off + int(n0[q])] > -1).sum())
             off += t
     out = {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", **timing, "pairs_per_step": len(pairs), "images_per_step": int(images.shape[0]),
-           "dtype": "f32 via 3 x bf16 split of both attention products, f32 accumulate (SuperPoint, GEMMs, sweeps: exact f32)",
+           "dtype": ("f32 via 3 x bf16 split of the attention products AND the matcher's projection / score GEMMs, f32 accumulate (SuperPoint, sweeps: exact f32)" if gemm_too
+                     else "f32 via 3 x bf16 split of both attention products, f32 accumulate (SuperPoint, GEMMs, sweeps: exact f32)"),
            "matcher_layers_run": float(torch.cat([r["stop"] for r in res]).float().mean()) if res and "stop" in res[0] else None,
            "against_exact_fp32_pipeline": {"pairs_with_identical_match_arrays": same_pairs, "pairs": len(pairs), "max_dscore_on_those": dmax, "matches": nmatch},
            "roofline": roof,
-           "workload": f"the first {len(pairs)} pairs of the headline workload with GTSFM_ATTENTION_MATH=bf16x3 (opt-in; the headline stays exact fp32)"}
+           "workload": f"the first {len(pairs)} pairs of the headline workload with {' and '.join(k + '=bf16x3' for k in switches)} (opt-in; the headline stays exact fp32)"}
     if oracle_out is not None and res:
         a = res[0]["n0"][0]
         out["parity_check"] = parity_check(oracle_out, feats, [pairs[0][0], pairs[0][1]], (res[0]["matches"][:a].cpu().numpy(), res[0]["mscores"][:a].cpu().numpy()))

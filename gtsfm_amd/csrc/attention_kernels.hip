@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "attention_kernels.h"
+#include "bf16x3.h"
 #include "mfma_tiles.h"
 
 #define AT_KT 64       // keys per tile
@@ -592,39 +593,9 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(AttnParams p) {
 // Keys beyond a problem's count are written as zeros by the split kernel (their scores are masked to -inf, P = 0 meets V = 0).
 // ---------------------------------------------------------------------------------------------------------------------
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 #define X3_PIECE_BYTES 8192               // one bf16 piece of a 64 x 64 tile
 #define X3_TILE_BYTES (3 * X3_PIECE_BYTES)  // hi | mid | lo
 #define X3_LDS_BYTES (2 * X3_TILE_BYTES)    // K tile + V^T tile, single-buffered
-
-struct X3Split {
-    unsigned hi, mid, lo;  // fp32 bit patterns whose top 16 bits are the bf16 pieces
-};
-__device__ __forceinline__ X3Split x3_split(float x) {
-    X3Split r;
-    r.hi = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(r.hi);  // exact
-    r.mid = __float_as_uint(r1) & 0xffff0000u;
-    r.lo = __float_as_uint(r1 - __uint_as_float(r.mid));  // exact; truncated to 8 bits when packed
-    return r;
-}
-// two bf16 (the top halves of a and b) in one register, a in the low half
-__device__ __forceinline__ unsigned x3_pack(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-__device__ __forceinline__ bf16x8 x3_frag(const u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
-__device__ __forceinline__ f32x16 x3_mfma(const u32x4 a, const u32x4 b, const f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_frag(a), x3_frag(b), c, 0, 0, 0);
-}
-// acc += A B with A = ah + am + al, B = bh + bm + bl: the six products, smallest first
-__device__ __forceinline__ void x3_product(f32x16& acc0, f32x16& acc1, const u32x4 (&a0)[3], const u32x4 (&a1)[3], const u32x4 (&b)[3]) {
-    acc0 = x3_mfma(a0[2], b[0], acc0), acc1 = x3_mfma(a1[2], b[0], acc1);  // lo hi
-    acc0 = x3_mfma(a0[0], b[2], acc0), acc1 = x3_mfma(a1[0], b[2], acc1);  // hi lo
-    acc0 = x3_mfma(a0[1], b[1], acc0), acc1 = x3_mfma(a1[1], b[1], acc1);  // mid mid
-    acc0 = x3_mfma(a0[1], b[0], acc0), acc1 = x3_mfma(a1[1], b[0], acc1);  // mid hi
-    acc0 = x3_mfma(a0[0], b[1], acc0), acc1 = x3_mfma(a1[0], b[1], acc1);  // hi mid
-    acc0 = x3_mfma(a0[0], b[0], acc0), acc1 = x3_mfma(a1[0], b[0], acc1);  // hi hi
-}
 
 // Byte offset of tile (tensor ten = 0: K, 1: V^T; piece; head h; problem g; key tile t) in the split buffer.
 __device__ __forceinline__ size_t x3_tile_offset(const AttnParams& p, int ten, int piece, int h, int g, int t) {

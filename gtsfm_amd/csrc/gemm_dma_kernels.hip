@@ -4,6 +4,7 @@
 
 #include <stdlib.h>
 
+#include "bf16x3.h"
 #include "gemm_kernels.h"
 #include "gemm_batch.h"
 #include "trace.h"
@@ -45,7 +46,11 @@ __device__ __forceinline__ int dm_swz(int row, int chunk) { return chunk ^ ((row
 // Measured and dropped: a fifth loader wave per workgroup issuing all 32 pieces of a stage (62 %: one stage of slack with two
 // buffers); all 8 pieces inside the first k-step (+-0); bias preloaded into the accumulators / fragments one k-step ahead (+-0).
 // ---------------------------------------------------------------------------------------------------------------
-template <bool HAS_RES, bool ROT, bool LNG = false>
+//   * X3 (round 4, opt-in GTSFM_GEMM_MATH=bf16x3): the same stages, DMA, epilogues -- only the products change: a stage's 32 k are two bf16
+//     k-steps of 16; each lane splits the eight fp32 values of its weight row and of its activation row EXACTLY into three bf16 pieces in
+//     registers (bf16x3.h) and every 32 x 32 x 16 block is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-class error per
+//     term, NOT the bits of the default. 24 + 24 MFMAs of 32 cycles per stage and wave instead of 64 of 64 cycles.
+template <bool HAS_RES, bool ROT, bool LNG = false, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, GemmBatch bt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A 4096 | W 4096]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
         const char* na = baseA + (size_t)dst * (DM_KC * 4);
         const char* nw = baseW + (size_t)dst * (DM_KC * 4);
         if (++dst == nstages) dst = 0, ++dcb;
-        if (last && vec_ok) {
+        if (last && vec_ok && !X3) {  // (X3: the operand pieces need the registers; the epilogue loads them where it uses them)
             // residual values / rotary (cos, sin) pairs of this block, in the epilogue's transposed lane mapping (see below):
             // requested now, in registers when the last MFMAs are done
 #pragma unroll
@@ -187,6 +192,24 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
     c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a0.e, c01, 0, 0, 0); \
     c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.e, a1.e, c10, 0, 0, 0); \
     c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a1.e, c11, 0, 0, 0);
+        if constexpr (X3) {
+            // k-step h of the stage: lane (row, kh) owns floats 16 h + 8 kh .. + 7 of its row = the 16-byte chunks 4 h + 2 kh and 4 h + 2 kh + 1
+            auto frag8 = [&](const float* base, int row, int h, u32x4 (&dst)[3]) {
+                const f32x4 lo4 = *reinterpret_cast<const f32x4*>(base + row * DM_KC + dm_swz(row, 4 * h + 2 * kh) * 4);
+                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(base + row * DM_KC + dm_swz(row, 4 * h + 2 * kh + 1) * 4);
+                x3_split8(lo4, hi4, dst);
+            };
+#pragma unroll
+            for (int h = 0; h < DM_KC / 16; ++h) {
+                u32x4 a0[3], a1[3], b0[3], b1[3];
+                frag8(sA, ra, h, a0), frag8(sA, ra + 32, h, a1);
+                frag8(sW, rw, h, b0), frag8(sW, rw + 32, h, b1);
+                x3_product(c00, c01, b0, b1, a0);  // weights = MFMA A operand (output columns), activations = B operand: a lane owns an output row
+#pragma unroll
+                for (int i = 0; i < 4; ++i) piece(4 * h + i, na, nw, nA, nW);
+                x3_product(c10, c11, b0, b1, a1);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < DM_KC / 8; ++s) {
             const f32x4 a0 = frag(sA, ra, s), a1 = frag(sA, ra + 32, s);
@@ -205,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
             } else {
                 GS(x) GS(y) GS(z) GS(w)
             }
+        }
         }
 #undef GS
         GT_SEG(2)
@@ -251,6 +275,16 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
                         f32x4 v = *reinterpret_cast<const f32x4*>(scr + rr * 32 + ((tc ^ (rr & 7)) << 2));
                         const int row = m0 + 64 * wm + 32 * (t >> 1) + rr;
                         const int col = n0 + 64 * wn + 32 * (t & 1) + 4 * tc;
+                        if (X3) {
+                            if (HAS_RES) {
+                                aux[4 * t + i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                if (row < M && col < N) aux[4 * t + i] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldres + col);
+                            }
+                            if (rot) {
+                                aux[4 * t + i] = f32x4{1.f, 0.f, 1.f, 0.f};
+                                if (row < M) aux[4 * t + i] = *reinterpret_cast<const f32x4*>(p.rot_enc + (size_t)row * 64 + 32 * (t & 1) + 4 * tc);
+                            }
+                        }
                         if (rot) {  // (x0, x1) -> (x0 c - x1 s, x1 c + x0 s) per feature pair, as apply_cached_rotary_emb
                             const f32x4 e = aux[4 * t + i];
                             v = f32x4{(v.x * e.x) + ((-v.y) * e.y), (v.y * e.x) + (v.x * e.y), (v.z * e.z) + ((-v.w) * e.w), (v.w * e.z) + (v.z * e.w)};
@@ -497,6 +531,10 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     // 512->512 107.0 -> 93.9 (640 large tiles), 256->768 72.5 -> 75.6 (960); 40960 rows 512->512 177 -> 193 (1280): the small tiling
     // wins up to ~700 large tiles. GTSFM_GEMM_SMALL_BELOW overrides the threshold (0: never).
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!p.res || (p.ldres & 3) == 0);
+    // GTSFM_GEMM_MATH=bf16x3 (read per launch; NOT bit-identical to the default): launches large enough for the 128 x 128 tiling only --
+    // single pairs (the per-call plugin API) keep the exact small-tile kernel
+    const char* math_env = getenv("GTSFM_GEMM_MATH");
+    const bool x3 = math_env && math_env[0] == 'b';
     const char* small_env = getenv("GTSFM_GEMM_SMALL_BELOW");
     const long long small_below = small_env ? atoll(small_env) : 700LL * gtsfm_cu_count() / 256;  // measured on 256 CUs; scales with the chip
     if (!bt.problems && !bt.ln_gamma && vec_ok && !p.n_dev && nbw == 1 && (long long)mtiles * ncb < small_below) {
@@ -513,6 +551,16 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     }
     const dim3 grid(ceil_div(mtiles, 8) * 8 * ceil_div(ncb, nbw), nprob);
     const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
+    if (x3 && !bt.ln_gamma) {  // opt-in arithmetic (GTSFM_GEMM_MATH=bf16x3): the same launch geometry, stages and epilogues
+        if (q.rot_enc)
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, true, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
+        else if (q.res)
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<true, false, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
+        else
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
+        GTSFM_CHECK_LAUNCH("gemm_dma_walk_kernel (bf16x3)");
+        return GTSFM_OK;
+    }
     if (bt.ln_gamma)
         hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
     else if (q.rot_enc)

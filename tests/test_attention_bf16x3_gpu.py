@@ -82,3 +82,66 @@ def test_bf16x3_two_stream_pipeline_is_deterministic(gpu_device, bf16x3):
         torch.cuda.synchronize()
         for x, y in zip(ref, out):
             assert torch.equal(x["matches"], y["matches"]) and torch.equal(x["mscores"], y["mscores"])
+
+
+@pytest.mark.parametrize("m,k,n,relu,res,m_live,n_live", [(1000, 512, 512, 1, 1, 1000, 512), (131, 256, 768, 0, 0, 131, 768), (640, 512, 256, 0, 1, 640, 132),
+                                                          (4097, 32, 128, 1, 0, 4097, 128), (260, 256, 300, 0, 1, 200, 296)])
+def test_gemm_bf16x3_arithmetic(gpu_device, monkeypatch, m, k, n, relu, res, m_live, n_live):
+    """GTSFM_GEMM_MATH=bf16x3: the LDS-DMA GEMM's products on bf16 MFMA with both operands split exactly into three bf16 pieces in registers,
+    same stages / epilogues / masking as the exact kernel. Against a FLOAT64 reference its error must be of the exact kernel's class (at most
+    twice + 1e-6 of the result's scale), untouched cells stay untouched, and it must NOT be the exact kernel's bits (the switch did something)."""
+    import torch.nn.functional as F
+
+    from gtsfm_amd.runtime import lib as L
+
+    lib = L.load()
+    gen = torch.Generator().manual_seed(m * 3 + k + n)
+    a = torch.randn((m, k), generator=gen)
+    w = torch.randn((n, k), generator=gen) / k**0.5
+    b = torch.randn((n,), generator=gen)
+    r = torch.randn((m, n + 4), generator=gen)
+    ref = F.linear(a.double(), w.double(), b.double()) * 0.5
+    if relu:
+        ref = F.relu(ref)
+    if res:
+        ref = r[:, :n].double() + ref
+    ad, wd, rd = a.to(gpu_device), w.to(gpu_device), r.to(gpu_device)
+    bp = torch.zeros((n + 63) // 64 * 64, device=gpu_device)
+    bp[:n] = b.to(gpu_device)
+    md = torch.tensor([m_live], dtype=torch.int32, device=gpu_device)
+    nd = torch.tensor([n_live], dtype=torch.int32, device=gpu_device)
+    monkeypatch.setenv("GTSFM_GEMM_SMALL_BELOW", "0")  # the 128 x 128 tiling in both runs
+
+    def run(math):
+        monkeypatch.setenv("GTSFM_GEMM_MATH", math)
+        out = torch.full((m, n + 8), -5.0, device=gpu_device)
+        rc = lib.gtsfm_linear_rowmajor_f32(ad.data_ptr(), k, m, md.data_ptr() if m_live < m else None, k, wd.data_ptr(), k, bp.data_ptr(), n,
+                                           nd.data_ptr() if n_live < n else None, out.data_ptr(), n + 8, 4, rd.data_ptr() if res else None, n + 4,
+                                           0.5, relu, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.gtsfm_last_error()
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    exact, x3 = run("f32"), run("bf16x3")
+    for got in (exact, x3):
+        assert torch.all(got[:, :4] == -5.0) and torch.all(got[:, n_live + 4 :] == -5.0) and torch.all(got[m_live:] == -5.0)
+    live = (slice(0, m_live), slice(4, n_live + 4))
+    e_exact = float((exact[live].double() - ref[:m_live, :n_live]).abs().max())
+    e_x3 = float((x3[live].double() - ref[:m_live, :n_live]).abs().max())
+    assert e_x3 <= 2.0 * e_exact + 1e-6 * max(1.0, float(ref.abs().max())), (e_x3, e_exact)
+    assert not torch.equal(exact[live], x3[live])
+
+
+def test_matcher_goldens_under_both_bf16x3_switches(gpu_device, monkeypatch):
+    """Attention AND projection / score GEMMs in the bf16x3 arithmetic (GTSFM_ATTENTION_MATH + GTSFM_GEMM_MATH): the reference-written
+    SuperGlue golden at 5000 x 4800, the HuggingFace-port LightGlue golden at N = 2048 and the LightGlue oracle at the cap still hold --
+    indices identical, scores within 1e-4."""
+    from test_bench_shapes_gpu import LG_BENCH_CASES, test_lightglue_full_depth_vs_oracle, test_superglue_full_depth_matches_reference_golden
+    from test_lightglue_hf_golden_gpu import test_hip_path_equals_the_hf_fixture
+
+    monkeypatch.setenv("GTSFM_ATTENTION_MATH", "bf16x3")
+    monkeypatch.setenv("GTSFM_GEMM_MATH", "bf16x3")
+    monkeypatch.setenv("GTSFM_GEMM_SMALL_BELOW", "0")  # single pairs would otherwise keep the exact small-tile GEMM
+    test_superglue_full_depth_matches_reference_golden(gpu_device, GOLDEN / "bench_superglue_5000x4800_s15_it20.npz")
+    test_hip_path_equals_the_hf_fixture(gpu_device, "n2048_full_depth")
+    test_lightglue_full_depth_vs_oracle(gpu_device, *LG_BENCH_CASES[-1])
