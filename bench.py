@@ -1016,18 +1016,21 @@ def config4_scene_share_rate(args, detector, device, h, w, with_oracle: bool, ma
     from gtsfm_amd.runtime import matcher_engine as ME
     from gtsfm_amd.runtime.pipeline import FrontEndPipeline
 
-    if math != "f32":  # the same leg under the opt-in attention arithmetic (read per call by the C entry points; graphs are captured under it)
-        old = os.environ.get("GTSFM_ATTENTION_MATH")
-        os.environ["GTSFM_ATTENTION_MATH"] = math
+    if math != "f32":  # the same leg under the opt-in arithmetic of attention and GEMMs (read per call / launch by the C side; graphs are captured under it)
+        switches = ("GTSFM_ATTENTION_MATH", "GTSFM_GEMM_MATH")
+        old = {k: os.environ.get(k) for k in switches}
+        for k in switches:
+            os.environ[k] = math
         try:
             out = config4_scene_share_rate(args, detector, device, h, w, with_oracle, "f32")
         finally:
-            if old is None:
-                os.environ.pop("GTSFM_ATTENTION_MATH", None)
-            else:
-                os.environ["GTSFM_ATTENTION_MATH"] = old
-        out["dtype"] = "f32 via 3 x bf16 split of both attention products, f32 accumulate (SuperPoint, GEMMs, Sinkhorn: exact f32)"
-        out["workload"] += f"; GTSFM_ATTENTION_MATH={math} (opt-in)"
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        out["dtype"] = "f32 via 3 x bf16 split of the attention products and the projection / score GEMMs, f32 accumulate (SuperPoint, Sinkhorn, extraction: exact f32)"
+        out["workload"] += f"; GTSFM_ATTENTION_MATH={math} and GTSFM_GEMM_MATH={math} (opt-in)"
         return out
     n, world, scene_pairs, iters = 101, 8, 5000, 100
     all_pairs = parallel.exhaustive_pairs(n)[:scene_pairs]
