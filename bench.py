@@ -185,11 +185,14 @@ def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5, 
     achieved = flops / (ms * 1e-3) / 1e12
     if math == 1:
         executed = 6.0 * flops  # six bf16 products per fp32 product term
+        tx, ts = pmc_traffic(f"attention_x3_kernel@{nseq}x4x{n}"), pmc_traffic(f"attention_x3_split_kernel@{nseq}x4x{n}")
+        traffic = None if tx is None or ts is None else tx["fetch_bytes"] + tx["write_bytes"] + ts["fetch_bytes"] + ts["write_bytes"]
         return {
             "bound": "mfma", "kernel": "attention_x3_split_kernel + attention_x3_kernel", "achieved": round(executed / (ms * 1e-3) / 1e12, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s (executed bf16)", "frac": round(executed / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
             "algorithmic_tflops": round(achieved, 2), "algorithmic_frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "flops_per_launch": flops,
-            "launch_shape": f"{nseq} sequences x 4 heads, N = {n} queries = keys, head_dim 64 (K / V split pass + attention)", "traffic": None,
+            "launch_shape": f"{nseq} sequences x 4 heads, N = {n} queries = keys, head_dim 64 (K / V split pass + attention)", "traffic": traffic,
+            "traffic_note": None if traffic is None else f"HBM-side bytes per launch (split pass + attention, incl. the merged states parked between key segments), rocprofv3 PMC, {tx['source']}",
         }
     t = pmc_traffic(f"attention_dma_kernel@{nseq}x4x{n}")
     return {
