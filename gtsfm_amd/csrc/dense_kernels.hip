@@ -97,29 +97,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
                 patch[tid] = a;
             }
             __syncthreads();
-            for (int idx = tid; idx < CV_HALO_PIX * 16; idx += 256) {
-                const int pix = idx >> 4, q = idx & 15;
-                const int hy = pix / CV_HW, hx = pix % CV_HW;
+            // relu(conv1a) of the 180 halo pixels ON THE MATRIX PIPE (round 4): per pixel and channel v = bias, then v = fmaf(patch[tap], w[tap], v)
+            // for the nine taps in order -- exactly what v_mfma_f32_32x32x2_f32 computes as a k-ordered fmaf chain from the accumulator's
+            // start value (k = tap; a tenth, zero tap fills the fifth instruction: fmaf(0, 0, v) = v). 6 pixel blocks x 2 channel blocks x 5
+            // MFMAs = 60 per workgroup replace 2880 x 36 VALU fmas (rounds 1-3: the fused layer ran at 0.78 - 0.80 of the MFMA peak where the
+            // plain pooled 64 -> 64 layer reaches 0.85; the difference was this staging loop). Bit-identical to the VALU form and to
+            // conv1a_kernel. Weights = A operand (rows = channels), patch values = B operand (columns = pixels): a lane owns a pixel and
+            // receives 4 x 4 consecutive channels, written as four 16-byte stores into the halo tile.
+            for (int chain = wave; chain < 12; chain += 4) {
+                const int pb = chain >> 1, cb = chain & 1;
+                const int pix = 32 * pb + j;
+                const int cpix = pix < CV_HALO_PIX ? pix : CV_HALO_PIX - 1;
+                const int hy = cpix / CV_HW, hx = cpix % CV_HW;
                 const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                    v = *reinterpret_cast<const f32x4*>(&w1[576 + q * 4]);
-                    const float* pa = patch + hy * CV_PATCH_W + hx;  // image pixel (gy - 1, gx - 1)
+                const float* pa = patch + hy * CV_PATCH_W + hx;  // image pixel (gy - 1, gx - 1)
+                f32x16 acc;
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
+                for (int r = 0; r < 16; ++r) acc[r] = w1[576 + 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * kh];
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const float a = pa[ky * CV_PATCH_W + kx];
-                            const f32x4 wt = *reinterpret_cast<const f32x4*>(&w1[(ky * 3 + kx) * 64 + q * 4]);
-                            v.x = fmaf(a, wt.x, v.x);
-                            v.y = fmaf(a, wt.y, v.y);
-                            v.z = fmaf(a, wt.z, v.z);
-                            v.w = fmaf(a, wt.w, v.w);
-                        }
-                    }
-                    v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                for (int s5 = 0; s5 < 5; ++s5) {
+                    const int tap = 2 * s5 + kh;  // k index of this lane half
+                    const bool live = tap < 9;
+                    const int tt = live ? tap : 0;
+                    const float bval = live ? pa[(tt / 3) * CV_PATCH_W + tt % 3] : 0.f;
+                    const float aval = live ? w1[tt * 64 + 32 * cb + j] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bval, acc, 0, 0, 0);
                 }
-                *reinterpret_cast<f32x4*>(&lds[hy * CV_ROW_PITCH + hx * MT_LDS_ROW + q * 4]) = v;
+                const bool inside = pix < CV_HALO_PIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                if (pix < CV_HALO_PIX) {
+                    float* dst = &lds[hy * CV_ROW_PITCH + hx * MT_LDS_ROW + 32 * cb + 4 * kh];
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 v = {fmaxf(acc[4 * g4], 0.f), fmaxf(acc[4 * g4 + 1], 0.f), fmaxf(acc[4 * g4 + 2], 0.f), fmaxf(acc[4 * g4 + 3], 0.f)};
+                        if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};  // conv1b's zero padding, not relu(conv1a) of an outside pixel
+                        *reinterpret_cast<f32x4*>(dst + 8 * g4) = v;
+                    }
+                }
             }
         } else {
             for (int idx = tid; idx < CV_HALO_PIX * 16; idx += 256) {
