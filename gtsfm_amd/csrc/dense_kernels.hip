@@ -173,7 +173,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvParams p) {
     }
 
     const bool cvalid = cout < p.Cout;
-    if (!p.pool) {
+    if (!p.pool && ((p.Cout | p.out_stride | p.out_coff) & 3) == 0) {
+        // Unpooled output, transposed through LDS (round 4): in the accumulator layout a lane owns ONE output channel of 32 pixels, so a
+        // store instruction moves 64 x 4 B and a wave needs 32 of them (the unpooled 64 -> 64 layer ran 5 points below the pooled one:
+        // 0.80 against 0.85, tools/bench_conv.py). Through a 32 x 32 scratch tile per wave -- its slice of the halo tile, which nobody
+        // reads any more -- 8 lanes cover the 128 contiguous bytes of a pixel's 32 channels: 8 store instructions of 64 x 16 B. Same values.
+        __syncthreads();  // every wave is done with the halo tile
+        float* scr = lds + wave * 1024;
+        float* __restrict__ out_t = p.out + (size_t)b * p.H * p.W * p.out_stride + p.out_coff + nb * 64 + wn * 32;
+        const int tp = lane >> 3, tc = lane & 7;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = t ? acc1[r] : acc0[r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                scr[mt_acc_row(r, lane) * 32 + j] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = tp + 8 * i;  // pixel of the wave's 32: tile row 4 wm + 2 t + (row >> 4), column row & 15
+                const f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * 32 + 4 * tc);
+                const int y = y0 + 4 * wm + 2 * t + (row >> 4), x = x0 + (row & 15);
+                if (y < p.H && x < p.W && nb * 64 + wn * 32 + 4 * tc < p.Cout)
+                    *reinterpret_cast<f32x4*>(out_t + ((size_t)y * p.W + x) * p.out_stride + 4 * tc) = v;
+            }
+        }
+    } else if (!p.pool) {
         float* __restrict__ out_b = p.out + (size_t)b * p.H * p.W * p.out_stride + p.out_coff + cout;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
