@@ -386,7 +386,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
 #define DS_A_FLOATS (64 * DM_KC)
 #define DS_STAGE_FLOATS (2 * DS_A_FLOATS)
 
-template <bool HAS_RES, bool ROT>
+// X3 (round 4): the bf16x3 arithmetic of gemm_dma_walk_kernel<..., X3> with the same six products in the same order per block and k-step, so that the
+// two tilings stay bit-identical to each other under GTSFM_GEMM_MATH=bf16x3 as well (batched == single-pair results).
+template <bool HAS_RES, bool ROT, bool X3 = false>
 __global__ __launch_bounds__(256, 4) void gemm_dma_small_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A 2048 | W 2048]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -460,6 +462,18 @@ __global__ __launch_bounds__(256, 4) void gemm_dma_small_kernel(GemmParams p) {
         const float* sA = lds + (st & 1) * DS_STAGE_FLOATS;
         const float* sW = sA + DS_A_FLOATS;
         if (st + 1 < nstages) stage_dma(st + 1, lds + ((st + 1) & 1) * DS_STAGE_FLOATS);  // the other buffer was last read one stage ago
+        if constexpr (X3) {
+#pragma unroll
+            for (int h = 0; h < DM_KC / 16; ++h) {
+                u32x4 a3[3], b3[3];
+                x3_split8(*reinterpret_cast<const f32x4*>(sA + ra * DM_KC + dm_swz(ra, 4 * h + 2 * kh) * 4),
+                          *reinterpret_cast<const f32x4*>(sA + ra * DM_KC + dm_swz(ra, 4 * h + 2 * kh + 1) * 4), a3);
+                x3_split8(*reinterpret_cast<const f32x4*>(sW + rw * DM_KC + dm_swz(rw, 4 * h + 2 * kh) * 4),
+                          *reinterpret_cast<const f32x4*>(sW + rw * DM_KC + dm_swz(rw, 4 * h + 2 * kh + 1) * 4), b3);
+                c = x3_mfma(b3[2], a3[0], c), c = x3_mfma(b3[0], a3[2], c), c = x3_mfma(b3[1], a3[1], c);  // the order of x3_product
+                c = x3_mfma(b3[1], a3[0], c), c = x3_mfma(b3[0], a3[1], c), c = x3_mfma(b3[0], a3[0], c);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < DM_KC / 8; ++s) {
             const f32x4 a = frag(sA, ra, s), b = frag(sW, rw, s);
@@ -468,6 +482,7 @@ __global__ __launch_bounds__(256, 4) void gemm_dma_small_kernel(GemmParams p) {
             c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, c, 0, 0, 0);
+        }
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
@@ -531,8 +546,8 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     // 512->512 107.0 -> 93.9 (640 large tiles), 256->768 72.5 -> 75.6 (960); 40960 rows 512->512 177 -> 193 (1280): the small tiling
     // wins up to ~700 large tiles. GTSFM_GEMM_SMALL_BELOW overrides the threshold (0: never).
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!p.res || (p.ldres & 3) == 0);
-    // GTSFM_GEMM_MATH=bf16x3 (read per launch; NOT bit-identical to the default): launches large enough for the 128 x 128 tiling only --
-    // single pairs (the per-call plugin API) keep the exact small-tile kernel
+    // GTSFM_GEMM_MATH=bf16x3 (read per launch; NOT bit-identical to the default): both tilings and the fused LayerNorm form run the same six
+    // products per block in the same order, so batched == single-pair results stay bit-identical under the switch too
     const char* math_env = getenv("GTSFM_GEMM_MATH");
     const bool x3 = math_env && math_env[0] == 'b';
     const char* small_env = getenv("GTSFM_GEMM_SMALL_BELOW");
@@ -540,7 +555,13 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     if (!bt.problems && !bt.ln_gamma && vec_ok && !p.n_dev && nbw == 1 && (long long)mtiles * ncb < small_below) {
         const dim3 sgrid(ceil_div(p.M, 64) * ceil_div(p.N, 64));
         const size_t slds = (size_t)2 * DS_STAGE_FLOATS * sizeof(float);
-        if (q.rot_enc)
+        if (x3 && q.rot_enc)
+            hipLaunchKernelGGL((gemm_dma_small_kernel<false, true, true>), sgrid, dim3(256), slds, stream, q);
+        else if (x3 && q.res)
+            hipLaunchKernelGGL((gemm_dma_small_kernel<true, false, true>), sgrid, dim3(256), slds, stream, q);
+        else if (x3)
+            hipLaunchKernelGGL((gemm_dma_small_kernel<false, false, true>), sgrid, dim3(256), slds, stream, q);
+        else if (q.rot_enc)
             hipLaunchKernelGGL((gemm_dma_small_kernel<false, true>), sgrid, dim3(256), slds, stream, q);
         else if (q.res)
             hipLaunchKernelGGL((gemm_dma_small_kernel<true, false>), sgrid, dim3(256), slds, stream, q);
@@ -551,8 +572,10 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     }
     const dim3 grid(ceil_div(mtiles, 8) * 8 * ceil_div(ncb, nbw), nprob);
     const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
-    if (x3 && !bt.ln_gamma) {  // opt-in arithmetic (GTSFM_GEMM_MATH=bf16x3): the same launch geometry, stages and epilogues
-        if (q.rot_enc)
+    if (x3) {  // opt-in arithmetic (GTSFM_GEMM_MATH=bf16x3): the same launch geometry, stages and epilogues
+        if (bt.ln_gamma)
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false, true, true>), grid, dim3(256), lds_bytes, stream, q, bt);
+        else if (q.rot_enc)
             hipLaunchKernelGGL((gemm_dma_walk_kernel<false, true, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
         else if (q.res)
             hipLaunchKernelGGL((gemm_dma_walk_kernel<true, false, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);

@@ -79,7 +79,7 @@ int gtsfm_linear_f32(const float* a_dev, int lda, int m, const int32_t* m_dev, i
 /* Same operation with the weights (or a second activation matrix) given row-major, W[n][ldw] as nn.Linear stores them:
  * both operands then travel by LDS-DMA (k % 32 == 0 and ldw % 4 == 0 required). n_dev (optional): column count in
  * device memory (<= n).                                                        same reference lines as gtsfm_linear_f32
- * Environment (read per launch): GTSFM_GEMM_MATH=bf16x3 runs launches of 700 or more 128 x 128 tiles in the opt-in arithmetic of
+ * Environment (read per launch): GTSFM_GEMM_MATH=bf16x3 runs the product (either tiling) in the opt-in arithmetic of
  * gtsfm_attention_math_f32 (operands split exactly into three bf16 pieces, six bf16 MFMA products per block, fp32 accumulation:
  * fp32-class error, NOT the default's bits); the default is exact fp32 and every parity statement is made with it. */
 int gtsfm_linear_rowmajor_f32(const float* a_dev, int lda, int m, const int32_t* m_dev, int k, const float* w_dev, int ldw,
