@@ -1205,6 +1205,33 @@ def plugin_api_rate(args, pipe, views_np, device, h, w):
                 for th in ths:
                     th.join()
                 threaded[str(nthreads)] = round(2 * len(pairs) / (time.perf_counter() - t0), 1)
+        # the same calls under the opt-in arithmetic (both switches; the image cache is emptied so that nothing computed in exact fp32 is reused)
+        x3 = {}
+        try:
+            mt._model.release_lanes()
+            old_env = {k: os.environ.get(k) for k in ("GTSFM_ATTENTION_MATH", "GTSFM_GEMM_MATH")}
+            os.environ.update({"GTSFM_ATTENTION_MATH": "bf16x3", "GTSFM_GEMM_MATH": "bf16x3"})
+            try:
+                got_x3, each_x3 = [], []
+                for rep in range(2):  # the first round uploads the images (misses), the second is all hits
+                    got_x3, each_x3 = [], []
+                    for i, j in pairs:
+                        t0 = time.perf_counter()
+                        got_x3.append(mt.match(feats[i][0], feats[j][0], feats[i][1], feats[j][1], shape, shape))
+                        each_x3.append(time.perf_counter() - t0)
+            finally:
+                for k, v in old_env.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+                mt._model.release_lanes()
+            per = float(np.median(each_x3))
+            x3 = {"match_ms_per_pair_resident": round(per * 1e3, 2), "pairs_per_s_match_only_resident": round(1.0 / per, 1),
+                  "calls_with_match_arrays_identical_to_exact_fp32": int(sum(np.array_equal(a, b) for a, b in zip(got, got_x3))), "calls": len(pairs),
+                  "switches": "GTSFM_ATTENTION_MATH=bf16x3 GTSFM_GEMM_MATH=bf16x3 (opt-in)"}
+        except Exception as exc:  # noqa: BLE001 - a side measurement must not cost the leg
+            x3 = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
     # the same pair through the batched, device-resident pipeline (device top-k keeps detection order, the plugin's Keypoints.get_top_k does
     # not, so the index pairs are compared as coordinate pairs)
     dev_feats = pipe.detect(torch.from_numpy(views_np[:n_img]).to(device))
@@ -1225,6 +1252,8 @@ def plugin_api_rate(args, pipe, views_np, device, h, w):
         "value_note": f"exhaustive scene of the headline's shape ({args.images} images, {args.pairs} pairs): 1 / (match + detect x images / pairs), PCIe and per-call synchronisation included",
         "keypoints_per_image": [int(min(len(f[0]) for f in feats)), int(max(len(f[0]) for f in feats))], "matches_first_pair": int(len(got[0])),
         "first_pair_equals_batched_pipeline": bool(ref_set == got_set),
+        "bf16x3": x3,
+        "match_ms_per_pair_resident": round(float(np.median(each[5:])) * 1e3, 2), "pairs_per_s_match_only_resident": round(1.0 / float(np.median(each[5:])), 1),
         "workload": f"SuperPointDetectorDescriptor.detect_and_describe x {n_img} + {type(mt).__name__}.match x {len(pairs)} (numpy in / numpy out, one call at a time)",
     }
 
