@@ -573,7 +573,8 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(AttnParams p) {
 //   x = hi + mid + lo EXACTLY: hi = x truncated to its top 8 significant bits (a bf16), mid = (x - hi) truncated, lo = the rest
 //   (8 + 8 + 8 = the 24 bits of an fp32 significand; bf16 shares fp32's exponent range). A product x y is then the sum of nine
 //   bf16 x bf16 products, each EXACT in fp32; six of them are executed -- hi hi, hi mid, mid hi, mid mid, hi lo, lo hi -- and the
-//   three dropped ones (mid lo, lo mid: 2^-24 |x y| each; lo lo: 2^-32) are below one fp32 rounding of the product. The sums
+//   three dropped ones (mid lo, lo mid: ~2^-24 |x y| each, < 2^-22 |x y| worst case because the split truncates; lo lo: 2^-30) are of the
+//   order of one fp32 rounding of the product (tests/test_bf16x3_host.py). The sums
 //   accumulate in fp32 inside the MFMA. So every score and every output element carries fp32-class error (the same 2^-24-per-term
 //   class as the fmaf chain of v_mfma_f32_32x32x2_f32), but NOT the same bits: this mode is not bit-identical to the exact-fp32
 //   kernel above, which stays the default and the one every parity statement is made with.

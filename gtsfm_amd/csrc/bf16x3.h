@@ -1,6 +1,6 @@
 // The "bf16x3" arithmetic shared by the opt-in attention and GEMM kernels: an fp32 number is split EXACTLY into three bf16 pieces
 // (8 + 8 + 8 significand bits), a product of two such numbers is executed as six bf16 x bf16 MFMA products with fp32 accumulation
-// (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi; the three dropped products are below 2^-23 of the term). See attention_kernels.hip.
+// (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi; the three dropped products are ~2^-24 of the term, below 2^-21 of it in the worst case). See attention_kernels.hip.
 #pragma once
 
 #include "common.h"

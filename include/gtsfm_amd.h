@@ -210,7 +210,7 @@ int gtsfm_attention_split_f32(const float* q_dev, int ldq, const float* k_dev, i
  * the default everywhere and the arithmetic every parity statement of this package is made with). math 1 = "bf16x3": both products
  * (K Q^T and P V) on v_mfma_f32_32x32x16_bf16 with each fp32 operand split EXACTLY into three bf16 pieces (8 + 8 + 8 significand
  * bits) and six of the nine piece products executed, fp32 accumulation -- fp32-class error per product term (the dropped terms are
- * below 2^-23 of it), NOT the same bits as math 0, 3/8 of its matrix-pipe time. Opt-in: the matchers take it from the environment
+ * ~2^-24 of it, below 2^-21 in the worst case), NOT the same bits as math 0, 3/8 of its matrix-pipe time. Opt-in: the matchers take it from the environment
  * variable GTSFM_ATTENTION_MATH=bf16x3 (read per call). max_k must be given (> 0); the workspace additionally holds the split K / V
  * tiles (6 x heads x nproblems x ceil(max_k / 64) x 8 KiB). */
 size_t gtsfm_attention_math_workspace_bytes(int nproblems, int max_q, int max_k, int heads, size_t rows, int math);
