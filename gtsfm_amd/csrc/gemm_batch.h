@@ -16,11 +16,6 @@ struct GemmBatch {
     const GemmProblem* problems;  // device, [nproblems]
     const int* counts;            // device
     int nproblems;
-    // optional LayerNorm + GELU over the N = 512 output columns (LightGlue's ffn.1 / ffn.2 behind ffn.0): the workgroup walks
-    // all four column blocks of its row tile, then normalises and activates its own 128 rows in place (the rows are L2-hot and
-    // the pass runs beside the other workgroups' MFMAs) -- the separate layernorm_gelu_kernel and its HBM round trip go away
-    const float* ln_gamma;
-    const float* ln_beta;
 };
 
 int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_t stream);

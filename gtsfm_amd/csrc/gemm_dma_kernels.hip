@@ -42,15 +42,17 @@ __device__ __forceinline__ int dm_swz(int row, int chunk) { return chunk ^ ((row
 //   * ROT: LightGlue's rotary embedding (apply_cached_rotary_emb) on the q and k column blocks in the epilogue,
 //     enc = [token][f][cos, sin];
 //   * ragged batches: per-tile live counts (LightGlue's 128-row-aligned sequences) or a problem table (GemmBatch);
-//   * LNG: LayerNorm + GELU of the workgroup's own rows after its last column block (LightGlue's FFN).
 // Measured and dropped: a fifth loader wave per workgroup issuing all 32 pieces of a stage (62 %: one stage of slack with two
-// buffers); all 8 pieces inside the first k-step (+-0); bias preloaded into the accumulators / fragments one k-step ahead (+-0).
+// buffers); all 8 pieces inside the first k-step (+-0); bias preloaded into the accumulators / fragments one k-step ahead (+-0);
+// LayerNorm + GELU of the workgroup's own rows after its last column block (rounds 2-4, GTSFM_FUSED_LN: the workgroup has to walk all four
+// column blocks of its row tile -- batched workload 495.8-499.9 against 500.1-501.3 image-pairs/s with the separate kernel, one pair at the cap
+// 13.5 against 11.5 ms (80 workgroups on 256 CUs): slower in both, removed in round 4).
 // ---------------------------------------------------------------------------------------------------------------
 //   * X3 (round 4, opt-in GTSFM_GEMM_MATH=bf16x3): the same stages, DMA, epilogues -- only the products change: a stage's 32 k are two bf16
 //     k-steps of 16; each lane splits the eight fp32 values of its weight row and of its activation row EXACTLY into three bf16 pieces in
 //     registers (bf16x3.h) and every 32 x 32 x 16 block is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-class error per
 //     term, NOT the bits of the default. 24 + 24 MFMAs of 32 cycles per stage and wave instead of 64 of 64 cycles.
-template <bool HAS_RES, bool ROT, bool LNG = false, bool X3 = false>
+template <bool HAS_RES, bool ROT, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, GemmBatch bt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A 4096 | W 4096]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -313,53 +315,6 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
         GT_SEG(4)
         if (++st == nstages) st = 0, ++cbi;
     }
-    if (LNG) {
-        // y = GELU(LayerNorm(x)) over this workgroup's rows, 512 columns, in place (eps 1e-5, affine; two-pass statistics as
-        // torch.nn.functional.layer_norm -- the same arithmetic as layernorm_gelu_kernel). The stores above are this
-        // workgroup's own: visible to its waves after the barrier.
-        __syncthreads();
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(bt.ln_gamma + lane * 8), g1 = *reinterpret_cast<const f32x4*>(bt.ln_gamma + lane * 8 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bt.ln_beta + lane * 8), b1 = *reinterpret_cast<const f32x4*>(bt.ln_beta + lane * 8 + 4);
-        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll 1
-        for (int r0 = 0; r0 < 32; r0 += 4) {
-            const int row0 = m0 + 32 * wave + r0;
-            if (row0 >= M) break;
-            f32x4 xa[4], xb[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* src = p.C + (size_t)min(row0 + r, M - 1) * p.ldc + p.c_coff + lane * 8;
-                xa[r] = *reinterpret_cast<const f32x4*>(src);
-                xb[r] = *reinterpret_cast<const f32x4*>(src + 4);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (row0 + r >= M) break;
-                float v[8] = {xa[r].x, xa[r].y, xa[r].z, xa[r].w, xb[r].x, xb[r].y, xb[r].z, xb[r].w};
-                float sum = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sum += v[e];
-                const float mean = wave_sum(sum) / 512.0f;
-                float ssq = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float d = v[e] - mean;
-                    ssq += d * d;
-                }
-                const float var = wave_sum(ssq) / 512.0f;
-                const float rstd = 1.0f / sqrtf(var + 1e-5f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float y = (v[e] - mean) * rstd * gm[e] + be[e];
-                    v[e] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
-                }
-                float* dst = p.C + (size_t)(row0 + r) * p.ldc + p.c_coff + lane * 8;
-                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            }
-        }
-    }
 #ifdef GTSFM_TRACE
     if (lane == 0 && g_gemm_trace) {
         unsigned long long* o = g_gemm_trace + ((size_t)blockIdx.x * 4 + wave) * 8;
@@ -512,7 +467,7 @@ bool gemm_uses_dma(int K, int ldw) {
 }
 
 int launch_gemm_dma(const GemmParams& p, hipStream_t stream) {
-    GemmBatch none = {nullptr, nullptr, 0, nullptr, nullptr};
+    GemmBatch none = {nullptr, nullptr, 0};
     return launch_gemm_dma_batched(p, none, stream);
 }
 
@@ -534,11 +489,6 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     int nbw = 1;
     static const char* env = getenv("GTSFM_GEMM_NB");
     if (env && atoi(env) > 0) nbw = atoi(env) < ncb ? atoi(env) : ncb;
-    if (bt.ln_gamma) {  // the fused LayerNorm needs every column of a row in one workgroup
-        GTSFM_CHECK_ARG(bt.ln_beta && p.N == 512 && !p.n_dev && !p.res && !p.rot_enc && !bt.problems && p.ldc % 4 == 0 && p.c_coff % 4 == 0 && !p.relu,
-                        "gemm: the LayerNorm + GELU epilogue serves plain 512-column products with 16-byte aligned rows");
-        nbw = ncb;
-    }
     q.nb_per_wg = nbw;
     // Small launches take 64 x 64 tiles (gemm_dma_small_kernel: bit-identical results). Measured (tools/bench_gemm_small.py, us per
     // launch, 128 x 128 -> 64 x 64 tiles): 4096 rows (one pair at N = 2048) 512->256 36.8 -> 15.3, 512->512 39.1 -> 24.6, 256->768
@@ -546,13 +496,13 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     // 512->512 107.0 -> 93.9 (640 large tiles), 256->768 72.5 -> 75.6 (960); 40960 rows 512->512 177 -> 193 (1280): the small tiling
     // wins up to ~700 large tiles. GTSFM_GEMM_SMALL_BELOW overrides the threshold (0: never).
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!p.res || (p.ldres & 3) == 0);
-    // GTSFM_GEMM_MATH=bf16x3 (read per launch; NOT bit-identical to the default): both tilings and the fused LayerNorm form run the same six
+    // GTSFM_GEMM_MATH=bf16x3 (read per launch; NOT bit-identical to the default): both tilings run the same six
     // products per block in the same order, so batched == single-pair results stay bit-identical under the switch too
     const char* math_env = getenv("GTSFM_GEMM_MATH");
     const bool x3 = math_env && math_env[0] == 'b';
     const char* small_env = getenv("GTSFM_GEMM_SMALL_BELOW");
     const long long small_below = small_env ? atoll(small_env) : 700LL * gtsfm_cu_count() / 256;  // measured on 256 CUs; scales with the chip
-    if (!bt.problems && !bt.ln_gamma && vec_ok && !p.n_dev && nbw == 1 && (long long)mtiles * ncb < small_below) {
+    if (!bt.problems && vec_ok && !p.n_dev && nbw == 1 && (long long)mtiles * ncb < small_below) {
         const dim3 sgrid(ceil_div(p.M, 64) * ceil_div(p.N, 64));
         const size_t slds = (size_t)2 * DS_STAGE_FLOATS * sizeof(float);
         if (x3 && q.rot_enc)
@@ -573,20 +523,16 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     const dim3 grid(ceil_div(mtiles, 8) * 8 * ceil_div(ncb, nbw), nprob);
     const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
     if (x3) {  // opt-in arithmetic (GTSFM_GEMM_MATH=bf16x3): the same launch geometry, stages and epilogues
-        if (bt.ln_gamma)
-            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false, true, true>), grid, dim3(256), lds_bytes, stream, q, bt);
-        else if (q.rot_enc)
-            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, true, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
+        if (q.rot_enc)
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, true, true>), grid, dim3(256), lds_bytes, stream, q, bt);
         else if (q.res)
-            hipLaunchKernelGGL((gemm_dma_walk_kernel<true, false, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<true, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
         else
-            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
         GTSFM_CHECK_LAUNCH("gemm_dma_walk_kernel (bf16x3)");
         return GTSFM_OK;
     }
-    if (bt.ln_gamma)
-        hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
-    else if (q.rot_enc)
+    if (q.rot_enc)
         hipLaunchKernelGGL((gemm_dma_walk_kernel<false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
     else if (q.res)
         hipLaunchKernelGGL((gemm_dma_walk_kernel<true, false>), grid, dim3(256), lds_bytes, stream, q, bt);

@@ -413,7 +413,7 @@ static int sg_forward_phased(const float* wts, int num_layers, float bin_score, 
         GemmParams g;
         memset(&g, 0, sizeof(g));
         g.A = MD, g.lda = 256, g.M = d.max_n0, g.K = 256, g.wraw = MD, g.ldw = 256, g.N = d.max_n1, g.C = Z, g.alpha = 0.0625f;
-        GemmBatch bt = {(const GemmProblem*)(desc_dev + DL.score_p), counts, npairs, nullptr, nullptr};
+        GemmBatch bt = {(const GemmProblem*)(desc_dev + DL.score_p), counts, npairs};
         TRY(launch_gemm_dma_batched(g, bt, stream));
     } else {
         int row = 0;
@@ -674,29 +674,11 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
         return launch_gemm(g, stream);
     };
     auto ffn = [&](float* Xc) -> int {  // x + ffn(cat[x, message])
-        // GTSFM_FUSED_LN=1: ffn.0 with LayerNorm + GELU applied by the GEMM's workgroups to their own rows (bit-identical results;
-        // layernorm_gelu_kernel and its 537 MB round trip disappear). Measured in the workload, three runs each: 495.8 / 499.1 /
-        // 499.9 image-pairs/s fused against 501.3 / 500.5 / 500.1 with the separate kernel (one stream: 489.0 vs 492.6) -- the
-        // fused form has to walk all four column blocks per workgroup (-1.5 % on that GEMM) and the separate kernel's HBM-bound
-        // pass already overlaps the other stream's MFMA-bound kernels. So the separate kernel stays the default.
-        const char* ln_env = getenv("GTSFM_FUSED_LN");
-        if (gemm_uses_dma(512, 512) && ln_env && ln_env[0] == '1') {
-            const float *w, *b, *raw;
-            cur.linear(512, 512, &w, &b, &raw);
-            GemmParams g;
-            memset(&g, 0, sizeof(g));
-            g.A = Xc, g.lda = 512, g.M = d.Tp, g.K = 512, g.wpack = w, g.wraw = raw, g.ldw = 512, g.bias = b, g.N = 512;
-            g.C = MLP, g.ldc = 512, g.alpha = 1.0f;
-            g.tile_cnt_idx = tile_idx, g.tile_row0 = tile_row0, g.live_counts = live;
-            GemmBatch ex = {nullptr, nullptr, 0, cur.raw(512), nullptr};
-            ex.ln_beta = cur.raw(512);
-            TRY(launch_gemm_dma_batched(g, ex, stream));
-        } else {
-            TRY(gemm(Xc, 512, 512, 512, MLP, 512, 0, nullptr, 0, 1.0f, live));
-            const float* gamma = cur.raw(512);
-            const float* beta = cur.raw(512);
-            TRY(launch_layernorm_gelu(MLP, 512, seqs, live, nseq, d.max_n, gamma, beta, stream));
-        }
+        // (LayerNorm + GELU inside the ffn.0 GEMM was an opt-in in rounds 2-4; slower batched and single-pair, removed: gemm_dma_kernels.hip)
+        TRY(gemm(Xc, 512, 512, 512, MLP, 512, 0, nullptr, 0, 1.0f, live));
+        const float* gamma = cur.raw(512);
+        const float* beta = cur.raw(512);
+        TRY(launch_layernorm_gelu(MLP, 512, seqs, live, nseq, d.max_n, gamma, beta, stream));
         TRY(gemm(MLP, 512, 512, 256, Xc, 512, 0, Xc, 512, 1.0f, live));
         return GTSFM_OK;
     };
@@ -770,7 +752,7 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
         GemmParams g;
         memset(&g, 0, sizeof(g));
         g.A = MD, g.lda = 256, g.M = d.max_n0, g.K = 256, g.wraw = MD, g.ldw = 256, g.N = d.max_n1, g.C = Z, g.alpha = 1.0f;
-        GemmBatch bt = {(const GemmProblem*)(desc_dev + DL.score_p), final_cnt, npairs, nullptr, nullptr};
+        GemmBatch bt = {(const GemmProblem*)(desc_dev + DL.score_p), final_cnt, npairs};
         TRY(launch_gemm_dma_batched(g, bt, stream));
     } else {
         size_t zoff = 0;

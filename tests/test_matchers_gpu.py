@@ -573,28 +573,6 @@ def test_eight_wave_sweep_tier_vs_oracle(gpu_device, matcher):
     assert (res["matches0"] > -1).sum() > 10
 
 
-def test_lightglue_fused_layernorm_epilogue_is_bit_identical(gpu_device, monkeypatch):
-    """GTSFM_FUSED_LN=1: LayerNorm + GELU applied by the ffn.0 GEMM's workgroups to their own rows (opt-in)
-    must give the same bits as the separate layernorm_gelu_kernel, incl. ragged sequences and early-stopped pairs."""
-    from gtsfm_amd.runtime.matcher_engine import LightGlueEngine
-
-    sd = synthetic.synthetic_lightglue_state_dict(num_layers=4, conf_bias=2.0, conf_gain=6.0, match_bias=1.0, match_gain=12.0)
-    eng = LightGlueEngine(sd, gpu_device)
-    pairs = [synthetic.synthetic_pair_features(n0, n1, (480, 640), (480, 640), seed=40 + i) for i, (n0, n1) in enumerate([(300, 280), (129, 700), (513, 64)])]
-    kp = T(np.concatenate([np.concatenate([p[0], p[3]]) for p in pairs])).to(gpu_device)
-    de = T(np.concatenate([np.concatenate([p[2], p[5]]) for p in pairs])).to(gpu_device)
-    n0, n1 = [len(p[0]) for p in pairs], [len(p[3]) for p in pairs]
-    hw = [[480, 640, 480, 640]] * 3
-    monkeypatch.setenv("GTSFM_FUSED_LN", "0")
-    a = eng.match_batch(kp, de, n0, n1, hw)
-    monkeypatch.setenv("GTSFM_FUSED_LN", "1")
-    b = eng.match_batch(kp, de, n0, n1, hw)
-    torch.cuda.synchronize()
-    for key in ("matches", "mscores", "stop", "kept"):
-        assert torch.equal(a[key], b[key]), key
-    assert int((a["matches"] > -1).sum()) > 100
-
-
 def test_lightglue_plugin_contract(gpu_device, tmp_path):
     """LightGlueMatcher.match (gtsfm/frontend/matcher/lightglue_matcher.py:43-112): (K,2) int64, in range,
     one-to-one, empty input -> empty result, ValueError without responses."""
