@@ -34,11 +34,13 @@ __global__ __launch_bounds__(256) void lg_store_rows_kernel(const float* __restr
 
 // check_if_stop for layer `layer`: ratio of confident points (pruned points count as confident) > depth_confidence.
 // One workgroup per pair. Also maintains the per-layer "assign" counts: the keypoint sets of the pairs that stop at
-// this layer (or at the last layer) get their final / assign counts set and their live counts zeroed.
+// this layer (or at the last layer) get their final / assign counts set and their live counts zeroed, and their kept-index lists
+// are copied to a stable array (later pruning steps ping-pong the live buffers; a kernel of its own until round 4).
 __global__ __launch_bounds__(256) void lg_stop_check_kernel(const float* __restrict__ conf, const SeqDesc* __restrict__ seqs,
                                                             int* __restrict__ live, int* __restrict__ final_cnt, int* __restrict__ assign,
                                                             const int* __restrict__ orig, int* __restrict__ stop_layer, int layer,
-                                                            int last_layer, float conf_threshold, float depth_confidence) {
+                                                            int last_layer, float conf_threshold, float depth_confidence,
+                                                            const int* __restrict__ ind_cur, int* __restrict__ ind_final) {
     __shared__ int wsum[4];
     const int p = blockIdx.x;
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
@@ -58,7 +60,10 @@ __global__ __launch_bounds__(256) void lg_stop_check_kernel(const float* __restr
         const float ratio = 1.0f - (float)total / (float)(orig[2 * p] + orig[2 * p + 1]);
         stop = ratio > depth_confidence;
     }
-    if (stop && threadIdx.x == 0) {
+    if (!stop) return;  // uniform
+    for (int i = threadIdx.x; i < c0; i += 256) ind_final[s0.row_off + i] = ind_cur[s0.row_off + i];
+    for (int i = threadIdx.x; i < c1; i += 256) ind_final[s1.row_off + i] = ind_cur[s1.row_off + i];
+    if (threadIdx.x == 0) {
         stop_layer[p] = layer;
         final_cnt[2 * p] = assign[2 * p] = c0;
         final_cnt[2 * p + 1] = assign[2 * p + 1] = c1;
@@ -169,10 +174,11 @@ int launch_lg_store_rows(const float* X, int ldx, const SeqDesc* seqs, const int
 }
 
 int launch_lg_stop_check(const float* conf, const SeqDesc* seqs, int* live, int* final_cnt, int* assign, const int* orig, int* stop_layer,
-                         int npairs, int layer, int last_layer, float conf_threshold, float depth_confidence, hipStream_t stream) {
+                         int npairs, int layer, int last_layer, float conf_threshold, float depth_confidence, const int* ind_cur, int* ind_final,
+                         hipStream_t stream) {
     if (npairs <= 0) return GTSFM_OK;
     hipLaunchKernelGGL(lg_stop_check_kernel, dim3(npairs), dim3(256), 0, stream, conf, seqs, live, final_cnt, assign, orig, stop_layer, layer,
-                       last_layer, conf_threshold, depth_confidence);
+                       last_layer, conf_threshold, depth_confidence, ind_cur, ind_final);
     GTSFM_CHECK_LAUNCH("lg_stop_check_kernel");
     return GTSFM_OK;
 }
@@ -201,18 +207,3 @@ int launch_lg_scatter_matches(const SeqDesc* seqs, const int* final_cnt, const i
     return GTSFM_OK;
 }
 
-// A pair that stops keeps its kept-index list in a stable array (later pruning steps ping-pong the live buffers).
-__global__ void lg_save_ind_kernel(const SeqDesc* __restrict__ seqs, const int* __restrict__ assign, const int* __restrict__ ind_cur,
-                                   int* __restrict__ ind_final) {
-    const SeqDesc sq = seqs[blockIdx.y];
-    const int n = assign[sq.cnt_idx];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        ind_final[sq.row_off + i] = ind_cur[sq.row_off + i];
-}
-
-int launch_lg_save_ind(const SeqDesc* seqs, const int* assign, const int* ind_cur, int* ind_final, int nseq, int max_n, hipStream_t stream) {
-    if (nseq <= 0 || max_n <= 0) return GTSFM_OK;
-    hipLaunchKernelGGL(lg_save_ind_kernel, dim3(ceil_div(max_n, 256), nseq), dim3(256), 0, stream, seqs, assign, ind_cur, ind_final);
-    GTSFM_CHECK_LAUNCH("lg_save_ind_kernel");
-    return GTSFM_OK;
-}

@@ -726,19 +726,21 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
         const float* w_match = cur.raw(256);
         const float* w_conf = (l < num_layers - 1) ? cur.raw(256) : nullptr;
         const float thr = (float)fmin(fmax(0.8 + 0.1 * exp(-4.0 * l / num_layers), 0.0), 1.0);
-        if (w_conf) TRY(launch_rowdot(X, 512, seqs, live, nseq, d.max_n, w_conf, conf_bias_host[l], 1, conf, stream));
-        TRY(launch_lg_stop_check(conf, seqs, live, final_cnt, assign, orig, stop_layer, npairs, l, num_layers - 1, thr, depth_confidence, stream));
+        // both heads over the live tokens in one pass: conf (depth / width), the matchability logit (kept by the pairs that stop here) and
+        // its sigmoid (pruning); the index lists of the pairs that stop are frozen by the stop check itself
+        const bool prune_here = do_prune && l < num_layers - 1;
+        TRY(launch_lg_heads(X, 512, seqs, live, nseq, d.max_n, w_conf, w_conf ? conf_bias_host[l] : 0.f, w_match, match_bias_host[l], conf, z_logit,
+                            prune_here ? mval : nullptr, stream));
+        TRY(launch_lg_stop_check(conf, seqs, live, final_cnt, assign, orig, stop_layer, npairs, l, num_layers - 1, thr, depth_confidence, ind, ind_final,
+                                 stream));
         {
-            // pairs that stopped at this layer: mdesc = final_proj(x) / 256^(1/4), z = matchability(x), freeze their index lists
+            // pairs that stopped at this layer: mdesc = final_proj(x) / 256^(1/4)
             const size_t keep = cur.off;
             cur.off = fp_off;
             TRY(gemm(X, 512, 256, 256, MD, 256, 0, nullptr, 0, 0.25f, assign));
             cur.off = keep;
-            TRY(launch_rowdot(X, 512, seqs, assign, nseq, d.max_n, w_match, match_bias_host[l], 0, z_logit, stream));
-            TRY(launch_lg_save_ind(seqs, assign, ind, ind_final, nseq, d.max_n, stream));
         }
-        if (do_prune && l < num_layers - 1) {
-            TRY(launch_rowdot(X, 512, seqs, live, nseq, d.max_n, w_match, match_bias_host[l], 1, mval, stream));
+        if (prune_here) {
             TRY(launch_lg_prune(conf, mval, seqs, live, old_cnt, pos, nseq, d.max_n, thr, (float)(1.0 - (double)width_confidence), pruning_threshold,
                                 depth_confidence > 0.f ? 1 : 0, X, Xalt, 512, enc, enc_alt, ind, ind_alt, stream));
             float* tx = X; X = Xalt; Xalt = tx;

@@ -58,8 +58,8 @@ int launch_lg_rotary(float* qkv, int ld, int ncols, const float* enc, const SeqD
                      hipStream_t stream);
 int launch_layernorm_gelu(float* x, int ld, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* gamma,
                           const float* beta, hipStream_t stream);
-int launch_rowdot(const float* x, int ld, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* w, float b, int act,
-                  float* out, hipStream_t stream);
+int launch_lg_heads(const float* x, int ld, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* w_conf, float b_conf,
+                    const float* w_match, float b_match, float* conf, float* z, float* mval, hipStream_t stream);
 // Score-matrix sweeps (sweep_kernels.hip): register-resident rows (a wave per row up to 2048 columns, a workgroup per row up to 10240), LDS-staged rows beyond
 int launch_sinkhorn(const SweepArgs& a, float bin_score, int iters, hipStream_t stream);
 int launch_double_softmax_lse(const SweepArgs& a, hipStream_t stream);

@@ -126,22 +126,34 @@ __global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__
     }
 }
 
-// out[t] = act(dot(x[t, :256], w) + b): token-confidence and matchability heads (Linear(256, 1)). One wave per token.
-// act: 0 = identity, 1 = sigmoid
-__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, int ld, const SeqDesc* __restrict__ seqs,
-                                                     const int* __restrict__ counts, const float* __restrict__ w, float b, int act,
-                                                     float* __restrict__ out) {
+// LightGlue's two Linear(256, 1) heads over the live tokens of a layer in ONE pass over x (lightglue.py: TokenConfidence.forward,
+// MatchAssignment.get_matchability): conf[t] = sigmoid(x_t . w_conf + b_conf) (adaptive depth / width; absent on the last layer),
+// z[t] = x_t . w_match + b_match (the matchability LOGIT the final assignment uses if the pair stops at this layer: stopped pairs have a
+// live count of 0 from then on, so their rows keep the values of their last layer) and mval[t] = sigmoid(z[t]) (point pruning).
+// One wave per token. Rounds 1-3 ran three launches of a one-head kernel here; the arithmetic per head is the same.
+__global__ __launch_bounds__(256) void lg_heads_kernel(const float* __restrict__ x, int ld, const SeqDesc* __restrict__ seqs,
+                                                       const int* __restrict__ counts, const float* __restrict__ w_conf, float b_conf,
+                                                       const float* __restrict__ w_match, float b_match, float* __restrict__ conf,
+                                                       float* __restrict__ z, float* __restrict__ mval) {
     const SeqDesc sq = seqs[blockIdx.y];
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= counts[sq.cnt_idx]) return;
     const int row = sq.row_off + i;
     const int lane = threadIdx.x & 63;
     const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)row * ld + lane * 4);
-    const f32x4 ww = *reinterpret_cast<const f32x4*>(w + lane * 4);
-    float s = a.x * ww.x + a.y * ww.y + a.z * ww.z + a.w * ww.w;
-    s = wave_sum(s) + b;
-    if (act == 1) s = 1.0f / (1.0f + expf(-s));
-    if (lane == 0) out[row] = s;
+    const f32x4 wm = *reinterpret_cast<const f32x4*>(w_match + lane * 4);
+    float sm = a.x * wm.x + a.y * wm.y + a.z * wm.z + a.w * wm.w;
+    sm = wave_sum(sm) + b_match;
+    if (w_conf) {
+        const f32x4 wc = *reinterpret_cast<const f32x4*>(w_conf + lane * 4);
+        float sc = a.x * wc.x + a.y * wc.y + a.z * wc.z + a.w * wc.w;
+        sc = wave_sum(sc) + b_conf;
+        if (lane == 0) conf[row] = 1.0f / (1.0f + expf(-sc));
+    }
+    if (lane == 0) {
+        z[row] = sm;
+        if (mval) mval[row] = 1.0f / (1.0f + expf(-sm));
+    }
 }
 
 __global__ __launch_bounds__(256) void copy_rows256_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows) {
@@ -207,11 +219,12 @@ int launch_layernorm_gelu(float* x, int ld, const SeqDesc* seqs, const int* coun
     return GTSFM_OK;
 }
 
-int launch_rowdot(const float* x, int ld, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* w, float b, int act,
-                  float* out, hipStream_t stream) {
+int launch_lg_heads(const float* x, int ld, const SeqDesc* seqs, const int* counts, int nseq, int max_n, const float* w_conf, float b_conf,
+                    const float* w_match, float b_match, float* conf, float* z, float* mval, hipStream_t stream) {
     if (nseq <= 0 || max_n <= 0) return GTSFM_OK;
-    hipLaunchKernelGGL(rowdot_kernel, dim3(ceil_div(max_n, 4), nseq), dim3(256), 0, stream, x, ld, seqs, counts, w, b, act, out);
-    GTSFM_CHECK_LAUNCH("rowdot_kernel");
+    hipLaunchKernelGGL(lg_heads_kernel, dim3(ceil_div(max_n, 4), nseq), dim3(256), 0, stream, x, ld, seqs, counts, w_conf, b_conf, w_match, b_match,
+                       conf, z, mval);
+    GTSFM_CHECK_LAUNCH("lg_heads_kernel");
     return GTSFM_OK;
 }
 

@@ -322,10 +322,30 @@ __global__ __launch_bounds__(256) void lg_cols_kernel(const PairDesc* __restrict
     const int nblk = ceil_div(m, SW_ROWS);
     const float* part = partials + pd.part_off + j;
     const size_t bs = (size_t)pd.ld * 2;
+    // the row-block partials of a column are 2 ld floats apart: eight loads in flight per thread (one pair at the 5000-keypoint cap is 20
+    // workgroups walking 157 blocks -- with one dependent load per step the kernel took 69 us, longer than the sweep over the matrix itself);
+    // the sum keeps its order, block 0 first
     float M = neg_inf();
-    for (int b = 0; b < nblk; ++b) M = fmaxf(M, part[b * bs]);
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(b + u) * bs];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) M = fmaxf(M, v[u]);
+    }
+    for (; b < nblk; ++b) M = fmaxf(M, part[b * bs]);
     float S = 0.f;
-    for (int b = 0; b < nblk; ++b) S += part[b * bs + pd.ld] * sw_exp2((part[b * bs] - M) * SW_LOG2E);
+    for (b = 0; b + 8 <= nblk; b += 8) {
+        float mv[8], sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = part[(b + u) * bs], sv[u] = part[(b + u) * bs + pd.ld];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv[u] = sv[u] * sw_exp2((mv[u] - M) * SW_LOG2E);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) S += sv[u];
+    }
+    for (; b < nblk; ++b) S += part[b * bs + pd.ld] * sw_exp2((part[b * bs] - M) * SW_LOG2E);
     colvec[vec_off(s1, 2 * p + 1) + j] = logf(S) + M;
 }
 
@@ -466,7 +486,17 @@ __global__ __launch_bounds__(256) void extract_cols_kernel(const PairDesc* __res
     const size_t bs = (size_t)pd.ld * 2;
     float bv = neg_inf();
     int bi = SW_NO_INDEX;
-    for (int b = 0; b < nblk; ++b) {
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {  // eight blocks' loads in flight (see lg_cols_kernel), compared in block order
+        float ov[8];
+        int oi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ov[u] = part[(b + u) * bs], oi[u] = reinterpret_cast<const int*>(part)[(b + u) * bs + pd.ld];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (ov[u] > bv || (ov[u] == bv && oi[u] < bi)) bv = ov[u], bi = oi[u];
+    }
+    for (; b < nblk; ++b) {
         const float ov = part[b * bs];
         const int oi = reinterpret_cast<const int*>(part)[b * bs + pd.ld];
         if (ov > bv || (ov == bv && oi < bi)) {
