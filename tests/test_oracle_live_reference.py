@@ -63,3 +63,64 @@ def test_superglue_restatement_equals_the_reference_model_on_fresh_pairs(ref, n0
                                                  data["descriptors0"], data["descriptors1"], shp0, shp1, sinkhorn_iterations=iters)
     for key in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
         assert out[key].dtype == ora[key].dtype and torch.equal(out[key], ora[key]), key
+
+
+def _reference_keypoints_class():
+    """gtsfm/common/keypoints.py imports cv2 for one method (cast_to_opencv_keypoints) that the path never calls: a stub module stands in."""
+    import importlib.util
+    import sys
+    import types
+
+    had = "cv2" in sys.modules
+    if not had:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+        sys.modules["cv2"].KeyPoint = object
+    try:
+        spec = importlib.util.spec_from_file_location("ref_keypoints", str(REFERENCE / "gtsfm" / "common" / "keypoints.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        if not had:
+            del sys.modules["cv2"]
+    return mod.Keypoints
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_keypoints_stand_in_equals_the_reference_class(seed):
+    """Row a19: ``get_top_k`` / ``filter_by_mask`` / ``extract_indices`` of the stand-in class used when GTSfM is not
+    importable (gtsfm_amd/common/keypoints.py) against gtsfm/common/keypoints.py:87-127 -- same selections in the same order, same dtypes,
+    incl. ties in the responses, k >= n, missing responses / scales, an empty set and keypoints exactly on .5 coordinates (np.round: half to even)."""
+    from gtsfm_amd.common import keypoints as K
+
+    if not getattr(K, "USING_STAND_IN", True):
+        pytest.skip("GTSfM's own Keypoints is importable: nothing to compare")
+    Ref = _reference_keypoints_class()
+    rng = np.random.default_rng(seed)
+    n = [0, 1, 37, 500, 500, 2000][seed]
+    h, w = 120, 160
+    coords = np.stack([rng.uniform(0, w - 1, n), rng.uniform(0, h - 1, n)], 1).astype(np.float32)
+    if n >= 37:
+        coords[::5] = np.floor(coords[::5]) + 0.5  # rounding ties
+        coords[:, 0] = np.clip(coords[:, 0], 0, w - 1.5)
+        coords[:, 1] = np.clip(coords[:, 1], 0, h - 1.5)
+    resp = rng.random(n).astype(np.float32)
+    if seed == 4:
+        resp = np.round(resp * 8) / 8  # many exact ties: argpartition's choice among them must be the same call on the same data
+    scales = rng.random(n).astype(np.float32) if seed % 2 else None
+    mask = (rng.random((h, w)) < 0.7).astype(np.uint8)
+    for responses in (resp, None):
+        ours, theirs = K.Keypoints(coords.copy(), scales, responses), Ref(coords.copy(), scales, responses)
+        assert len(ours) == len(theirs) == n
+        for k in (0, 1, n // 3, n, n + 5):
+            (a, ia), (b, ib) = ours.get_top_k(k), theirs.get_top_k(k)
+            assert ia.dtype == ib.dtype and np.array_equal(ia, ib), (k, responses is None)
+            assert np.array_equal(a.coordinates, b.coordinates) and len(a) == len(b)
+            for fa, fb in ((a.scales, b.scales), (a.responses, b.responses)):
+                assert (fa is None) == (fb is None) and (fa is None or (fa.dtype == fb.dtype and np.array_equal(fa, fb)))
+        (a, ia), (b, ib) = ours.filter_by_mask(mask), theirs.filter_by_mask(mask)
+        assert ia.dtype == ib.dtype and np.array_equal(ia, ib)
+        assert np.array_equal(a.coordinates, b.coordinates)
+        assert np.array_equal(ours.get_x_coordinates(), theirs.get_x_coordinates()) and np.array_equal(ours.get_y_coordinates(), theirs.get_y_coordinates())
+        assert (ours == K.Keypoints(coords.copy(), scales, responses)) and (theirs == Ref(coords.copy(), scales, responses))
+        if n:
+            assert ours != K.Keypoints(coords + 1, scales, responses) and theirs != Ref(coords + 1, scales, responses)
