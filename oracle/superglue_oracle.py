@@ -203,7 +203,8 @@ def match(
     sinkhorn_iterations: int = 20,
     dtype=torch.float32,
 ) -> np.ndarray:
-    """gtsfm/frontend/matcher/superglue_matcher.py:75-113: numpy -> torch dict -> model -> (K,2) uint32."""
+    """gtsfm/frontend/matcher/superglue_matcher.py:75-113: numpy -> torch dict -> model -> (K,2) uint32. Pinned: the reference's own
+    ``SuperGlueMatcher.match``, run live, returns the same arrays (oracle/validate_wrappers_against_reference.py)."""
     with torch.no_grad():
         pred = superglue_forward(
             sd,

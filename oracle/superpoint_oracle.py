@@ -137,7 +137,8 @@ def detect_and_describe(
 ):
     """gtsfm/frontend/detector_descriptor/superpoint.py:63-93 on an already-gray uint8 image (cv2 is absent here,
     SURVEY.md section 8c caveat 4). Returns (coordinates [K,2] f32, responses [K] f32, descriptors [K,256] f32)
-    after ``filter_by_mask`` / ``get_top_k`` (gtsfm/common/keypoints.py:89-127)."""
+    after ``filter_by_mask`` / ``get_top_k`` (gtsfm/common/keypoints.py:89-127). Pinned: the reference's own wrapper class, run live on gray
+    frames, returns the same arrays bit for bit (oracle/validate_wrappers_against_reference.py)."""
     with torch.no_grad():
         res = superpoint_forward(sd, gray_u8_to_tensor(gray, dtype))
     coordinates = res["keypoints"].to(torch.float32).numpy()

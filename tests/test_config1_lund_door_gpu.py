@@ -3,7 +3,8 @@ loader's resolution (``max_resolution: 760``, gtsfm/configs/loader/olsson.yaml:5
 (gtsfm/configs/deep_front_end.yaml:29), all 66 exhaustive pairs -- through the plugin classes and their cachers, and through the
 batched correspondence generator, against golden vectors WRITTEN BY THE REFERENCE'S OWN MODEL FILES
 (``oracle/validate_against_reference.py::check_lund_door_config1``: reference SuperPoint + the wrapper's ``get_top_k`` restated,
-reference SuperGlue with GTSfM's 20 Sinkhorn iterations + the wrapper's output marshalling). The reduced gray frames travel in the
+reference SuperGlue with GTSfM's 20 Sinkhorn iterations + the wrapper's output marshalling; the reference's own plugin classes, run live by
+``oracle/validate_wrappers_against_reference.py``, return exactly these arrays for all 12 frames and 66 pairs). The reduced gray frames travel in the
 fixture (/root/reference does not exist on the GPU box); the loader's ``cv.INTER_CUBIC`` reduction in front of them is the one step
 restated without a pin (cv2 absent).
 

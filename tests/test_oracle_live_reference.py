@@ -124,3 +124,19 @@ def test_keypoints_stand_in_equals_the_reference_class(seed):
         assert (ours == K.Keypoints(coords.copy(), scales, responses)) and (theirs == Ref(coords.copy(), scales, responses))
         if n:
             assert ours != K.Keypoints(coords + 1, scales, responses) and theirs != Ref(coords + 1, scales, responses)
+
+
+def test_reference_plugin_classes_return_what_the_restatement_and_the_config1_golden_hold():
+    """``oracle/validate_wrappers_against_reference.py`` in a process of its own (it makes ``gtsfm`` importable with cv2 / gtsam stubbed, which
+    must not leak into this one): the reference's ``SuperPointDetectorDescriptor.detect_and_describe`` and ``SuperGlueMatcher.match`` -- the two
+    plugin classes the HIP plugins replace -- run live on the CPU and equal the oracle's restatement bit for bit; on the
+    first two Lund-door frames and their pair they return exactly the arrays ``tests/golden/lund_door_config1.npz`` holds."""
+    import subprocess
+    import sys
+
+    repo = Path(__file__).resolve().parents[1]
+    out = subprocess.run([sys.executable, str(repo / "oracle" / "validate_wrappers_against_reference.py"), "--frames", "2", "--pairs", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=str(repo))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.rstrip().endswith("OK") and "lund door pair (0,1): the reference wrapper returns the golden's 243 matches" in out.stdout
+    assert out.stdout.count("wrapper == restatement") >= 9
