@@ -457,29 +457,35 @@ def parse_args(argv=None):
     return args
 
 
-class _FakePipeline:
-    """--plumbing-only stand-in for FrontEndPipeline: random features, synthetic match lists (CPU tensors)."""
+def make_scene_generator(args, plumbing: bool):
+    """The product class of ``--mode scene``, built the way a GTSfM config builds it: from the two plugin objects (checkpoints = the seeded
+    synthetic weights, written to a temporary directory by every rank for itself; only rank 0 ever reads them -- the others receive the packed
+    blobs over RCCL). ``--plumbing-only``: the same class around the stand-in pipeline (no kernels, CPU, gloo)."""
+    import tempfile
+    import types
 
-    def __init__(self, k: int):
-        self.k = k
+    from gtsfm_amd.frontend.correspondence_generator.sharded_det_desc_correspondence_generator import ShardedDetDescCorrespondenceGenerator
 
-    def detect(self, images):
-        n = images.shape[0]
-        g = torch.Generator().manual_seed(int(images[:, 0, 0].sum()) + n)
-        return {"count": torch.full((n,), self.k, dtype=torch.int32), "xy": torch.rand((n, self.k, 2), generator=g),
-                "scores": torch.rand((n, self.k), generator=g), "descriptors": torch.rand((n, self.k, 256), generator=g)}
+    if plumbing:
+        from gtsfm_amd.utils.standin import stand_in_pipeline_factory
 
-    def match(self, feats, pairs, shapes, counts=None, **kw):
-        res = []
-        for c0 in range(0, len(pairs), 32):
-            chunk = list(pairs[c0 : c0 + 32])
-            m = torch.full((len(chunk) * 2 * self.k,), -1, dtype=torch.int32)
-            for q, (i, j) in enumerate(chunk):  # keypoint t of image i <-> keypoint t of image j for t < (i + j) % k
-                t = torch.arange((i + j) % self.k, dtype=torch.int32)
-                m[q * 2 * self.k : q * 2 * self.k + len(t)] = t
-                m[q * 2 * self.k + self.k : q * 2 * self.k + self.k + len(t)] = t
-            res.append({"matches": m, "mscores": torch.zeros(m.shape), "pairs": chunk, "n0": [self.k] * len(chunk), "n1": [self.k] * len(chunk)})
-        return res
+        return ShardedDetDescCorrespondenceGenerator(None, types.SimpleNamespace(max_keypoints=args.keypoints), pipeline_factory=stand_in_pipeline_factory), None
+    from gtsfm_amd.frontend.detector_descriptor.superpoint import SuperPointDetectorDescriptor
+    from gtsfm_amd.frontend.matcher.lightglue_matcher import LightGlueMatcher
+    from gtsfm_amd.frontend.matcher.superglue_matcher import SuperGlueMatcher
+
+    tmp = tempfile.TemporaryDirectory()
+    torch.save(synthetic.synthetic_superpoint_state_dict(), f"{tmp.name}/sp.pth")
+    det = SuperPointDetectorDescriptor(max_keypoints=args.keypoints, weights_path=f"{tmp.name}/sp.pth")
+    if args.matcher == "superglue":
+        torch.save(synthetic.synthetic_superglue_state_dict(), f"{tmp.name}/sg.pth")
+        mt = SuperGlueMatcher(weights_path=f"{tmp.name}/sg.pth")
+    else:
+        torch.save(synthetic.synthetic_lightglue_state_dict(), f"{tmp.name}/lg.pth")
+        mt = LightGlueMatcher("superpoint", weights_path=f"{tmp.name}/lg.pth")
+    gen = ShardedDetDescCorrespondenceGenerator(mt, det, pair_batch=args.pair_chunk, pipeline_options={
+        "num_streams": args.streams, "use_graphs": bool(args.graphs), "share_first_layer": bool(args.share_first_layer)})
+    return gen, tmp  # the directory lives as long as the caller holds it (attach() reads the checkpoints on rank 0)
 
 
 def matches_to_numpy(results):
@@ -525,9 +531,20 @@ def main() -> None:
     h = args.height or args.size
     w = args.width or args.size
     scene = args.mode == "scene"
-    lib = detector = matcher = None
-    if plumbing:
-        pipe = _FakePipeline(min(args.keypoints, 32))
+    lib = detector = matcher = gen = None
+    if scene:
+        # ONE scene sharded over the ranks: the product class does it (RCCL weight broadcast, cyclic detection, the feature exchange to
+        # the ranks that match an image, 2-D cyclic pair ownership, the ragged gather of the match lists); this file only times it
+        gen, _weights_dir = make_scene_generator(args, plumbing)
+        pipe = gen.attach()
+        if not plumbing:
+            from gtsfm_amd.runtime import lib as L
+
+            lib, detector, matcher = L.load(), gen._detector_descriptor._model, gen._matcher._model
+    elif plumbing:
+        from gtsfm_amd.utils.standin import StandInPipeline
+
+        pipe = StandInPipeline(min(args.keypoints, 32))
     else:
         from gtsfm_amd.runtime import lib as L
         from gtsfm_amd.runtime import matcher_engine as ME
@@ -561,13 +578,13 @@ def main() -> None:
         views_np = synthetic.synthetic_overlapping_views(n, h, w, 1000 + (0 if scene else rank))
     independent = args.pair_definition == "independent" and have_matcher
     my_images = list(range(n))
+    plan = None
     if scene:
         all_pairs = parallel.exhaustive_pairs(n)[: args.pairs]
-        my_images = parallel.partition_images(n, rank, world)
-        my_pairs = parallel.partition_pairs_2d(all_pairs, rank, world)
+        plan = parallel.ScenePlan(n, all_pairs, rank, world)  # what the generator computes per call; here for the report
+        my_images, my_pairs, pairs = plan.my_images, plan.my_pairs, plan.local_pairs
         images = torch.from_numpy(views_np[my_images]).to(device)  # this rank's views, resident before the timed region
-        pairs = [(parallel.table_index(i, n, world), parallel.table_index(j, n, world)) for i, j in my_pairs]
-        shapes = [(h, w)] * (world * (-(-n // world)))
+        shapes = [(h, w)] * n
     else:
         images = torch.from_numpy(views_np).to(device)  # inputs resident in HBM before the timed region
         all_pairs = my_pairs = pairs = parallel.exhaustive_pairs(n)[: args.pairs] if have_matcher else []
@@ -581,17 +598,12 @@ def main() -> None:
         shapes = [(h, w)] * n
 
     def step():
+        if scene:  # detect own views -> exchange -> match own pairs -> gather: ShardedDetDescCorrespondenceGenerator.detect_and_run_scene
+            out = gen.detect_and_run_scene(images, args.images, shapes, all_pairs, **mk)
+            return out.table, out.results, out.matches
         feats = pipe.detect(images)
-        gathered = None
-        if scene:
-            feats = parallel.all_gather_feature_table(feats, args.images)  # RCCL all-gather: the one exchange step of the path
-            counts = feats["count"].cpu().numpy()
-            res = pipe.match(feats, pairs, shapes, counts=counts, **mk)
-            local = matches_to_numpy(res)
-            gathered = parallel.gather_matches({my: local[t] for my, t in zip(my_pairs, pairs)}, device)
-        else:
-            res = pipe.match(feats, pairs, shapes, **mk) if have_matcher else []
-        return feats, res, gathered
+        res = pipe.match(feats, pairs, shapes, **mk) if have_matcher else []
+        return feats, res, None
 
     def sync():
         if dist is not None:
@@ -624,8 +636,6 @@ def main() -> None:
 
     if rank == 0:
         kcount = feats["count"].tolist()
-        if scene:
-            kcount = [int(feats["count"][parallel.table_index(i, args.images, world)]) for i in range(args.images)]
         nmatch = int(sum(int((r["matches"] > -1).sum()) for r in res)) // 2 if res else 0
         layers, kept_frac = 18.0, 1.0
         if args.matcher == "lightglue" and not plumbing and res:
@@ -641,9 +651,9 @@ def main() -> None:
         if detect_only:
             workload = f"SuperPoint-only: {n} synthetic {h}x{w} gray images per GPU per step"
         elif scene:
-            workload = (f"SuperPoint+{args.matcher}, ONE scene sharded over {world} GPU(s): {len(all_pairs)} exhaustive (i<j) pairs of {args.images} "
-                        f"synthetic {h}x{w} gray images per step (cyclic image ownership, RCCL feature all-gather, 2-D block-cyclic pair ownership, "
-                        f"match lists gathered), top-{args.keypoints} keypoints per image")
+            workload = (f"SuperPoint+{args.matcher}, ONE scene sharded over {world} GPU(s) by ShardedDetDescCorrespondenceGenerator: {len(all_pairs)} exhaustive "
+                        f"(i<j) pairs of {args.images} synthetic {h}x{w} gray images per step (cyclic image ownership, RCCL all_to_all of every image to the ranks "
+                        f"that match it, 2-D block-cyclic pair ownership, match lists gathered), top-{args.keypoints} keypoints per image")
         elif independent:
             workload = (f"SuperPoint+{args.matcher}: {len(pairs)} independent pairs = {n} fresh detections of synthetic {h}x{w} gray images per GPU "
                         f"per step, top-{args.keypoints} keypoints per image")
@@ -702,11 +712,16 @@ def main() -> None:
             empty_ranks = sum(1 for r in range(world) if not parallel.partition_pairs_2d(all_pairs, r, world))
             result["scene_check"] = {"pairs_gathered": len(gathered), "pairs_of_the_scene": len(all_pairs), "each_pair_exactly_once": True,
                                      "ranks_without_pairs": empty_ranks}
+            result["exchange"] = {"images_of_the_scene": args.images, "images_in_rank0_table": len(plan.table_images),
+                                  "image_blocks_rank0_sends": plan.images_sent(),
+                                  "largest_table_over_ranks": max(len(t) for t in plan.needed_by),
+                                  "class": "gtsfm_amd.frontend.correspondence_generator.sharded_det_desc_correspondence_generator.ShardedDetDescCorrespondenceGenerator"}
         if dist is not None:
             result["distributed"] = {
                 "backend": dist.get_backend(), "world_size": world,
                 "collectives": ["broadcast (packed weights)", "barrier", "all_reduce MAX (step time)"]
-                               + (["all_gather_into_tensor (feature table)", "all_gather (ragged match lists)"] if scene else []),
+                               + (["broadcast_object_list (matcher scalars)", "all_to_all_single (feature rows to the ranks that match them)",
+                                   "all_gather_into_tensor (ragged match lists)"] if scene else []),
             }
         if kept_frac < 1.0:
             result["tflops_note"] = (f"upper bound: counted at full width N = {args.keypoints} in every layer; point pruning left "

@@ -466,6 +466,11 @@ bool gemm_uses_dma(int K, int ldw) {
     return K % DM_KC == 0 && ldw % 4 == 0 && !(which && which[0] == 'm');
 }
 
+int gemm_math_from_env() {
+    const char* math_env = getenv("GTSFM_GEMM_MATH");
+    return (math_env && math_env[0] == 'b') ? 1 : 0;
+}
+
 int launch_gemm_dma(const GemmParams& p, hipStream_t stream) {
     GemmBatch none = {nullptr, nullptr, 0};
     return launch_gemm_dma_batched(p, none, stream);
@@ -496,10 +501,11 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     // 512->512 107.0 -> 93.9 (640 large tiles), 256->768 72.5 -> 75.6 (960); 40960 rows 512->512 177 -> 193 (1280): the small tiling
     // wins up to ~700 large tiles. GTSFM_GEMM_SMALL_BELOW overrides the threshold (0: never).
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!p.res || (p.ldres & 3) == 0);
-    // GTSFM_GEMM_MATH=bf16x3 (read per launch; NOT bit-identical to the default): both tilings run the same six
-    // products per block in the same order, so batched == single-pair results stay bit-identical under the switch too
-    const char* math_env = getenv("GTSFM_GEMM_MATH");
-    const bool x3 = math_env && math_env[0] == 'b';
+    // p.math = 1 (the matchers under GTSFM_GEMM_MATH=bf16x3; NOT bit-identical to the default): both tilings run the same six
+    // products per block in the same order, so batched == single-pair results stay bit-identical under the switch too. The switch is
+    // a field the CALLER sets (matcher_api.hip, the stand-alone linear entry points): SuperPoint's convPb / convDb come through this
+    // launcher as well and leave it 0 -- keypoint scores and dense descriptors never change with the environment.
+    const bool x3 = p.math == 1;
     const char* small_env = getenv("GTSFM_GEMM_SMALL_BELOW");
     const long long small_below = small_env ? atoll(small_env) : 700LL * gtsfm_cu_count() / 256;  // measured on 256 CUs; scales with the chip
     if (!bt.problems && vec_ok && !p.n_dev && nbw == 1 && (long long)mtiles * ncb < small_below) {

@@ -45,8 +45,13 @@ __global__ __launch_bounds__(256) void lg_stop_check_kernel(const float* __restr
     const int p = blockIdx.x;
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
     const int c0 = live[2 * p], c1 = live[2 * p + 1];
+    const int stopped_at = stop_layer[p];
+    // every wave has read the counts and the stop layer before thread 0 overwrites them below: on the last layer there is no other
+    // barrier between these loads and those stores, and a wave that ran late would read 0 / 0 with stop_layer >= 0, leave at the
+    // early-out and skip its share of the index copy
+    __syncthreads();
     if (threadIdx.x == 0) assign[2 * p] = assign[2 * p + 1] = 0;
-    if (c0 == 0 && c1 == 0 && stop_layer[p] >= 0) return;  // stopped earlier (uniform)
+    if (c0 == 0 && c1 == 0 && stopped_at >= 0) return;  // stopped earlier (uniform)
     bool stop = (layer == last_layer);
     if (!stop && depth_confidence > 0.f) {
         int cnt = 0;

@@ -330,6 +330,7 @@ static int sg_forward_phased(const float* wts, int num_layers, float bin_score, 
     GTSFM_CHECK_ARG(npairs > 0 && num_layers >= 0 && sinkhorn_iters >= 0, "sg_forward: bad arguments");
     const BatchDims d = batch_dims(npairs, n0, n1, 1);
     const int attn_math = attention_math_from_env();  // GTSFM_ATTENTION_MATH, read per call (sizing and launches of one call agree)
+    const int gemm_math = gemm_math_from_env();       // GTSFM_GEMM_MATH: the matchers' projection / FFN / score GEMMs only
     const SgWorkspace ws = sg_workspace_layout(d, attn_math);
     if (workspace_bytes < ws.total) {
         gtsfm_set_error("sg_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.total);
@@ -367,6 +368,7 @@ static int sg_forward_phased(const float* wts, int num_layers, float bin_score, 
         memset(&g, 0, sizeof(g));
         g.A = A, g.lda = lda, g.M = T, g.K = kpad8(K), g.wpack = w, g.wraw = raw, g.ldw = kpad8(K), g.bias = b, g.N = N;
         g.C = C, g.ldc = ldc, g.c_coff = coff, g.res = res, g.ldres = ldres, g.alpha = 1.0f, g.relu = relu;
+        g.math = gemm_math;
         return launch_gemm(g, stream);
     };
 
@@ -413,6 +415,7 @@ static int sg_forward_phased(const float* wts, int num_layers, float bin_score, 
         GemmParams g;
         memset(&g, 0, sizeof(g));
         g.A = MD, g.lda = 256, g.M = d.max_n0, g.K = 256, g.wraw = MD, g.ldw = 256, g.N = d.max_n1, g.C = Z, g.alpha = 0.0625f;
+        g.math = gemm_math;
         GemmBatch bt = {(const GemmProblem*)(desc_dev + DL.score_p), counts, npairs};
         TRY(launch_gemm_dma_batched(g, bt, stream));
     } else {
@@ -613,6 +616,7 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
     GTSFM_CHECK_ARG(npairs > 0 && num_layers > 0 && (num_layers == 1 || conf_bias_host), "lg_forward: bad arguments");
     const LgDims d = lg_dims(npairs, n0, n1);
     const int attn_math = attention_math_from_env();  // GTSFM_ATTENTION_MATH, read per call (sizing and launches of one call agree)
+    const int gemm_math = gemm_math_from_env();       // GTSFM_GEMM_MATH: the matchers' projection / FFN / score GEMMs only
     const LgWorkspace ws = lg_workspace_layout(d, attn_math);
     if (workspace_bytes < ws.total) {
         gtsfm_set_error("lg_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.total);
@@ -671,6 +675,7 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
         g.C = C, g.ldc = ldc, g.c_coff = coff, g.res = res, g.ldres = ldres, g.alpha = alpha, g.relu = 0;
         g.tile_cnt_idx = tile_idx, g.tile_row0 = tile_row0, g.live_counts = cnt;
         g.rot_enc = rot_enc, g.rot_cols = rot_cols;
+        g.math = gemm_math;
         return launch_gemm(g, stream);
     };
     auto ffn = [&](float* Xc) -> int {  // x + ffn(cat[x, message])
@@ -754,6 +759,7 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
         GemmParams g;
         memset(&g, 0, sizeof(g));
         g.A = MD, g.lda = 256, g.M = d.max_n0, g.K = 256, g.wraw = MD, g.ldw = 256, g.N = d.max_n1, g.C = Z, g.alpha = 1.0f;
+        g.math = gemm_math;
         GemmBatch bt = {(const GemmProblem*)(desc_dev + DL.score_p), final_cnt, npairs};
         TRY(launch_gemm_dma_batched(g, bt, stream));
     } else {

@@ -108,6 +108,7 @@ extern "C" int gtsfm_linear_rowmajor_f32(const float* a_dev, int lda, int m, con
     p.A = a_dev, p.lda = lda, p.M = m, p.K = k, p.m_dev = m_dev;
     p.wraw = w_dev, p.ldw = ldw, p.n_dev = n_dev, p.bias = bias_dev, p.N = n;
     p.C = c_dev, p.ldc = ldc, p.c_coff = c_coff, p.res = res_dev, p.ldres = ldres, p.alpha = alpha, p.relu = relu;
+    p.math = gemm_math_from_env();  // the stand-alone product the arithmetic tests and bench.py's GEMM rooflines call
     return launch_gemm(p, (hipStream_t)stream);
 }
 

@@ -20,7 +20,6 @@ from typing import Any, Dict, List, Sequence, Tuple
 
 import numpy as np
 
-from gtsfm_amd.common.image import rgb_to_gray_u8
 from gtsfm_amd.common.keypoints import Keypoints
 from gtsfm_amd.frontend.correspondence_generator.correspondence_generator_base import CorrespondenceGeneratorBase
 from gtsfm_amd.frontend.detector_descriptor.superpoint import SuperPointDetectorDescriptor
@@ -106,75 +105,44 @@ class BatchedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         return keypoints_list, putative, {p: verified[p] for p in putative}
 
     def _detect_and_match(self, client: Any, images: List[Any], visibility_graph: List[Tuple[int, int]]):
-        import torch
-
-        from gtsfm_amd.runtime.image_prep import ImagePrep
         from gtsfm_amd.runtime.pipeline import FrontEndPipeline
-
-        prep = None
 
         imgs = self._resolve(client, images)
         det, matcher = self._detector_descriptor, self._matcher
         det._ensure_model_loaded()
         matcher._ensure_model_loaded()
         pipe = FrontEndPipeline(det._model, matcher._model, max_keypoints=det.max_keypoints, pair_chunk=self._pair_batch)
-        device = det._model.device
-        n = len(imgs)
         shapes = [(im.height, im.width) for im in imgs]
-        k = det.max_keypoints
-        xy = torch.zeros((n, k, 2), dtype=torch.float32, device=device)
-        sc = torch.zeros((n, k), dtype=torch.float32, device=device)
-        de = torch.zeros((n, k, 256), dtype=torch.float32, device=device)
-        counts = np.zeros(n, dtype=np.int64)
-
-        # equally-sized images are detected in batches with the top-k taken on the device; image masks
-        # (Keypoints.filter_by_mask ahead of get_top_k, gtsfm/frontend/detector_descriptor/superpoint.py:76-91) ride along as a
-        # uint8 batch and are applied on the device between the NMS and the keypoint extraction
-        by_shape: Dict[Tuple[int, int], List[int]] = {}
-        for i in range(n):
-            by_shape.setdefault(shapes[i], []).append(i)
-        for (h, w), idxs in by_shape.items():
-            for b0 in range(0, len(idxs), self._image_batch):
-                sel = idxs[b0 : b0 + self._image_batch]
-                arrays = [imgs[i].value_array for i in sel]
-                if all(a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == arrays[0].shape[2] for a in arrays):
-                    # RGB(A) uint8: one upload of the batch, gray conversion on the device (same 15-bit fixed-point formula)
-                    if prep is None:
-                        prep = ImagePrep(device)
-                    batch = prep.rgb_to_gray(torch.from_numpy(np.ascontiguousarray(np.stack(arrays))).to(device))
-                else:
-                    gray = np.stack([np.ascontiguousarray(rgb_to_gray_u8(a)) for a in arrays])
-                    if gray.dtype != np.uint8:
-                        gray = gray.astype(np.float32) / 255.0
-                    batch = torch.from_numpy(gray).to(device)
-                masks = None
-                if any(imgs[i].mask is not None for i in sel):
-                    masks = torch.from_numpy(np.ascontiguousarray(np.stack(
-                        [np.ones((h, w), dtype=np.uint8) if imgs[i].mask is None else (np.asarray(imgs[i].mask) == 1).astype(np.uint8) for i in sel]
-                    ))).to(device)
-                out = det._model.forward(batch, top_k=k, valid_masks=masks)
-                ii = torch.tensor(sel, dtype=torch.long, device=device)
-                xy[ii], sc[ii], de[ii] = out["xy"], out["scores"], out["descriptors"]
-                counts[sel] = out["count"].cpu().numpy()
-        feats = {"xy": xy, "scores": sc, "descriptors": de, "count": torch.from_numpy(counts).to(device)}
-
-        keypoints_list = []
-        xy_h, sc_h = xy.cpu().numpy(), sc.cpu().numpy()
-        for i in range(n):
-            c = int(counts[i])
-            keypoints_list.append(Keypoints(coordinates=xy_h[i, :c].copy(), scales=None, responses=sc_h[i, :c].copy()))
+        feats = pipe.detect_image_objects(imgs, self._image_batch)  # batched by shape, gray conversion / masks / top-k on the device
+        counts = feats["count"].cpu().numpy().astype(np.int64)
+        keypoints_list = keypoints_from_table(feats, counts)
 
         pairs = [(int(i1), int(i2)) for (i1, i2) in visibility_graph]
-        empty = [p for p in pairs if counts[p[0]] == 0 or counts[p[1]] == 0]  # superglue.py:233-240 early-out
-        empty_set = set(empty)
-        todo = [p for p in pairs if p not in empty_set]
-        is_sg = isinstance(matcher, SuperGlueMatcher)
-        dtype = np.uint32 if is_sg else np.int64
-        kwargs = (
-            {"sinkhorn_iterations": matcher._config["sinkhorn_iterations"], "match_threshold": DEFAULT_MATCH_THRESHOLD} if is_sg else {}
-        )
+        todo, empty = split_empty_pairs(pairs, counts)  # superglue.py:233-240 early-out
+        dtype, kwargs = match_output_convention(matcher)
         results = pipe.match(feats, todo, shapes, counts=counts, **kwargs) if todo else []
         result = pipe.matches_to_numpy(results, dtype=dtype)
         for p in empty:
             result[p] = np.zeros((0, 2), dtype=dtype)
         return keypoints_list, {p: result[p] for p in pairs}, {"pipe": pipe, "feats": feats, "results": results}
+
+
+def keypoints_from_table(feats, counts) -> List[Keypoints]:
+    """The generator's first return value from a device feature table: per image the first ``count`` rows (detection order)."""
+    xy_h, sc_h = feats["xy"].cpu().numpy(), feats["scores"].cpu().numpy()
+    return [Keypoints(coordinates=xy_h[i, : int(c)].copy(), scales=None, responses=sc_h[i, : int(c)].copy()) for i, c in enumerate(counts)]
+
+
+def split_empty_pairs(pairs, counts):
+    """(pairs to match, pairs with an empty keypoint set): the latter never reach the matcher (superglue.py:233-240 early-out)."""
+    empty = [p for p in pairs if counts[p[0]] == 0 or counts[p[1]] == 0]
+    empty_set = set(empty)
+    return [p for p in pairs if p not in empty_set], empty
+
+
+def match_output_convention(matcher):
+    """(dtype of the (K, 2) arrays, matcher keyword arguments) per plugin: SuperGlue returns uint32 (superglue_matcher.py:104-113) and runs
+    its configured Sinkhorn iterations, LightGlue returns int64 (lightglue_matcher.py:107-110)."""
+    if isinstance(matcher, SuperGlueMatcher):
+        return np.uint32, {"sinkhorn_iterations": matcher._config["sinkhorn_iterations"], "match_threshold": DEFAULT_MATCH_THRESHOLD}
+    return np.int64, {}

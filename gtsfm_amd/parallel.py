@@ -9,9 +9,14 @@ therefore init / result plumbing only, all MB-scale:
 * ``broadcast_packed_weights`` -- rank 0 packs a checkpoint once, everyone receives the packed blob (5-50 MB)
 * ``partition_images`` / ``partition_pairs_2d`` -- deterministic cyclic / 2-D block-cyclic ownership, computed locally on
   every rank (``partition_pairs``: contiguous blocks of the pair list)
-* ``all_gather_feature_table`` / ``gather_features`` -- all_gather of padded per-image feature blocks between the detect
-  and match phases (device table / per-image dict)
-* ``gather_matches`` -- variable-length (K,2) match arrays back to every rank (counts + padded all_gather)
+* ``ScenePlan`` + ``exchange_feature_rows`` -- the exchange step of a sharded scene: ONE ``all_to_all_single`` per feature array
+  ships every detected image to exactly the ranks whose pairs touch it (about ``n / rows + n / cols`` images per rank on a
+  ``rows x cols`` process grid instead of all ``n``); the received blocks land contiguously in the rank's own feature table
+* ``all_gather_feature_table`` / ``gather_features`` -- all_gather of padded per-image feature blocks (every rank receives every
+  image: the keypoint lists a correspondence generator returns; round 1-4's exchange step)
+* ``gather_matches`` -- variable-length (K,2) match arrays back to every rank (per-pair headers + padded all_gather)
+
+The product class that drives these is ``gtsfm_amd.frontend.correspondence_generator.sharded_det_desc_correspondence_generator``.
 """
 
 from __future__ import annotations
@@ -93,18 +98,19 @@ def table_index(image: int, num_images: int, world: int) -> int:
     return (image % world) * slots + image // world
 
 
-def all_gather_feature_table(local: Dict[str, torch.Tensor], num_images: int) -> Dict[str, torch.Tensor]:
+def all_gather_feature_table(local: Dict[str, torch.Tensor], num_images: int,
+                             keys: Sequence[str] = ("count", "xy", "scores", "descriptors")) -> Dict[str, torch.Tensor]:
     """Device-resident feature exchange between the detect and match phases of ONE scene sharded over the ranks: every
     rank passes the features of its ``partition_images`` (count [s], xy [s,K,2], scores [s,K], descriptors [s,K,256],
     s <= slots = ceil(num_images / world), same K everywhere) and receives the whole table [world * slots, ...]; image i
     sits at row ``table_index(i)``. One ``all_gather_into_tensor`` per array (RCCL over xGMI on the GPUs; MB scale)."""
     d = _dist()
     if d is None:
-        return dict(local)
+        return {key: local[key] for key in keys}
     world = d.get_world_size()
     slots = -(-num_images // world)
     out: Dict[str, torch.Tensor] = {}
-    for key in ("count", "xy", "scores", "descriptors"):
+    for key in keys:
         t = local[key]
         if t.shape[0] < slots:  # ranks with one image fewer pad with an empty slot (count 0)
             t = torch.cat([t, torch.zeros((slots - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)], 0)
@@ -112,6 +118,64 @@ def all_gather_feature_table(local: Dict[str, torch.Tensor], num_images: int) ->
         full = torch.empty((world * slots,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         d.all_gather_into_tensor(full, t)
         out[key] = full
+    return out
+
+
+class ScenePlan:
+    """Who detects, who matches and who needs which image when ONE scene is sharded over ``world`` ranks:
+    cyclic image ownership for detection (``partition_images``), 2-D block-cyclic pair ownership (``partition_pairs_2d``), and -- the
+    point of the 2-D tiling -- a feature table per rank that holds only the images its own pairs touch. Computed identically on every
+    rank from (num_images, pairs, world) alone, so the exchange needs no negotiation: every rank knows what every other rank sends.
+
+    ``table_images``: the images in this rank's table, ordered by (owning rank, slot on that rank) -- the block each owner sends is then
+    one contiguous run of table rows and ``all_to_all_single`` can receive straight into the table. ``local_pairs``: this rank's pairs
+    as (table row, table row). ``send_slots[q]``: which of this rank's detections (positions in ``my_images``) rank q needs, in q's
+    table order; ``recv_counts[q]``: how many table rows come from rank q."""
+
+    def __init__(self, num_images: int, pairs: Sequence[Tuple[int, int]], rank: int, world: int, block: int = 1):
+        self.num_images, self.rank, self.world = int(num_images), int(rank), int(world)
+        self.pairs = [(int(i), int(j)) for i, j in pairs]
+        self.my_images = partition_images(self.num_images, self.rank, self.world)
+        order = lambda i: (i % self.world, i // self.world)  # noqa: E731 - (owner, slot)
+        self.pairs_of = [partition_pairs_2d(self.pairs, q, self.world, block) for q in range(self.world)]
+        self.needed_by = [sorted(images_touched(part), key=order) for part in self.pairs_of]
+        self.my_pairs = self.pairs_of[self.rank]
+        self.table_images = self.needed_by[self.rank]
+        self.row_of = {img: row for row, img in enumerate(self.table_images)}
+        self.local_pairs = [(self.row_of[i], self.row_of[j]) for i, j in self.my_pairs]
+        self.send_slots = [[i // self.world for i in need if i % self.world == self.rank] for need in self.needed_by]
+        self.send_counts = [len(sl) for sl in self.send_slots]
+        self.recv_counts = [sum(1 for i in self.table_images if i % self.world == q) for q in range(self.world)]
+
+    def images_sent(self) -> int:
+        """Image blocks this rank puts on the wire (its own table rows stay local)."""
+        return sum(c for q, c in enumerate(self.send_counts) if q != self.rank)
+
+
+def exchange_feature_rows(plan: ScenePlan, local: Dict[str, torch.Tensor], gather_rows=None,
+                          keys: Sequence[str] = ("count", "xy", "scores", "descriptors")) -> Dict[str, torch.Tensor]:
+    """The one exchange step of a sharded scene, between the detect and match phases. ``local``: this rank's detections, row s = image
+    ``plan.my_images[s]`` (count [s], xy [s,K,2], scores [s,K], descriptors [s,K,256]; same K on every rank). Returns the rank's feature
+    table, row r = image ``plan.table_images[r]``: ONE ``all_to_all_single`` per array (RCCL over xGMI on the GPUs: grouped point-to-point
+    sends, MB-scale per link) moves every image to exactly the ranks that match it; a rank's own images take the same call (a local copy).
+    ``gather_rows(tensor, index)``: how the send buffer is assembled from ``local`` (default ``torch.index_select``; the GPU pipeline passes
+    its block-move kernel). Without a process group the table is assembled locally."""
+    d = _dist()
+    index = [s for slots in plan.send_slots for s in slots] if d is not None else [i // plan.world for i in plan.table_images]
+    some = local[keys[0]]
+    idx = torch.tensor(index, dtype=torch.int64, device=some.device)
+    take = gather_rows if gather_rows is not None else (lambda t, ix: torch.index_select(t, 0, ix))
+    out: Dict[str, torch.Tensor] = {}
+    for key in keys:
+        t = local[key]
+        identity = d is None and index == list(range(t.shape[0]))
+        send = t if identity else take(t.contiguous(), idx)
+        if d is None:
+            out[key] = send
+            continue
+        table = torch.empty((len(plan.table_images),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        d.all_to_all_single(table, send.contiguous(), output_split_sizes=plan.recv_counts, input_split_sizes=plan.send_counts)
+        out[key] = table
     return out
 
 
@@ -148,37 +212,40 @@ def gather_features(
 
 
 def gather_matches(local: Dict[Tuple[int, int], np.ndarray], device: torch.device) -> Dict[Tuple[int, int], np.ndarray]:
-    """Variable-length (K,2) match arrays of every rank's pairs, returned on every rank (all_gatherv emulation:
-    all_gather of sizes, then of one padded int64 buffer per rank: rows [i1, i2, idx1, idx2])."""
+    """Variable-length (K,2) match arrays of every rank's pairs, returned on every rank as int64 (all_gatherv emulation): an
+    all_gather of the sizes, then of one padded header per rank -- rows (i1, i2, K) -- and of one padded int32 body per rank -- the
+    pairs' (idx1, idx2) rows back to back in header order. Ranks without a pair take part with empty buffers."""
     d = _dist()
     if d is None:
         return dict(local)
     world = d.get_world_size()
-    rows = [np.concatenate([np.full((m.shape[0], 2), p, dtype=np.int64), m.astype(np.int64)], axis=1) for p, m in local.items()]
-    empties = [p for p, m in local.items() if m.shape[0] == 0]
-    flat = np.concatenate(rows, axis=0) if rows else np.zeros((0, 4), dtype=np.int64)
-    meta = torch.tensor([flat.shape[0], len(empties)], dtype=torch.int64, device=device)
+    items = list(local.items())
+    header = np.array([[p[0], p[1], m.shape[0]] for p, m in items], dtype=np.int64).reshape(-1, 3)
+    body = np.concatenate([np.asarray(m).reshape(-1, 2) for _, m in items], axis=0).astype(np.int32) if items else np.zeros((0, 2), dtype=np.int32)
+    if body.shape[0] and max(int(np.asarray(m).max(initial=0)) for _, m in items) > np.iinfo(np.int32).max:
+        raise ValueError("gather_matches: keypoint indices beyond int32")
+    meta = torch.tensor([header.shape[0], body.shape[0]], dtype=torch.int64, device=device)
     metas = [torch.empty_like(meta) for _ in range(world)]
     d.all_gather(metas, meta)
-    max_rows = max(int(m[0]) for m in metas)
-    max_empty = max(int(m[1]) for m in metas)
-    buf = torch.zeros((max_rows + max_empty, 4), dtype=torch.int64, device=device)
-    if flat.shape[0]:
-        buf[: flat.shape[0]] = torch.from_numpy(flat).to(device)
-    for e, p in enumerate(empties):
-        buf[max_rows + e, 0], buf[max_rows + e, 1] = p
-    bufs = [torch.empty_like(buf) for _ in range(world)]
-    d.all_gather(bufs, buf)
-    out: Dict[Tuple[int, int], List[np.ndarray]] = {}
+    max_pairs = max(1, max(int(m[0]) for m in metas))
+    max_rows = max(1, max(int(m[1]) for m in metas))
+    hbuf = torch.zeros((max_pairs, 3), dtype=torch.int64, device=device)
+    bbuf = torch.zeros((max_rows, 2), dtype=torch.int32, device=device)
+    if header.shape[0]:
+        hbuf[: header.shape[0]] = torch.from_numpy(header).to(device)
+    if body.shape[0]:
+        bbuf[: body.shape[0]] = torch.from_numpy(body).to(device)
+    hall = torch.empty((world * max_pairs, 3), dtype=torch.int64, device=device)
+    ball = torch.empty((world * max_rows, 2), dtype=torch.int32, device=device)
+    d.all_gather_into_tensor(hall, hbuf)
+    d.all_gather_into_tensor(ball, bbuf)
+    hall, ball = hall.cpu().numpy().reshape(world, max_pairs, 3), ball.cpu().numpy().reshape(world, max_rows, 2)
+    out: Dict[Tuple[int, int], np.ndarray] = {}
     for r in range(world):
-        nrows, nempty = int(metas[r][0]), int(metas[r][1])
-        b = bufs[r].cpu().numpy()
-        for row in b[max_rows : max_rows + nempty]:
-            out.setdefault((int(row[0]), int(row[1])), [])
-        data = b[:nrows]
-        if nrows:
-            keys = data[:, 0] * (1 << 32) + data[:, 1]
-            for key in np.unique(keys):
-                sel = data[keys == key]
-                out.setdefault((int(sel[0, 0]), int(sel[0, 1])), []).append(sel[:, 2:])
-    return {p: (np.concatenate(v, axis=0) if v else np.zeros((0, 2), dtype=np.int64)) for p, v in out.items()}
+        row = 0
+        for i, j, k in hall[r, : int(metas[r][0])]:
+            if (int(i), int(j)) in out:
+                raise RuntimeError(f"gather_matches: pair {(int(i), int(j))} came back from two ranks")
+            out[(int(i), int(j))] = ball[r, row : row + int(k)].astype(np.int64)
+            row += int(k)
+    return out

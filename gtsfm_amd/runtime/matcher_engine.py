@@ -262,13 +262,15 @@ class _MatcherBase:
             counts = [len(images[i][0][0]) for i in miss]
             x = self._prepare_staged(staged, counts, [images[i][1] for i in miss])
             ready = torch.cuda.Event()
-            ready.record(stream)
             off = 0
             for i, c in zip(miss, counts):
+                # every tensor an entry holds is its own allocation (evicting one image frees its memory while its siblings of the same
+                # call live on) and is enqueued on the producer stream BEFORE the event consumers on other lanes wait for
                 kp = staged[0][off : off + c].clone()
                 sc = staged[1][off : off + c].reshape(-1).clone() if len(staged) == 3 else None
-                found[i] = _ImageEntry(kp, sc, x[off : off + c], ready, stream)
+                found[i] = _ImageEntry(kp, sc, x[off : off + c].clone() if len(miss) > 1 else x[off : off + c], ready, stream)
                 off += c
+            ready.record(stream)  # after the clones: a consumer lane that waits for `ready` sees kpts / scores / x complete
             with root._image_cache_lock:
                 for i in miss:
                     root._image_cache[keys[i]] = found[i]
@@ -381,6 +383,19 @@ class SuperGlueEngine(_MatcherBase):
         self.num_layers = superglue_num_layers(state_dict)
         self.bin_score = float(state_dict["bin_score"])
         self.weights = torch.from_numpy(pack_blob(superglue_entries(state_dict))).to(self.device)
+
+    def packed_meta(self) -> dict:
+        """What besides the packed weight blob a rank needs to run this model (``from_packed``): small host values."""
+        return {"kind": "superglue", "num_layers": int(self.num_layers), "bin_score": float(self.bin_score)}
+
+    @classmethod
+    def from_packed(cls, weights: torch.Tensor, meta: Mapping) -> "SuperGlueEngine":
+        """Build from an already-packed device blob + ``packed_meta()`` (received by an RCCL broadcast: the rank never reads a checkpoint)."""
+        assert meta["kind"] == "superglue"
+        self = cls.__new__(cls)
+        _MatcherBase.__init__(self, weights.device)
+        self.num_layers, self.bin_score, self.weights = int(meta["num_layers"]), float(meta["bin_score"]), weights
+        return self
 
     def match_batch(
         self,
@@ -577,6 +592,22 @@ class LightGlueEngine(_MatcherBase):
         self.num_layers = lightglue_num_layers(state_dict)
         entries, self.match_bias, self.conf_bias = lightglue_entries(state_dict)
         self.weights = torch.from_numpy(pack_blob(entries)).to(self.device)
+
+    def packed_meta(self) -> dict:
+        """What besides the packed weight blob a rank needs to run this model (``from_packed``): small host values."""
+        return {"kind": "lightglue", "num_layers": int(self.num_layers), "match_bias": [float(v) for v in self.match_bias],
+                "conf_bias": [float(v) for v in self.conf_bias]}
+
+    @classmethod
+    def from_packed(cls, weights: torch.Tensor, meta: Mapping) -> "LightGlueEngine":
+        """Build from an already-packed device blob + ``packed_meta()`` (received by an RCCL broadcast: the rank never reads a checkpoint)."""
+        assert meta["kind"] == "lightglue"
+        self = cls.__new__(cls)
+        _MatcherBase.__init__(self, weights.device)
+        self.num_layers, self.weights = int(meta["num_layers"]), weights
+        self.match_bias = np.array(meta["match_bias"], dtype=np.float32)
+        self.conf_bias = np.array(meta["conf_bias"], dtype=np.float32)
+        return self
 
     def match_batch(
         self,

@@ -102,6 +102,49 @@ class FrontEndPipeline:
         outs = [self.detector.forward(images[i : i + image_chunk], top_k=self.max_keypoints) for i in range(0, images.shape[0], image_chunk)]
         return {k: torch.cat([o[k] for o in outs], 0) for k in ("count", "xy", "scores", "descriptors")}
 
+    def detect_image_objects(self, imgs: Sequence, image_batch: int = 16) -> Dict[str, torch.Tensor]:
+        """``detect`` for a list of ``Image`` objects as a correspondence generator receives them (``value_array`` HxW[xC] host arrays of
+        possibly different sizes, optional ``mask``): equally-sized images are uploaded and detected in batches with the top-k taken on the
+        device; RGB(A) uint8 batches are converted to gray on the device (``ImagePrep.rgb_to_gray``: the same 15-bit fixed-point formula as
+        the host path); image masks (``Keypoints.filter_by_mask`` ahead of ``get_top_k``, gtsfm/frontend/detector_descriptor/
+        superpoint.py:76-91) ride along as a uint8 batch and are applied on the device between the NMS and the keypoint extraction.
+        Returns count [n] (int32), xy [n,K,2], scores [n,K], descriptors [n,K,256] in the order of ``imgs``; n = 0 gives empty tables."""
+        from gtsfm_amd.common.image import rgb_to_gray_u8
+
+        device, k, n = self.detector.device, self.max_keypoints, len(imgs)
+        xy = torch.zeros((n, k, 2), dtype=torch.float32, device=device)
+        sc = torch.zeros((n, k), dtype=torch.float32, device=device)
+        de = torch.zeros((n, k, 256), dtype=torch.float32, device=device)
+        cnt = torch.zeros((n,), dtype=torch.int32, device=device)
+        by_shape: Dict[Tuple[int, int], List[int]] = {}
+        for i, im in enumerate(imgs):
+            by_shape.setdefault((int(im.height), int(im.width)), []).append(i)
+        prep = None
+        for (h, w), idxs in by_shape.items():
+            for b0 in range(0, len(idxs), image_batch):
+                sel = idxs[b0 : b0 + image_batch]
+                arrays = [imgs[i].value_array for i in sel]
+                if all(a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == arrays[0].shape[2] for a in arrays):
+                    if prep is None:
+                        from gtsfm_amd.runtime.image_prep import ImagePrep
+
+                        prep = ImagePrep(device)
+                    batch = prep.rgb_to_gray(torch.from_numpy(np.ascontiguousarray(np.stack(arrays))).to(device))  # one upload of the batch
+                else:
+                    gray = np.stack([np.ascontiguousarray(rgb_to_gray_u8(a)) for a in arrays])
+                    if gray.dtype != np.uint8:
+                        gray = gray.astype(np.float32) / 255.0
+                    batch = torch.from_numpy(gray).to(device)
+                masks = None
+                if any(imgs[i].mask is not None for i in sel):
+                    masks = torch.from_numpy(np.ascontiguousarray(np.stack(
+                        [np.ones((h, w), dtype=np.uint8) if imgs[i].mask is None else (np.asarray(imgs[i].mask) == 1).astype(np.uint8) for i in sel]
+                    ))).to(device)
+                out = self.detector.forward(batch, top_k=k, valid_masks=masks)
+                ii = torch.tensor(sel, dtype=torch.long, device=device)
+                xy[ii], sc[ii], de[ii], cnt[ii] = out["xy"], out["scores"], out["descriptors"], out["count"].to(torch.int32)
+        return {"count": cnt, "xy": xy, "scores": sc, "descriptors": de}
+
     def match(
         self, feats: Dict[str, torch.Tensor], pairs: Sequence[Tuple[int, int]], shapes: Sequence[Tuple[int, int]], counts: Optional[np.ndarray] = None,
         **matcher_kwargs,

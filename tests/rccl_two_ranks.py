@@ -33,6 +33,10 @@ table = parallel.all_gather_feature_table(local, n)
 for i in range(n):
     row = parallel.table_index(i, n, world)
     assert int(table["count"][row]) == k - i and float(table["descriptors"][row, 3, 7]) == float(i)
+plan = parallel.ScenePlan(n, parallel.exhaustive_pairs(n), rank, world)  # the sharded generator's exchange: all_to_all_single on RCCL
+mine_table = parallel.exchange_feature_rows(plan, local)
+for row, i in enumerate(plan.table_images):
+    assert int(mine_table["count"][row]) == k - i and float(mine_table["xy"][row, 2, 1]) == float(i) and float(mine_table["descriptors"][row, 3, 7]) == float(i)
 pairs = parallel.partition_pairs_2d(parallel.exhaustive_pairs(n), rank, world)
 gathered = parallel.gather_matches({p: np.full((p[0] + p[1], 2), p[0], dtype=np.int64) for p in pairs}, dev)
 assert sorted(gathered) == parallel.exhaustive_pairs(n) and all(v.shape == (p[0] + p[1], 2) for p, v in gathered.items())

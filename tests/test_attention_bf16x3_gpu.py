@@ -145,3 +145,21 @@ def test_matcher_goldens_under_both_bf16x3_switches(gpu_device, monkeypatch):
     test_superglue_full_depth_matches_reference_golden(gpu_device, GOLDEN / "bench_superglue_5000x4800_s15_it20.npz")
     test_hip_path_equals_the_hf_fixture(gpu_device, "n2048_full_depth")
     test_lightglue_full_depth_vs_oracle(gpu_device, *LG_BENCH_CASES[-1])
+
+
+def test_superpoint_is_bit_identical_under_the_gemm_switch(gpu_device, monkeypatch):
+    """GTSFM_GEMM_MATH=bf16x3 is the MATCHERS' switch (GemmParams.math, set by gtsfm_{sg,lg}_forward* and the stand-alone linear entry points):
+    SuperPoint's convPb / convDb reach the same LDS-DMA launcher (superpoint_api.hip, 1x1 convolutions with K = 256) and must stay exact fp32 --
+    score maps, keypoints, scores and descriptors bit for bit the same with the variable set (until round 5 the launcher read
+    the environment itself and the logits changed with it)."""
+    from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+
+    eng = SuperPointEngine(synthetic.synthetic_superpoint_state_dict(), gpu_device)
+    imgs = torch.from_numpy(np.stack([synthetic.synthetic_gray_image(240, 320, s) for s in (5, 6)])).to(gpu_device)
+    exact = eng.forward(imgs, return_score_maps=True)
+    monkeypatch.setenv("GTSFM_GEMM_MATH", "bf16x3")
+    monkeypatch.setenv("GTSFM_ATTENTION_MATH", "bf16x3")
+    switched = eng.forward(imgs, return_score_maps=True)
+    assert int(exact["count"].min()) > 100
+    for key in ("count", "xy", "scores", "descriptors", "dense_scores", "nms_scores"):
+        assert torch.equal(exact[key], switched[key]), key

@@ -51,8 +51,11 @@ def test_bench_eight_ranks_scene_with_idle_ranks():
     assert idle >= 1 and sorted(q for part in parts for q in part) == sorted(pairs)
     assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["plumbing_only"] is True
     assert r["scene_check"] == {"pairs_gathered": 7, "pairs_of_the_scene": 7, "each_pair_exactly_once": True, "ranks_without_pairs": idle}
-    assert r["distributed"]["world_size"] == 8 and "all_gather (ragged match lists)" in r["distributed"]["collectives"]
+    assert r["distributed"]["world_size"] == 8 and "all_gather_into_tensor (ragged match lists)" in r["distributed"]["collectives"] and any("all_to_all_single" in c for c in r["distributed"]["collectives"])
     assert r["config"]["pairs_per_gpu_per_step"] == len(parts[0])
+    # the step is the product class's, and the exchange ships an image only to the ranks whose pairs touch it
+    assert r["exchange"]["class"].endswith("ShardedDetDescCorrespondenceGenerator") and r["exchange"]["images_in_rank0_table"] == len(parallel.images_touched(parts[0]))
+    assert r["exchange"]["largest_table_over_ranks"] < 5
 
 
 def test_bench_replica_mode_self_launch_weak_scaling():
@@ -60,6 +63,23 @@ def test_bench_replica_mode_self_launch_weak_scaling():
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["pairs_per_gpu_per_step"] == 8
+
+
+def test_bench_eight_ranks_replica_default_is_the_drivers_scale_command():
+    """`python bench.py --gpus 8` with no --mode: the command the driver's SCALE step issues on an 8-GPU node (replica = BASELINE config 3 per
+    rank, weak scaling). Self-launched here on gloo with stand-in kernels: eight ranks rendezvous on 127.0.0.1, every rank owns its own image
+    set / pair list, barrier + max-over-ranks timing, rank 0 prints ONE line whose value aggregates all ranks."""
+    p, lines = _run_bench("--gpus", "8", "--plumbing-only", "--images", "5", "--pairs", "8", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["scaling"] == "weak" and r["plumbing_only"] is True and r["steps"] == 2 and r["warmup"] == 1
+    assert r["distributed"]["world_size"] == 8 and r["distributed"]["backend"] == "gloo"
+    assert r["config"]["mode"] == "replica" and r["config"]["pairs_per_gpu_per_step"] == 8 and r["config"]["images_per_gpu_per_step"] == 5
+    assert r["config"]["parallelism"].startswith("dp8")
+    # whole-job aggregate: 8 ranks x 8 pairs per step over the slowest rank's step time
+    assert abs(r["value"] - 8 * 8 / (r["ms_per_step"] * 1e-3)) <= 0.01 * r["value"] + 0.01
+    assert "scene_check" not in r and r["higher_is_better"] is True and r["unit"] == "image-pairs/s"
 
 
 def test_bench_rejects_a_mismatched_launcher():

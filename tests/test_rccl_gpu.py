@@ -38,11 +38,43 @@ def test_scene_mode_through_rccl_on_the_device(gpu_device):
     dist = _bench({"GTSFM_BENCH_FORCE_DIST": "1"}, "--dump-matches", "1")
     plain = _bench({}, "--dump-matches", "1")
     assert dist["distributed"]["backend"] == "nccl" and dist["distributed"]["world_size"] == 1
-    assert any("all_gather_into_tensor" in c for c in dist["distributed"]["collectives"])
+    assert any("all_gather_into_tensor" in c for c in dist["distributed"]["collectives"]) and any("all_to_all_single" in c for c in dist["distributed"]["collectives"])
+    assert dist["exchange"]["class"].endswith("ShardedDetDescCorrespondenceGenerator")  # bench.py's scene step IS the product class's
     assert "distributed" not in plain
     assert dist["config"]["pairs_per_gpu_per_step"] == 30 and dist["scaling"] == "strong"
     # the exchange step changes nothing: same pairs, same match lists (checksum over the gathered (K,2) arrays)
     assert dist["match_digest"] == plain["match_digest"] and dist["config"]["matches_per_pair"] == plain["config"]["matches_per_pair"] > 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
+def test_sharded_generator_class_through_rccl_equals_the_single_process_generators(gpu_device, matcher, tmp_path):
+    """``ShardedDetDescCorrespondenceGenerator.generate_correspondences`` in joined mode on a one-rank RCCL group (subprocess) == the same
+    class without a process group == ``BatchedDetDescCorrespondenceGenerator``: identical keypoints and (K, 2) arrays for every edge,
+    including a fully masked view (empty keypoint set: its pairs come back as (0, 2) arrays) and an RGB view."""
+    sys.path.insert(0, str(REPO / "tests"))
+    import rccl_sharded_one_rank as helper
+    from gtsfm_amd.frontend.correspondence_generator.batched_det_desc_correspondence_generator import BatchedDetDescCorrespondenceGenerator
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, str(REPO / "tests" / "rccl_sharded_one_rank.py"), matcher], capture_output=True, text=True, env=env, timeout=600, cwd=str(REPO))
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    joined = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert joined["backend"] == "nccl" and joined["table_images"] == [0, 1, 2, 3, 4, 5]
+
+    gen = helper.build(str(tmp_path), matcher, 1)
+    images, pairs = helper.scene()
+    kps, matches = gen.generate_correspondences(None, images, pairs)
+    single = helper.digest(kps, matches, pairs)
+    assert single["keypoints"][3] == 0 and min(single["keypoints"][:3]) > 100 and single["matches"] > 50
+    assert all(matches[p].shape == (0, 2) for p in pairs if 3 in p)
+    assert single["dtype"] == ("uint32" if matcher == "superglue" else "int64")
+    assert {k: joined[k] for k in single} == single
+    batched = BatchedDetDescCorrespondenceGenerator(gen._matcher, gen._detector_descriptor)
+    kps_b, matches_b = batched.generate_correspondences(None, images, pairs)
+    assert helper.digest(kps_b, matches_b, pairs) == single
 
 
 @pytest.mark.gpu
