@@ -27,6 +27,42 @@ TOL = 1e-4              # scores / descriptors / match scores (BASELINE.json nor
 MATCH_THRESHOLD = 0.2   # superglue.py default match_threshold (GTSfM does not override it)
 NUM_IMAGES = 12
 
+# What the run SAW, not only that it passed: every count a tolerance below could hide is recorded here and written to
+# gpurun_out/config1_observed.json (copied to profiles/r05_config1_observed.json), and the asserts hold the run to the values observed on
+# MI355X -- zero stray keypoints, zero threshold-borderline matches, zero matches0 disagreements for the plugin path against the reference's
+# arrays. ``Keypoints.__eq__`` = ``np.array_equal`` is the reference's own bar
+# (tests/repro_tests/frontend/detector_descriptor/reproducibility_base.py:25-36).
+OBSERVED = {}
+EXPECTED_STRAY_KEYPOINTS_PER_FRAME = 0      # plugin path and batched generator, all 12 frames
+EXPECTED_BORDERLINE_MATCHES = 0             # plugin path, all 66 pairs: (K, 2) arrays array_equal to the reference's
+EXPECTED_MATCHES0_DISAGREEMENTS = 0         # plugin path, the 11 pairs whose full matches0 / score vectors are compared
+# generators that feed the matcher the keypoints in THEIR OWN order (detection order / this process's get_top_k order): the order enters the
+# fp32 sums of attention and Sinkhorn, scores move in the sixth digit, a match AT the 0.2 threshold may fall on the other side. The numbers
+# below are the symmetric differences observed on MI355X over all edges; the run must reproduce them exactly.
+EXPECTED_BATCHED_GENERATOR_DIFFERING = None   # None = not pinned yet: recorded, bounded by 0.2 % of the matches
+EXPECTED_PER_PAIR_GENERATOR_DIFFERING = None
+
+
+def _exact_fp32() -> bool:
+    """The pinned counts are statements about the default arithmetic; under the opt-in bf16x3 switches the old bounds apply (and the
+    observations go to a file of their own)."""
+    import os
+
+    return not (os.environ.get("GTSFM_ATTENTION_MATH") or os.environ.get("GTSFM_GEMM_MATH"))
+
+
+def _record(key, value):
+    import json
+    import os
+
+    from conftest import REPO
+
+    OBSERVED[key] = value
+    out = REPO / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    tag = "" if _exact_fp32() else "_bf16x3"
+    (out / f"config1_observed{tag}.json").write_text(json.dumps(OBSERVED, indent=1, sort_keys=True))
+
 
 @pytest.fixture(scope="module")
 def golden():
@@ -87,9 +123,10 @@ def detections(golden, images, plugins):
 
 
 def test_detections_equal_the_reference_on_all_12_frames(golden, images, detections):
-    """Keypoints identical to the reference's 5000 (as a set: ``np.argpartition``'s order is implementation-defined, and scores that
-    differ in the last bits order differently), responses and descriptors within 1e-4."""
+    """Keypoints identical to the reference's 5000 in every frame -- as a set: ``np.argpartition``'s order is implementation-defined, and
+    scores that differ in the last bits order differently; ZERO stray keypoints, recorded per frame --, responses and descriptors within 1e-4."""
     width = images[0].width
+    strays, max_dscore, max_ddesc = [], 0.0, 0.0
     for i, (kps, desc) in enumerate(detections):
         ref_xy, ref_sc, ref_head = golden[f"keypoints_{i}"].astype(np.float32), golden[f"scores_{i}"], golden[f"descriptors_head_{i}"]
         assert isinstance(kps, Keypoints) and len(kps) == 5000 == desc.shape[0] and desc.shape[1] == 256 and kps.scales is None
@@ -97,16 +134,16 @@ def test_detections_equal_the_reference_on_all_12_frames(golden, images, detecti
         got_key, ref_key = _pixel_key(kps.coordinates, width), _pixel_key(ref_xy, width)
         assert len(np.unique(got_key)) == 5000
         stray = np.setxor1d(got_key, ref_key)
-        if len(stray):  # a top-k boundary decided by the last bits of two scores: tolerated only within the score tolerance of the cut
-            cut = ref_sc.min()
-            sc_of = dict(zip(ref_key.tolist(), ref_sc.tolist()))
-            sc_of.update({k: s for k, s in zip(got_key.tolist(), kps.responses.tolist()) if k not in sc_of})
-            assert len(stray) <= 4 and all(abs(sc_of[k] - cut) < 2e-5 for k in stray.tolist()), (i, len(stray))
+        strays.append(int(len(stray)))
         common, gi, ri = np.intersect1d(got_key, ref_key, return_indices=True)
-        assert len(common) >= 4998
-        np.testing.assert_allclose(kps.responses[gi], ref_sc[ri], rtol=0, atol=TOL)
         head = np.flatnonzero(ri < len(ref_head))  # the stored descriptor rows: the first 64 of the reference's order
-        np.testing.assert_allclose(desc[gi[head]], ref_head[ri[head]], rtol=0, atol=TOL)
+        max_dscore = max(max_dscore, float(np.abs(kps.responses[gi] - ref_sc[ri]).max()))
+        max_ddesc = max(max_ddesc, float(np.abs(desc[gi[head]] - ref_head[ri[head]]).max()))
+    _record("plugin_detect.stray_keypoints_per_frame", strays)
+    _record("plugin_detect.max_abs_dresponse", max_dscore)
+    _record("plugin_detect.max_abs_ddescriptor_first64", max_ddesc)
+    assert strays == [EXPECTED_STRAY_KEYPOINTS_PER_FRAME] * NUM_IMAGES, strays  # the reference's 5000 keypoints of every frame, as a set (SuperPoint has no opt-in arithmetic)
+    assert max_dscore < TOL and max_ddesc < TOL, (max_dscore, max_ddesc)
 
 
 def _in_reference_order(golden, images, plugins, detections, i):
@@ -143,6 +180,7 @@ def test_all_66_pairs_through_the_matcher_plugin_equal_the_reference(golden, ima
     pairs = [(i, j) for i in range(NUM_IMAGES) for j in range(i + 1, NUM_IMAGES)]
     assert int(golden["num_pairs"]) == len(pairs) == 66
     total, borderline, results = 0, 0, {}
+    differing_pairs, m0_disagreements, off_scores, max_dms = [], 0, 0, 0.0
     for q, (i, j) in enumerate(pairs):
         got = plugins["sg_cacher"].match(feats[i][0], feats[j][0], feats[i][1], feats[j][1], im_shape_i1=shape, im_shape_i2=shape)
         results[(i, j)] = got
@@ -157,20 +195,34 @@ def test_all_66_pairs_through_the_matcher_plugin_equal_the_reference(golden, ima
             for a, _ in diff:
                 assert abs(float(ref_scores[a]) - MATCH_THRESHOLD) < 2e-4 or abs(float(res["matching_scores0"][a]) - MATCH_THRESHOLD) < 2e-4, ((i, j), a)
             borderline += len(diff)
+            differing_pairs.append([i, j, len(diff)])
         if q % 6 == 0:
             res = sg._model.match_pair(feats[i][0].coordinates, feats[i][0].responses, feats[i][1], feats[j][0].coordinates, feats[j][0].responses, feats[j][1],
                                        shape[:2], shape[:2], sinkhorn_iterations=20)
             ref_m0 = golden[f"matches0_{i}_{j}"].astype(np.int64)
             same = res["matches0"] == ref_m0
+            m0_disagreements += int((~same).sum())
             assert same.mean() > 0.999
             matched = same & (ref_m0 > -1)
+            max_dms = max(max_dms, float(np.abs(res["matching_scores0"][matched] - ref_scores[matched]).max()))
             np.testing.assert_allclose(res["matching_scores0"][matched], ref_scores[matched], rtol=0, atol=TOL)
             # unmatched keypoints carry exp(max) where they are mutual nearest neighbours and 0 where not (superglue.py:270-272): a
             # score may differ only where that flag flipped between two negligible candidates, never near the threshold
             off = np.abs(res["matching_scores0"] - ref_scores) > TOL
+            off_scores += int(off.sum())
             assert off.sum() <= 5 and np.all(np.maximum(res["matching_scores0"][off], ref_scores[off]) < 0.5 * MATCH_THRESHOLD), ((i, j), int(off.sum()))
+    _record("plugin_match.reference_matches_over_66_pairs", int(total))
+    _record("plugin_match.borderline_matches_differing", int(borderline))
+    _record("plugin_match.pairs_with_a_differing_match_array", differing_pairs)
+    _record("plugin_match.matches0_disagreements_over_11_full_pairs", int(m0_disagreements))
+    _record("plugin_match.unmatched_score_flag_flips_over_11_full_pairs", int(off_scores))
+    _record("plugin_match.max_abs_dmatching_score", max_dms)
     assert plugins["calls"]["sg"] == 66 and total > 3000
-    assert borderline <= 3, f"{borderline} threshold-borderline matches differ over {total}"
+    if _exact_fp32():
+        assert borderline == EXPECTED_BORDERLINE_MATCHES, f"{borderline} threshold-borderline matches differ over {total}: {differing_pairs}"
+        assert m0_disagreements == EXPECTED_MATCHES0_DISAGREEMENTS, m0_disagreements
+    else:
+        assert borderline <= 3, f"{borderline} threshold-borderline matches differ over {total}"
     # second pass: cache hits only (matcher_cacher.py:46-126, detector_descriptor_cacher.py:48-69) -- neither plugin runs again
     for (i, j) in pairs[::5]:
         again = plugins["sg_cacher"].match(feats[i][0], feats[j][0], feats[i][1], feats[j][1], im_shape_i1=shape, im_shape_i2=shape)
@@ -193,10 +245,15 @@ def test_batched_correspondence_generator_on_config1(golden, images, plugins):
     keypoints, putative = gen.generate_correspondences(None, images, pairs)
     width = images[0].width
     assert len(keypoints) == NUM_IMAGES and sorted(putative) == pairs
+    strays = []
     for i, kps in enumerate(keypoints):
         stray = np.setxor1d(_pixel_key(kps.coordinates, width), _pixel_key(golden[f"keypoints_{i}"], width))
-        assert len(kps) == 5000 and len(stray) <= 4, (i, len(stray))
+        strays.append(int(len(stray)))
+        assert len(kps) == 5000
+    _record("batched_generator.stray_keypoints_per_frame", strays)
+    assert strays == [EXPECTED_STRAY_KEYPOINTS_PER_FRAME] * NUM_IMAGES, strays
     total = differing = 0
+    per_pair_diff = []
     for (i, j) in pairs:
         got = putative[(i, j)]
         assert got.dtype == np.uint32
@@ -207,8 +264,16 @@ def test_batched_correspondence_generator_on_config1(golden, images, plugins):
         got_set = set(zip(gi[got[:, 0].astype(np.int64)].tolist(), gj[got[:, 1].astype(np.int64)].tolist()))
         total += len(ref_set)
         differing += len(ref_set ^ got_set)
+        if ref_set ^ got_set:
+            per_pair_diff.append([i, j, len(ref_set ^ got_set)])
         assert len(ref_set ^ got_set) <= max(2, 0.01 * len(ref_set)), ((i, j), len(ref_set ^ got_set), len(ref_set))
-    assert differing <= 0.002 * total + 2, (differing, total)
+    _record("batched_generator.reference_matches_over_66_pairs", int(total))
+    _record("batched_generator.differing_matches_own_keypoint_order", int(differing))
+    _record("batched_generator.pairs_with_differences", per_pair_diff)
+    if EXPECTED_BATCHED_GENERATOR_DIFFERING is None or not _exact_fp32():
+        assert differing <= 0.002 * total + 2, (differing, total)
+    else:
+        assert differing == EXPECTED_BATCHED_GENERATOR_DIFFERING, (differing, total, per_pair_diff)
 
 
 def test_per_pair_generator_on_config1(golden, images, plugins, detections, tmp_path_factory):
@@ -240,4 +305,11 @@ def test_per_pair_generator_on_config1(golden, images, plugins, detections, tmp_
         total += len(ref_set)
         differing += len(ref_set ^ got_set)
         per_pair.append(((i, j), len(ref_set), len(ref_set ^ got_set)))
-    assert total > 1000 and differing <= 0.002 * total + 2, (differing, total, [p for p in per_pair if p[2]])
+    _record("per_pair_generator.reference_matches_over_22_pairs", int(total))
+    _record("per_pair_generator.differing_matches_own_keypoint_order", int(differing))
+    _record("per_pair_generator.pairs_with_differences", [[p[0][0], p[0][1], p[2]] for p in per_pair if p[2]])
+    assert total > 1000
+    if EXPECTED_PER_PAIR_GENERATOR_DIFFERING is None or not _exact_fp32():
+        assert differing <= 0.002 * total + 2, (differing, total, [p for p in per_pair if p[2]])
+    else:
+        assert differing == EXPECTED_PER_PAIR_GENERATOR_DIFFERING, (differing, total, [p for p in per_pair if p[2]])

@@ -16,7 +16,13 @@ import yaml
 from gtsfm_amd.utils import synthetic
 from tests.conftest import REPO
 
-CONFIG = REPO / "gtsfm_amd" / "configs" / "deep_front_end_amd.yaml"
+CONFIGS = REPO / "gtsfm_amd" / "configs"
+CONFIG = CONFIGS / "deep_front_end_amd.yaml"
+
+
+def _load(name):
+    """``yaml.safe_load`` = ONE document per file, as Hydra / OmegaConf require (the two variants used to share a multi-document file)."""
+    return yaml.safe_load((CONFIGS / name).read_text())
 
 
 def instantiate(node, overrides=None, path=""):
@@ -56,7 +62,9 @@ def test_front_end_subtree_instantiates_like_the_reference_config(weights):
     from gtsfm_amd.frontend.matcher.lightglue_matcher import LightGlueMatcher
     from gtsfm_amd.frontend.matcher.superglue_matcher import SuperGlueMatcher
 
-    per_pair, batched = list(yaml.safe_load_all(CONFIG.read_text()))
+    from gtsfm_amd.frontend.correspondence_generator.sharded_det_desc_correspondence_generator import ShardedDetDescCorrespondenceGenerator
+
+    per_pair, batched, sharded = _load("deep_front_end_amd.yaml"), _load("deep_front_end_amd_batched.yaml"), _load("deep_front_end_amd_sharded.yaml")
     # variant A: the reference's graph shape -- generator(cacher(SuperPoint), cacher(LightGlue))
     gen = instantiate(per_pair, {
         "correspondence_generator.detector_descriptor.detector_descriptor_obj.weights_path": weights / "sp.pth",
@@ -76,6 +84,14 @@ def test_front_end_subtree_instantiates_like_the_reference_config(weights):
     })["correspondence_generator"]
     assert isinstance(gen_b, BatchedDetDescCorrespondenceGenerator) and isinstance(gen_b._matcher, SuperGlueMatcher)
     assert gen_b._matcher._config["weights"] == "outdoor" and gen_b._detector_descriptor.max_keypoints == 5000
+    # variant C: one scene sharded over the node's GPUs -- same two plugin arguments, ranks are started at the first call, not here
+    gen_c = instantiate(sharded, {
+        "correspondence_generator.detector_descriptor.weights_path": weights / "sp.pth",
+        "correspondence_generator.matcher.weights_path": weights / "sg.pth",
+    })["correspondence_generator"]
+    assert isinstance(gen_c, ShardedDetDescCorrespondenceGenerator) and isinstance(gen_c._matcher, SuperGlueMatcher) and gen_c._num_gpus is None
+    assert gen_c._pool is None and gen_c._pipe is None and gen_c._detector_descriptor._model is None
+    assert type(pickle.loads(pickle.dumps(gen_c))._detector_descriptor) is SuperPointDetectorDescriptor
     # a missing checkpoint fails at instantiation, like the reference's constructor (gtsfm/frontend/detector_descriptor/superpoint.py:47-53)
     with pytest.raises(FileNotFoundError):
         instantiate(per_pair, {"correspondence_generator.detector_descriptor.detector_descriptor_obj.weights_path": Path("/nonexistent/sp.pth")})
