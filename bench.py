@@ -82,6 +82,14 @@ def matcher_flops(matcher: str, n: int, layers: float, sinkhorn: int) -> float:
     return layers * 2 * (2490368 * n + 1792 * n * n) + 262144 * n + 512 * n * n
 
 
+def folded_projection_flops(matcher: str, n: int, layers: float) -> float:
+    """FLOPs of SURVEY's formula that the shipped path never executes: the attention output projections (SuperGlue ``attn.merge``, LightGlue
+    ``out_proj`` / ``to_out``: one 256 x 256 product per block and image) are folded into the following layer's weights at load time
+    (matcher_engine._fold_projection). Per pair: blocks x 2 images x 2 * 256 * 256 * N."""
+    blocks = 18.0 if matcher == "superglue" else 2.0 * layers
+    return blocks * 2 * 2.0 * 256 * 256 * n
+
+
 def first_block_flops(matcher: str, n: int) -> float:
     """Dense FLOP of the block of the first matcher layer that sees ONE image (N keypoints): SuperGlue's keypoint encoder
     (217 280 N) + one GNN layer (1 310 720 N + 1024 N^2); LightGlue's first self block (Wqkv, out_proj, FFN: 1 310 720 N;
@@ -89,17 +97,18 @@ def first_block_flops(matcher: str, n: int) -> float:
     return (217280 * n if matcher == "superglue" else 0) + 1310720 * n + 1024 * n * n
 
 
+PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"  # collected on THIS round's tree (tools/prof_r05.sh); older rounds' files are history, never cited
+
+
 def pmc_traffic(kernel: str):
-    """HBM bytes per launch measured with rocprofv3 PMC passes and committed under profiles/ (bench.py cannot collect
-    counters itself); None when no file holds the kernel."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        try:
-            entry = json.loads((REPO / "profiles" / name).read_text()).get(kernel)
-        except (OSError, ValueError):
-            entry = None
-        if entry is not None:
-            return dict(entry, source=f"profiles/{name}")
-    return None
+    """HBM-side bytes per launch measured with rocprofv3 PMC passes on this round's tree and committed under profiles/ (bench.py cannot
+    collect counters itself); None when the file does not hold the kernel -- a figure from an earlier round's kernels is never printed
+    under this round's headline."""
+    try:
+        entry = json.loads((REPO / "profiles" / PMC_TRAFFIC_FILE).read_text()).get(kernel)
+    except (OSError, ValueError):
+        entry = None
+    return None if entry is None else dict(entry, source=f"profiles/{PMC_TRAFFIC_FILE}")
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -156,8 +165,10 @@ def measure_conv_roofline(lib, device, batch: int, h: int, w: int, reps: int = 5
     return {
         "bound": "mfma", "kernel": "conv3x3_mfma_kernel", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-        "traffic": None if t is None else (t["fetch_bytes_per_image"] + t["write_bytes_per_image"]) * batch,
-        "traffic_note": None if t is None else f"HBM bytes per launch (avg over the 8 launches), rocprofv3 PMC, {t['source']}",
+        "traffic": None if t is None else t["fetch_bytes_per_image"] + t["write_bytes_per_image"],
+        "algorithmic_bytes": None if t is None else t.get("algorithmic_bytes_per_image"),
+        "traffic_note": None if t is None else ("HBM-side bytes PER IMAGE over the whole 8-launch stack (fetched + written), beside algorithmic_bytes = every layer's input read once + "
+                                                f"every layer's output written once per image; rocprofv3 PMC, {t['source']}"),
         "launches_per_step": launches, "avg_launch_ms": round(total_ms / launches, 4), "flops_per_step": total_flops, **first,
     }
 
@@ -206,7 +217,9 @@ def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5, 
 
 
 def measure_gemm_roofline(lib, device, rows: int, k: int, n: int, reps: int = 5):
-    """The matchers' projection GEMM at one of their shapes (rows x k -> n), row-major weights (LDS-DMA kernel)."""
+    """The matchers' projection GEMM at one of their shapes (rows x k -> n), row-major weights (LDS-DMA kernel). Under GTSFM_GEMM_MATH=bf16x3
+    (read by the entry point) the kernel executes six bf16 MFMA products per fp32 product term: `frac` is then EXECUTED bf16 FLOP/s over the
+    bf16 MFMA roof, and the algorithmic fp32 rate against the fp32 roof is a side field -- no `frac` in the line exceeds 1."""
     from gtsfm_amd.runtime import lib as L
 
     stream = torch.cuda.current_stream(device)
@@ -217,6 +230,14 @@ def measure_gemm_roofline(lib, device, rows: int, k: int, n: int, reps: int = 5)
     args = (a.data_ptr(), k, rows, None, k, w.data_ptr(), k, bias.data_ptr(), n, None, c.data_ptr(), n, 0, None, 0, 1.0, 0, stream.cuda_stream)
     ms = _time_launches(lambda: L.check(lib.gtsfm_linear_rowmajor_f32(*args), "linear_rowmajor"), stream, reps)
     achieved = 2.0 * rows * k * n / (ms * 1e-3) / 1e12
+    if (os.environ.get("GTSFM_GEMM_MATH") or "")[:1] == "b":
+        executed = 6.0 * achieved
+        return {
+            "bound": "mfma", "kernel": "gemm_dma_walk_kernel<X3>", "achieved": round(executed, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (executed bf16)",
+            "frac": round(executed / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 4), "launch_shape": f"{rows} x {k} -> {n}",
+            "algorithmic_tflops": round(achieved, 2), "algorithmic_frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "arithmetic": "bf16x3: six bf16 MFMA products per fp32 product term, operands split in registers", "traffic": None,
+        }
     t = pmc_traffic(f"gemm_dma_walk_kernel@{rows}x{k}x{n}")
     return {
         "bound": "mfma", "kernel": "gemm_dma_walk_kernel", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -267,6 +288,62 @@ def measure_sinkhorn_roofline(lib, device, n: int, npairs: int, iters: int = 20)
         "launch_shape": f"{npairs} pairs, ({n}+1) x ({n}+1) couplings", "traffic": None if t is None else t["fetch_bytes"] + t["write_bytes"],
         "traffic_note": None if t is None else f"HBM bytes per iteration, rocprofv3 PMC, {t['source']}",
     }
+
+
+def measure_lg_assignment_roofline(lib, device, n: int, npairs: int, reps: int = 5):
+    """LightGlue's last stage on `npairs` N x N similarity matrices, its two halves timed separately through gtsfm_lg_assignment_f32: the two
+    log-softmax sweeps (lg_rows[_wide]_kernel + lg_cols_kernel) and the match extraction (extract_rows[_wide]_kernel + extract_cols_kernel +
+    mutual_matches) -- each ONE read of the matrices, 4 N^2 B per pair, HBM-bound. The extraction is the kernel furthest below its roof in
+    the tree (compare / select chains on an under-occupied chip: DESIGN.md section 8); it is in the line for that reason."""
+    from gtsfm_amd.runtime import lib as L
+
+    if not hasattr(lib, "gtsfm_lg_assignment_f32"):
+        return []
+    stream = torch.cuda.current_stream(device)
+    ld = (n + 3) // 4 * 4
+    cap = -(-n // 128) * 128
+    sim = torch.randn((npairs, n, ld), device=device) * 4.0
+    zl = torch.randn((2 * npairs * cap,), device=device)
+    m = torch.full((npairs,), n, dtype=torch.int32)
+    ws = torch.empty(int(lib.gtsfm_lg_assignment_workspace_bytes(npairs, m.data_ptr(), m.data_ptr())), dtype=torch.uint8, device=device)
+    matches = torch.empty((2 * npairs * cap,), dtype=torch.int32, device=device)
+    ms = torch.empty((2 * npairs * cap,), dtype=torch.float32, device=device)
+
+    def run(stages):
+        L.check(lib.gtsfm_lg_assignment_f32(sim.data_ptr(), npairs, m.data_ptr(), m.data_ptr(), zl.data_ptr(), 0.1, stages, ws.data_ptr(), ws.numel(),
+                                            matches.data_ptr(), ms.data_ptr(), stream.cuda_stream), "lg_assignment")
+
+    run(1)
+    out = []
+    bytes_pass = 4.0 * n * n * npairs
+    for stages, kernel in ((1, ("lg_rows_kernel" if n <= 2048 else "lg_rows_wide_kernel") + " + lg_cols_kernel (double log-softmax)"),
+                           (2, ("extract_rows_kernel" if n <= 2048 else "extract_rows_wide_kernel") + " + extract_cols_kernel + mutual_matches (match extraction)")):
+        t = _time_launches(lambda: run(stages), stream, reps)  # includes the entry point's descriptor upload + one stream synchronisation (~0.03 ms)
+        achieved = bytes_pass / (t * 1e-3) / 1e9
+        pt = pmc_traffic(("lg_double_softmax" if stages == 1 else "lg_extract") + f"@{npairs}x{n}")
+        out.append({"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "avg_launch_ms": round(t, 4), "algorithmic_bytes": bytes_pass, "launch_shape": f"{npairs} pairs, {n} x {n} similarities",
+                    "traffic": None if pt is None else pt["fetch_bytes"] + pt["write_bytes"],
+                    "traffic_note": None if pt is None else f"HBM-side bytes per pass, rocprofv3 PMC, {pt['source']}"})
+    return out
+
+
+def measure_layernorm_roofline(lib, device, rows: int, reps: int = 5):
+    """layernorm_gelu_kernel over `rows` token rows of 512 floats, in place: 2 x rows x 512 x 4 B, HBM-bound (1.3 % of the headline step)."""
+    from gtsfm_amd.runtime import lib as L
+
+    if not hasattr(lib, "gtsfm_layernorm_gelu_f32"):
+        return None
+    stream = torch.cuda.current_stream(device)
+    x = torch.randn((rows, 512), device=device)
+    gamma, beta = torch.ones(512, device=device), torch.zeros(512, device=device)
+    scratch = torch.empty(64, dtype=torch.uint8, device=device)
+    t = _time_launches(lambda: L.check(lib.gtsfm_layernorm_gelu_f32(x.data_ptr(), 512, rows, gamma.data_ptr(), beta.data_ptr(), scratch.data_ptr(), stream.cuda_stream),
+                                       "layernorm_gelu"), stream, reps)
+    nbytes = 2.0 * rows * 512 * 4
+    achieved = nbytes / (t * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "layernorm_gelu_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "avg_launch_ms": round(t, 4), "algorithmic_bytes": nbytes, "launch_shape": f"{rows} rows x 512 (read + written in place)", "traffic": None}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -643,11 +720,14 @@ def main() -> None:
             kept_frac = float(torch.cat([r["kept"] for r in res]).float().mean()) / max(1, args.keypoints)
         n_img_total = args.images if scene else n * world
         flops_step = superpoint_flops(h, w) * n_img_total
+        folded_step = 0.0
         if res:
+            folded_step = folded_projection_flops(args.matcher, args.keypoints, layers) * units_per_step
             flops_step += matcher_flops(args.matcher, args.keypoints, layers, args.sinkhorn) * units_per_step
             shared_images = int(getattr(pipe, "last_shared_images", 0))
             if shared_images:  # executed work: the per-image block once per image of this rank's table, not twice per pair
                 flops_step -= first_block_flops(args.matcher, args.keypoints) * (2 * len(pairs) - shared_images) * world  # ranks are balanced
+                folded_step -= 2.0 * 256 * 256 * args.keypoints * (2 * len(pairs) - shared_images) * world  # that block's folded projection likewise
         if detect_only:
             workload = f"SuperPoint-only: {n} synthetic {h}x{w} gray images per GPU per step"
         elif scene:
@@ -697,7 +777,10 @@ def main() -> None:
                                                 "bit-identical matches (tests/test_matchers_gpu.py)") if getattr(pipe, "last_shared_images", 0)
                                                else "per pair side (nothing shared)",
             },
-            "tflops": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2),
+            # SURVEY.md section 8(d)'s per-unit formula x the units of a step (the per-image first block counted once per image when shared):
+            # the ALGORITHMIC rate, which is what a roofline compares; executed_tflops leaves out the products the folded projections remove
+            "algorithmic_tflops": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2),
+            "executed_tflops": round((flops_step - folded_step) / (ms_per_step * 1e-3) / 1e12, 2),
         }
         if args.dump_matches:
             import hashlib
@@ -748,6 +831,10 @@ def main() -> None:
                     other = [guarded(measure_gemm_roofline, lib, device, rows, k, nn) for k, nn in ((256, 768), (512, 512), (512, 256), (256, 512))]
                     other.append(guarded(measure_score_gemm_roofline, lib, device, args.keypoints, chunk_pairs))
                     other.append(guarded(measure_sinkhorn_roofline, lib, device, args.keypoints, chunk_pairs))  # SuperGlue legs (headline or secondary)
+                    if args.matcher == "lightglue" or not args.no_secondary:  # the worst kernel of the tree belongs in the line
+                        lga = guarded(measure_lg_assignment_roofline, lib, device, args.keypoints, chunk_pairs)
+                        other.extend(lga if isinstance(lga, list) else [lga])
+                        other.append(guarded(measure_layernorm_roofline, lib, device, rows))
                     result["roofline_other"] = [r for r in other if r is not None] + [conv_roof]
             base = ora = None
             if world == 1 and not args.no_cpu_baseline:  # rank 0 at N = 1 only
@@ -1013,7 +1100,7 @@ def config2_superpoint_rate(lib, detector, device, with_oracle: bool):
     kc = np.asarray(feats["count"].tolist())
     out = {"value": round(n / (ms * 1e-3), 1), "unit": "images/s", **timing, "images_per_step": n, "dtype": "f32",
            "keypoints_per_image": {"min": int(kc.min()), "median": int(np.median(kc)), "max": int(kc.max())},
-           "tflops": round(superpoint_flops(h, w) * n / (ms * 1e-3) / 1e12, 2),
+           "algorithmic_tflops": round(superpoint_flops(h, w) * n / (ms * 1e-3) / 1e12, 2),
            "workload": f"BASELINE config 2: SuperPoint detect+describe over {n} synthetic {w}x{h} gray uint8 images resident in HBM, batches of 16, top-{cap} keypoints kept on the device",
            "roofline": measure_conv_roofline(lib, device, 16, h, w)}
     if with_oracle:
@@ -1128,8 +1215,7 @@ def attention_bf16x3_rate(args, lib, detector, matcher, images, pairs, shapes, d
         roof = measure_attention_roofline(lib, device, args.keypoints, min(args.pair_chunk, len(pairs)), math=1)
         if gemm_too:
             rows = 2 * min(args.pair_chunk, len(pairs)) * (-(-args.keypoints // 128) * 128)
-            roof = {"attention": roof, "gemm": [dict(measure_gemm_roofline(lib, device, rows, k, nn), kernel="gemm_dma_walk_kernel<X3>", arithmetic="bf16x3: frac is algorithmic fp32 FLOP/s over the fp32 MFMA roof")
-                                                for k, nn in ((256, 768), (512, 512), (512, 256))]}
+            roof = {"attention": roof, "gemm": [measure_gemm_roofline(lib, device, rows, k, nn) for k, nn in ((256, 768), (512, 512), (512, 256))]}
     finally:
         for k, v in old.items():
             if v is None:

@@ -142,7 +142,10 @@ extern "C" int gtsfm_match_build_desc(int superglue, int npairs, const int32_t* 
     for (int p = 0; p < npairs; ++p) max_n1 = max_n1 > n1[p] ? max_n1 : n1[p];
     const int R = sweep_partial_rows(max_n1, ext);
     for (int p = 0; p < npairs; ++p) {
-        GTSFM_CHECK_ARG(n0[p] > 0 && n1[p] > 0, "match_build_desc: pair %d has an empty keypoint set", p);
+        // an empty SECOND set is a valid descriptor: the per-image phase (gtsfm_{sg,lg}_forward_phase, phase 1) takes keypoint sets two at a
+        // time and an odd number of images leaves the last slot empty (no tiles, no rows, count 0: every kernel skips it). The whole-pair
+        // phases reject it themselves.
+        GTSFM_CHECK_ARG(n0[p] > 0 && n1[p] >= 0, "match_build_desc: pair %d has an empty keypoint set", p);
         const int ns[2] = {n0[p], n1[p]};
         int offs[2];
         out[L.stop + p] = -1;
@@ -328,6 +331,7 @@ static int sg_forward_phased(const float* wts, int num_layers, float bin_score, 
     GTSFM_CHECK_ARG(phase == 2 || (kpts_dev && scores_dev), "sg_forward: null keypoints / scores");
     GTSFM_CHECK_ARG(phase >= 0 && phase <= 2 && (phase == 0 || num_layers >= 1), "sg_forward: bad phase");
     GTSFM_CHECK_ARG(npairs > 0 && num_layers >= 0 && sinkhorn_iters >= 0, "sg_forward: bad arguments");
+    for (int p = 0; p < npairs; ++p) GTSFM_CHECK_ARG(n0[p] > 0 && (n1[p] > 0 || (phase == 1 && n1[p] == 0)), "sg_forward: pair %d has an empty keypoint set", p);
     const BatchDims d = batch_dims(npairs, n0, n1, 1);
     const int attn_math = attention_math_from_env();  // GTSFM_ATTENTION_MATH, read per call (sizing and launches of one call agree)
     const int gemm_math = gemm_math_from_env();       // GTSFM_GEMM_MATH: the matchers' projection / FFN / score GEMMs only
@@ -539,6 +543,90 @@ extern "C" int gtsfm_sinkhorn_f32(float* z_dev, int npairs, const int32_t* m, co
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Stand-alone LightGlue assignment (sigmoid_log_double_softmax + filter_matches on given similarity matrices) and stand-alone
+// LayerNorm + GELU: parity tests against torch, bench.py's rooflines of the sweep / row kernels the forward launches
+// ---------------------------------------------------------------------------------------------------------------
+
+namespace {
+
+struct LgaWorkspace {
+    size_t desc, part, uv_row, uv_col, max0, idx0, idx1, total;
+};
+
+LgaWorkspace lga_workspace_layout(int P, const int32_t* m, const int32_t* n) {
+    LgaWorkspace w;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t r = o;
+        o += align_up(bytes, 256);
+        return r;
+    };
+    size_t Tp = 0, part = 0;
+    int mx = 0;
+    for (int p = 0; p < P; ++p) mx = mx > n[p] ? mx : n[p];
+    const int R = sweep_partial_rows(mx, 0);
+    for (int p = 0; p < P; ++p) {
+        Tp += (size_t)cap128(m[p]) + cap128(n[p]);
+        part += (size_t)ceil_div(m[p], R) * z_ld(n[p], 0) * 2;
+    }
+    w.desc = take(desc_layout(P, count_tiles(0, P, m, n)).total * sizeof(int32_t));
+    w.part = take(part * 4);
+    w.uv_row = take((Tp + 16 * (size_t)P + 8) * 4), w.uv_col = take((Tp + 16 * (size_t)P + 8) * 4);
+    w.max0 = take(Tp * 4), w.idx0 = take(Tp * 4), w.idx1 = take(Tp * 4);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t gtsfm_lg_assignment_workspace_bytes(int npairs, const int32_t* m, const int32_t* n) {
+    if (npairs <= 0 || !m || !n) return 256;
+    return lga_workspace_layout(npairs, m, n).total;
+}
+
+extern "C" int gtsfm_lg_assignment_f32(const float* sim_dev, int npairs, const int32_t* m, const int32_t* n, const float* zlogit_dev,
+                                       float filter_threshold, int stages, void* workspace_dev, size_t workspace_bytes, int32_t* matches_dev,
+                                       float* mscores_dev, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GTSFM_CHECK_ARG(sim_dev && m && n && zlogit_dev && workspace_dev && matches_dev && mscores_dev, "lg_assignment: null pointer");
+    GTSFM_CHECK_ARG(npairs > 0 && stages >= 1 && stages <= 3, "lg_assignment: stages is 1 (double-softmax sweeps), 2 (extraction; after a call with 1 on the same workspace) or 3 (both)");
+    const LgaWorkspace ws = lga_workspace_layout(npairs, m, n);
+    if (workspace_bytes < ws.total) {
+        gtsfm_set_error("lg_assignment: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.total);
+        return GTSFM_ERR_WORKSPACE;
+    }
+    const DescLayout DL = desc_layout(npairs, count_tiles(0, npairs, m, n));
+    std::vector<int32_t> host(DL.total), hw((size_t)4 * npairs, 1);
+    TRY(gtsfm_match_build_desc(0, npairs, m, n, hw.data(), host.data()));
+    for (int s = 0; s < 2 * npairs; ++s) host[DL.final_cnt + s] = host[DL.live + s];  // the assignment runs over the kept keypoints: all of them here
+    char* wsp = (char*)workspace_dev;
+    int32_t* desc_dev = (int32_t*)(wsp + ws.desc);
+    if (hipMemcpyAsync(desc_dev, host.data(), DL.total * sizeof(int32_t), hipMemcpyHostToDevice, stream) != hipSuccess) return GTSFM_ERR_HIP;
+    if (hipStreamSynchronize(stream) != hipSuccess) return GTSFM_ERR_HIP;  // `host` goes out of scope below
+    int max_m = 0, max_n = 0;
+    for (int p = 0; p < npairs; ++p) max_m = max_m > m[p] ? max_m : m[p], max_n = max_n > n[p] ? max_n : n[p];
+    SweepArgs sa;
+    sa.pairs = (const PairDesc*)(desc_dev + DL.pairs), sa.seqs = (const SeqDesc*)(desc_dev + DL.seqs), sa.counts = desc_dev + DL.final_cnt;
+    sa.npairs = npairs, sa.max_m = max_m, sa.max_n = max_n;
+    sa.zbuf = const_cast<float*>(sim_dev), sa.rowvec = (float*)(wsp + ws.uv_row), sa.colvec = (float*)(wsp + ws.uv_col), sa.partials = (float*)(wsp + ws.part);
+    if (stages & 1) TRY(launch_double_softmax_lse(sa, stream));
+    if (stages & 2)
+        TRY(launch_extract_matches(sa, 0, zlogit_dev, filter_threshold, (float*)(wsp + ws.max0), (int*)(wsp + ws.idx0), (int*)(wsp + ws.idx1), matches_dev,
+                                   mscores_dev, stream));
+    return GTSFM_OK;
+}
+
+extern "C" int gtsfm_layernorm_gelu_f32(float* x_dev, int ld, int rows, const float* gamma_dev, const float* beta_dev, void* scratch_dev, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GTSFM_CHECK_ARG(x_dev && gamma_dev && beta_dev && scratch_dev && rows >= 0 && ld >= 512, "layernorm_gelu: bad arguments (512 columns per row, 64 bytes of scratch)");
+    if (rows == 0) return GTSFM_OK;
+    const int32_t host[8] = {0, 6, 0, 0, 0, rows, rows, 0};  // SeqDesc {row_off 0, cnt_idx 6, H, W, in_off, cap} followed by the count it points at
+    if (hipMemcpyAsync(scratch_dev, host, sizeof(host), hipMemcpyHostToDevice, stream) != hipSuccess) return GTSFM_ERR_HIP;
+    if (hipStreamSynchronize(stream) != hipSuccess) return GTSFM_ERR_HIP;  // `host` is a stack array
+    return launch_layernorm_gelu(x_dev, ld, (const SeqDesc*)scratch_dev, (const int*)scratch_dev, 1, rows, gamma_dev, beta_dev, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LightGlue (features = "superpoint": 9 layers, 4 heads x 64, descriptor_dim 256)
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -614,6 +702,7 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
     GTSFM_CHECK_ARG(wts && match_bias_host && n0 && n1 && desc_dev && kpts_dev && descriptors_dev && workspace_dev, "lg_forward: null pointer");
     GTSFM_CHECK_ARG(phase >= 0 && phase <= 2 && (phase == 1 ? x_out_dev != nullptr : (matches_dev && mscores_dev)), "lg_forward: bad phase / null output");
     GTSFM_CHECK_ARG(npairs > 0 && num_layers > 0 && (num_layers == 1 || conf_bias_host), "lg_forward: bad arguments");
+    for (int p = 0; p < npairs; ++p) GTSFM_CHECK_ARG(n0[p] > 0 && (n1[p] > 0 || (phase == 1 && n1[p] == 0)), "lg_forward: pair %d has an empty keypoint set", p);
     const LgDims d = lg_dims(npairs, n0, n1);
     const int attn_math = attention_math_from_env();  // GTSFM_ATTENTION_MATH, read per call (sizing and launches of one call agree)
     const int gemm_math = gemm_math_from_env();       // GTSFM_GEMM_MATH: the matchers' projection / FFN / score GEMMs only

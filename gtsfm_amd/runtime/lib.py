@@ -131,6 +131,12 @@ SIGNATURES = {
          C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "gtsfm_verify_compact_matches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gtsfm_lg_assignment_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p]),
+    "gtsfm_lg_assignment_f32": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "gtsfm_layernorm_gelu_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gtsfm_lg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_void_p, C.c_void_p]),
     "gtsfm_lg_forward": (
         C.c_int,

@@ -119,10 +119,31 @@ class _ImageEntry:
     """One image's device-resident matcher inputs (the per-call plugin path): its keypoints (and scores) as uploaded and the output
     of ``prepare_images`` -- the matcher block that sees ONE image. ``ready`` orders consumers on other lanes' streams behind it."""
 
-    __slots__ = ("kpts", "scores", "x", "ready", "stream")
+    __slots__ = ("kpts", "scores", "x", "ready", "stream", "digest")
 
-    def __init__(self, kpts, scores, x, ready, stream):
-        self.kpts, self.scores, self.x, self.ready, self.stream = kpts, scores, x, ready, stream
+    def __init__(self, kpts, scores, x, ready, stream, digest=None):
+        self.kpts, self.scores, self.x, self.ready, self.stream, self.digest = kpts, scores, x, ready, stream, digest
+
+
+def _full_digest(arrays: Sequence[np.ndarray]) -> bytes:
+    """Checksum over EVERY byte of an image's host arrays (xxh3-128 where the xxhash package is importable: 0.4 ms per 5000 x 256 float32
+    descriptor matrix; zlib.crc32 + adler32 otherwise: 7 ms). The per-call path's image cache is validated against it on every hit, while the
+    GPU already works on the pair (``_MatcherBase._entries_still_valid``): a cached image can never be served for changed arrays."""
+    try:
+        import xxhash
+
+        h = xxhash.xxh3_128()
+        for a in arrays:
+            h.update(np.ascontiguousarray(a))
+        return h.digest()
+    except ImportError:
+        import zlib
+
+        crc = adler = 0
+        for a in arrays:
+            buf = np.ascontiguousarray(a)
+            crc, adler = zlib.crc32(buf, crc), zlib.adler32(buf, adler)
+        return crc.to_bytes(4, "little") + adler.to_bytes(4, "little")
 
 
 class _MatcherBase:
@@ -156,7 +177,7 @@ class _MatcherBase:
         self.image_cache_capacity = max(0, int(os.environ.get("GTSFM_PLUGIN_IMAGE_CACHE", "64")))
         self._image_cache: "OrderedDict[tuple, _ImageEntry]" = OrderedDict()
         self._image_cache_lock = threading.Lock()
-        self.image_cache_hits = self.image_cache_misses = 0
+        self.image_cache_hits = self.image_cache_misses = self.image_cache_stale = 0
 
     def _init_call_state(self) -> None:
         """Everything a call writes; a lane has its own."""
@@ -169,6 +190,7 @@ class _MatcherBase:
         self._pinning = False
         self._staging: Optional[dict] = None
         self._lane_stream: Optional[torch.cuda.Stream] = None
+        self._last_lookup: tuple = ((), [])  # what the last _image_entries call of this lane found (read by _entries_still_valid)
 
     def _sibling(self) -> "_MatcherBase":
         """An engine sharing this one's weights (read-only on the device) and nothing a call writes: built from the explicit list
@@ -228,10 +250,13 @@ class _MatcherBase:
 
     @staticmethod
     def _image_key(arrays: Sequence[np.ndarray], shape: Tuple[int, int]) -> tuple:
-        """Identity of one image's host arrays as a ``match()`` call hands them over: address, shape, dtype and strides of every array
+        """LOOKUP key of one image's host arrays as a ``match()`` call hands them over: address, shape, dtype and strides of every array
         plus a hash over a sample of rows (the first and last 10 and 16 evenly spaced ones) -- the reference's own MatcherCacher keys
-        a pair on the first 10 rows alone (gtsfm/frontend/cacher/matcher_cacher.py:24,46-80). An array that is overwritten in place
-        between two calls AND keeps all sampled rows would be taken for the old one; GTSFM_PLUGIN_IMAGE_CACHE=0 turns the cache off."""
+        a pair on the first 10 rows alone (gtsfm/frontend/cacher/matcher_cacher.py:24,46-80). Cheap enough for the critical path of a
+        call (0.05 ms); it only FINDS a candidate entry. Whether the candidate still describes the arrays is decided by the checksum over
+        all of their bytes (``_full_digest``), verified on every hit while the GPU runs the pair (``_entries_still_valid``): an array
+        overwritten in place that keeps all sampled rows is detected there and the pair is redone from the arrays (round 5; until then
+        such a caller was served the old features). GTSFM_PLUGIN_IMAGE_CACHE=0 turns the cache off."""
         n = len(arrays[0])
         rows = np.unique(np.concatenate([np.arange(min(10, n)), np.arange(max(0, n - 10), n), np.linspace(0, n - 1, 16).astype(np.int64)])) if n else np.zeros(0, np.int64)
         h = hashlib.blake2b(digest_size=16)
@@ -268,9 +293,11 @@ class _MatcherBase:
                 # call live on) and is enqueued on the producer stream BEFORE the event consumers on other lanes wait for
                 kp = staged[0][off : off + c].clone()
                 sc = staged[1][off : off + c].reshape(-1).clone() if len(staged) == 3 else None
-                found[i] = _ImageEntry(kp, sc, x[off : off + c].clone() if len(miss) > 1 else x[off : off + c], ready, stream)
+                found[i] = _ImageEntry(kp, sc, x[off : off + c].clone() if len(miss) > 1 else x, ready, stream)
                 off += c
             ready.record(stream)  # after the clones: a consumer lane that waits for `ready` sees kpts / scores / x complete
+            for i in miss:  # over every byte, on the host while the device runs the upload and the per-image block; before the entry is published
+                found[i].digest = _full_digest(images[i][0])
             with root._image_cache_lock:
                 for i in miss:
                     root._image_cache[keys[i]] = found[i]
@@ -289,7 +316,25 @@ class _MatcherBase:
                 for t in (e.kpts, e.scores, e.x):
                     if t is not None:
                         t.record_stream(stream)
+        self._last_lookup = (keys, [i not in miss and keys[i] not in [keys[m] for m in miss] for i in range(len(images))])
         return found
+
+    def _entries_still_valid(self, images: Sequence[Tuple[Sequence[np.ndarray], Tuple[int, int]]], entries: Sequence[_ImageEntry]) -> bool:
+        """Called between enqueueing a pair's launches and fetching its result: the entries that came from the cache (hits of the cheap
+        lookup key) are checked against the checksum over ALL bytes of the arrays they were found for. The GPU is busy with the pair
+        meanwhile (11 ms at the 5000-keypoint cap against 0.8 ms for two images), so a hit costs the call nothing. An entry that fails is
+        dropped from the cache and False is returned: the caller discards the enqueued result and runs the pair again from the arrays."""
+        root = self._root
+        keys, was_hit = self._last_lookup
+        ok = True
+        for (arrs, _), e, key, hit in zip(images, entries, keys, was_hit):
+            if hit and e.digest != _full_digest(arrs):
+                ok = False
+                with root._image_cache_lock:
+                    if root._image_cache.get(key) is e:
+                        del root._image_cache[key]
+                    root.image_cache_stale += 1
+        return ok
 
     def _stage_pair(self, arrays0: Sequence[np.ndarray], arrays1: Sequence[np.ndarray]) -> List[torch.Tensor]:
         """Host arrays of the two images of ONE pair -> device tensors [n0 + n1, ...], one per array (see ``_stage_sets``)."""
@@ -456,24 +501,23 @@ class SuperGlueEngine(_MatcherBase):
         shapes = [tuple(int(v) for v in s) for s in shapes]
         t = sum(counts)
         assert kpts.shape == (t, 2) and scores.shape == (t,) and desc.shape == (t, 256) and min(counts) > 0
-        if len(counts) % 2:  # the ABI works on pairs of keypoint sets: run the last image twice
-            last = counts[-1]
-            kpts, scores, desc = torch.cat([kpts, kpts[t - last :]]), torch.cat([scores, scores[t - last :]]), torch.cat([desc, desc[t - last :]])
-            counts, shapes = counts + [last], shapes + [shapes[-1]]
+        kpts, scores, desc = kpts.contiguous(), scores.contiguous(), desc.contiguous()
+        if len(counts) % 2:  # the ABI takes keypoint sets two at a time: an odd last image leaves the second slot empty (count 0: no rows, no work)
+            counts, shapes = counts + [0], shapes + [shapes[-1]]
         n0 = np.ascontiguousarray(counts[0::2], dtype=np.int32)
         n1 = np.ascontiguousarray(counts[1::2], dtype=np.int32)
         hw = np.ascontiguousarray([[*shapes[2 * q], *shapes[2 * q + 1]] for q in range(len(n0))], dtype=np.int32)
         dsc = self._build_desc(True, n0, n1, hw)
         need = self._lib.gtsfm_sg_workspace_bytes(len(n0), n0.ctypes.data, n1.ctypes.data)
         ws = workspace if workspace is not None and workspace.numel() >= need else self._get_workspace(need)
-        x = torch.empty((kpts.shape[0], 256), dtype=torch.float32, device=self.device)
+        x = torch.empty((t, 256), dtype=torch.float32, device=self.device)
         rc = self._lib.gtsfm_sg_forward_phase(
             self.weights.data_ptr(), self.num_layers, self.bin_score, len(n0), n0.ctypes.data, n1.ctypes.data, dsc.data_ptr(),
-            kpts.contiguous().data_ptr(), scores.contiguous().data_ptr(), desc.contiguous().data_ptr(), 0, 0.0, ws.data_ptr(), ws.numel(),
+            kpts.data_ptr(), scores.data_ptr(), desc.data_ptr(), 0, 0.0, ws.data_ptr(), ws.numel(),
             None, None, None, 1, x.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream,
         )
         _lib.check(rc, "gtsfm_sg_forward_phase")
-        return x[:t]
+        return x
 
     def match_pair(
         self, k0: np.ndarray, s0: np.ndarray, d0: np.ndarray, k1: np.ndarray, s1: np.ndarray, d1: np.ndarray,
@@ -491,9 +535,13 @@ class SuperGlueEngine(_MatcherBase):
         with self._lane() as eng:
             hw = [[shape0[0], shape0[1], shape1[0], shape1[1]]]
             if self.image_cache_capacity > 0 and self.num_layers >= 1:
-                e0, e1 = eng._image_entries([((k0, s0, d0), shape0), ((k1, s1, d1), shape1)])
-                out = eng.match_batch(torch.cat([e0.kpts, e1.kpts]), torch.cat([e0.scores, e1.scores]), torch.cat([e0.x, e1.x]), [n0], [n1], hw,
-                                      sinkhorn_iterations, match_threshold, return_ot, first_layer_done=True)
+                images = [((k0, s0, d0), shape0), ((k1, s1, d1), shape1)]
+                for attempt in range(2):  # a second round only when a cached image turned out to be stale (its entry is gone by then)
+                    e0, e1 = eng._image_entries(images)
+                    out = eng.match_batch(torch.cat([e0.kpts, e1.kpts]), torch.cat([e0.scores, e1.scores]), torch.cat([e0.x, e1.x]), [n0], [n1], hw,
+                                          sinkhorn_iterations, match_threshold, return_ot, first_layer_done=True)
+                    if eng._entries_still_valid(images, (e0, e1)):
+                        break
             else:
                 kp, sc, de = eng._stage_pair((k0, s0, d0), (k1, s1, d1))
                 out = eng.match_batch(kp, sc.reshape(-1), de, [n0], [n1], hw, sinkhorn_iterations, match_threshold, return_ot)
@@ -668,24 +716,23 @@ class LightGlueEngine(_MatcherBase):
         shapes = [tuple(int(v) for v in s) for s in shapes]
         t = sum(counts)
         assert kpts.shape == (t, 2) and desc.shape == (t, 256) and min(counts) > 0
-        if len(counts) % 2:  # the ABI works on pairs of keypoint sets: run the last image twice
-            last = counts[-1]
-            kpts, desc = torch.cat([kpts, kpts[t - last :]]), torch.cat([desc, desc[t - last :]])
-            counts, shapes = counts + [last], shapes + [shapes[-1]]
+        kpts, desc = kpts.contiguous(), desc.contiguous()
+        if len(counts) % 2:  # the ABI takes keypoint sets two at a time: an odd last image leaves the second slot empty (count 0: no rows, no work)
+            counts, shapes = counts + [0], shapes + [shapes[-1]]
         n0 = np.ascontiguousarray(counts[0::2], dtype=np.int32)
         n1 = np.ascontiguousarray(counts[1::2], dtype=np.int32)
         hw = np.ascontiguousarray([[*shapes[2 * q], *shapes[2 * q + 1]] for q in range(len(n0))], dtype=np.int32)
         dsc = self._build_desc(False, n0, n1, hw)
         need = self._lib.gtsfm_lg_workspace_bytes(len(n0), n0.ctypes.data, n1.ctypes.data)
         ws = workspace if workspace is not None and workspace.numel() >= need else self._get_workspace(need)
-        x = torch.empty((kpts.shape[0], 256), dtype=torch.float32, device=self.device)
+        x = torch.empty((t, 256), dtype=torch.float32, device=self.device)
         rc = self._lib.gtsfm_lg_forward_phase(
             self.weights.data_ptr(), self.num_layers, self.match_bias.ctypes.data, self.conf_bias.ctypes.data, len(n0),
-            n0.ctypes.data, n1.ctypes.data, dsc.data_ptr(), kpts.contiguous().data_ptr(), desc.contiguous().data_ptr(), 0.0, 0.0, 0.0, NO_PRUNING,
+            n0.ctypes.data, n1.ctypes.data, dsc.data_ptr(), kpts.data_ptr(), desc.data_ptr(), 0.0, 0.0, 0.0, NO_PRUNING,
             ws.data_ptr(), ws.numel(), None, None, None, 1, x.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream,
         )
         _lib.check(rc, "gtsfm_lg_forward_phase")
-        return x[:t]
+        return x
 
     def match_pair(
         self, k0: np.ndarray, d0: np.ndarray, k1: np.ndarray, d1: np.ndarray, shape0: Tuple[int, int], shape1: Tuple[int, int],
@@ -703,8 +750,12 @@ class LightGlueEngine(_MatcherBase):
         with self._lane() as eng:
             hw = [[shape0[0], shape0[1], shape1[0], shape1[1]]]
             if self.image_cache_capacity > 0 and not kwargs.get("first_layer_done", False):
-                e0, e1 = eng._image_entries([((k0, d0), shape0), ((k1, d1), shape1)])
-                out = eng.match_batch(torch.cat([e0.kpts, e1.kpts]), torch.cat([e0.x, e1.x]), [n0], [n1], hw, **dict(kwargs, first_layer_done=True))
+                images = [((k0, d0), shape0), ((k1, d1), shape1)]
+                for attempt in range(2):  # a second round only when a cached image turned out to be stale (its entry is gone by then)
+                    e0, e1 = eng._image_entries(images)
+                    out = eng.match_batch(torch.cat([e0.kpts, e1.kpts]), torch.cat([e0.x, e1.x]), [n0], [n1], hw, **dict(kwargs, first_layer_done=True))
+                    if eng._entries_still_valid(images, (e0, e1)):
+                        break
             else:
                 kp, de = eng._stage_pair((k0, d0), (k1, d1))
                 out = eng.match_batch(kp, de, [n0], [n1], hw, **kwargs)

@@ -172,7 +172,8 @@ size_t gtsfm_blob_floats(int count, const int32_t* kinds, const int32_t* n, cons
 int gtsfm_pack_blob(int count, const int32_t* kinds, const int32_t* n, const int32_t* k, const float* const* w_host,
                     const float* const* b_host, float* packed_host);
 
-/* Batch descriptors. A batch is `npairs` image pairs; pair p has n0[p] / n1[p] keypoints (all > 0) and image shapes
+/* Batch descriptors. A batch is `npairs` image pairs; pair p has n0[p] / n1[p] keypoints (all > 0; n1[p] == 0 is accepted for
+ * the per-image phase 1 of gtsfm_{sg,lg}_forward_phase only: an odd number of images leaves the last second slot empty) and image shapes
  * hw[p] = {H0, W0, H1, W1}. Token-major inputs concatenate the keypoint sets in the order pair0/img0, pair0/img1,
  * pair1/img0, ... (T = sum of all counts rows). The int32 descriptor block (counts, per-set row offsets / image
  * shapes, per-pair score-matrix offsets, attention problem lists) is built on the host and uploaded by the caller;
@@ -257,7 +258,8 @@ int gtsfm_sinkhorn_f32(float* z_dev, int npairs, const int32_t* m_host, const in
 /* The same, split at the point where a pair's two images first see each other (for callers that match one image against
  * many: the per-image part runs once per image instead of once per pair; results are bit-identical to gtsfm_sg_forward).
  * phase 1: keypoint encoder + the first (self) GNN layer of every keypoint set of the batch (superglue.py:243-248, first
- * iteration of :126-137) -> x_out_dev [T][256] in the input's row order; matches / scores outputs unused (may be NULL).
+ * iteration of :126-137) -> x_out_dev [T][256] in the input's row order; matches / scores outputs unused (may be NULL);
+ * the keypoint sets are independent here, so an odd number of images is passed with n1 = 0 in the last slot.
  * phase 2: descriptors_dev holds that x; kpts_dev / scores_dev unused; the rest of the forward. phase 0 = gtsfm_sg_forward. */
 int gtsfm_sg_forward_phase(const float* blob_dev, int num_layers, float bin_score, int npairs, const int32_t* n0_host,
                            const int32_t* n1_host, const int32_t* desc_dev, const float* kpts_dev, const float* scores_dev,
@@ -281,6 +283,26 @@ int gtsfm_lg_forward(const float* blob_dev, int num_layers, const float* match_b
                      const float* kpts_dev, const float* descriptors_dev, float depth_confidence,
                      float width_confidence, float filter_threshold, int pruning_threshold, void* workspace_dev,
                      size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev, void* stream);
+
+/* LightGlue's assignment stage alone, on given similarity matrices (parity tests; bench.py's rooflines of the sweep kernels the forward
+ * launches).                                  replaces upstream sigmoid_log_double_softmax + filter_matches (call site
+ *                                             gtsfm/frontend/matcher/lightglue_matcher.py:104-110)
+ * sim_dev    : pair p's m[p] x n[p] similarities at float offset sum_{q<p} m[q] * ld[q], row stride ld[p] = n[p] rounded up to 4
+ * zlogit_dev : matchability logits, token-major with every keypoint set aligned to 128 rows (pair0/img0, pair0/img1, pair1/img0, ...:
+ *              set s starts at row sum of the previous sets' counts each rounded up to 128); matches_dev / mscores_dev: same layout,
+ *              match index within the other set or -1, exp(score) as upstream's matching_scores
+ * stages     : 1 = the two log-softmax sweeps (row / column log-sum-exp into the workspace), 2 = mutual arg-max extraction + filter
+ *              (needs the workspace of a call with 1 on the same inputs), 3 = both. Builds and uploads its own batch descriptor:
+ *              synchronises `stream` once. */
+size_t gtsfm_lg_assignment_workspace_bytes(int npairs, const int32_t* m_host, const int32_t* n_host);
+int gtsfm_lg_assignment_f32(const float* sim_dev, int npairs, const int32_t* m_host, const int32_t* n_host, const float* zlogit_dev,
+                            float filter_threshold, int stages, void* workspace_dev, size_t workspace_bytes, int32_t* matches_dev,
+                            float* mscores_dev, void* stream);
+
+/* x = gelu(layer_norm(x) * gamma + beta) in place over rows of 512 columns (row stride ld >= 512): the FFN's normalisation /
+ * activation of a LightGlue block (upstream nn.LayerNorm(512) + nn.GELU between ffn.0 and ffn.3), stand-alone for parity tests and
+ * bench.py's roofline. scratch_dev: 64 bytes of device memory; synchronises `stream` once. */
+int gtsfm_layernorm_gelu_f32(float* x_dev, int ld, int rows, const float* gamma_dev, const float* beta_dev, void* scratch_dev, void* stream);
 
 /* LightGlue split the same way: phase 1 = the first layer's SELF block (rotary self-attention + FFN of one image) -> x_out_dev;
  * phase 2 = descriptors_dev holds that x, the first self block is skipped. Bit-identical to gtsfm_lg_forward (phase 0). */

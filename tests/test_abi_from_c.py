@@ -46,6 +46,43 @@ def test_device_program_compiles_as_c(built_library, tmp_path):
     assert exe.exists()
 
 
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
+def test_model_program_compiles_as_c_and_its_header_is_current(built_library, tmp_path):
+    """CPU half of the model-level test: the program compiles and links here, and the expectation header it includes is what
+    oracle/make_abi_model_expectation.py writes today (same hash, same oracle) -- checked on its cheap fields."""
+    exe, _ = _build_c(tmp_path, built_library, "abi_model_from_c.c", ["-isystem", "/opt/rocm/include", f"-I{REPO / 'tests' / 'abi'}"])
+    assert exe.exists()
+    import re
+    import sys
+
+    sys.path.insert(0, str(REPO))
+    import numpy as np
+    import torch
+
+    from oracle import make_abi_model_expectation as gen
+    from oracle import superpoint_oracle as spo
+
+    header = (REPO / "tests" / "abi" / "abi_model_expected.h").read_text()
+    seed = int(re.search(r"#define ABI_MODEL_SEED (\d+)u", header).group(1))
+    k = int(re.search(r"#define ABI_MODEL_K (\d+)", header).group(1))
+    xy = np.array(re.findall(r"\{(\d+), (\d+)\}", header.split("abi_model_xy")[1].split(";")[0]), dtype=np.int64)
+    with torch.no_grad():
+        out = spo.superpoint_forward(gen.tensors(seed), spo.gray_u8_to_tensor(gen.image(seed)))
+    assert out["keypoints"].shape[0] == k == len(xy)
+    np.testing.assert_array_equal(out["keypoints"].numpy().astype(np.int64), xy)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
+def test_model_level_entry_points_driven_from_c(built_library, tmp_path):
+    """gtsfm_sp_pack_weights -> gtsfm_sp_workspace_bytes -> gtsfm_sp_forward from a C program that owns its device memory and stream (no Python
+    in the process): keypoint count and every coordinate identical to the oracle's numbers in abi_model_expected.h, scores / descriptors 1e-4."""
+    exe, env = _build_c(tmp_path, built_library, "abi_model_from_c.c", ["-isystem", "/opt/rocm/include", f"-I{REPO / 'tests' / 'abi'}"])
+    run = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    assert "abi_model_from_c OK" in run.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
 def test_device_entry_point_driven_from_c(built_library, tmp_path):

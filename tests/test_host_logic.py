@@ -275,3 +275,21 @@ def test_image_key_tells_arrays_apart():
     d[-1, 3] += 1.0  # in-place change of a sampled row
     assert key != _MatcherBase._image_key((k, d), (480, 640))
     assert _MatcherBase._image_key((k[:0], d[:0]), (8, 8))  # empty sets do not break it
+
+
+def test_full_digest_sees_every_byte():
+    """The image cache's validation checksum (matcher_engine._full_digest) covers all bytes of all arrays: a change in a row the lookup key
+    does not sample, a permutation of rows, another dtype view -- all give another digest; equal content in another buffer gives the same."""
+    from gtsfm_amd.runtime.matcher_engine import _MatcherBase, _full_digest
+
+    rng = np.random.default_rng(1)
+    k, d = rng.random((500, 2), dtype=np.float32), rng.random((500, 256), dtype=np.float32)
+    base = _full_digest((k, d))
+    assert base == _full_digest((k.copy(), d.copy())) and len(base) >= 8
+    key = _MatcherBase._image_key((k, d), (480, 640))
+    d[250, 17] += 1e-3  # row 250 is not among the 36 sampled rows of 500
+    assert _MatcherBase._image_key((k, d), (480, 640)) == key and _full_digest((k, d)) != base
+    d[250, 17] -= 1e-3
+    d[[100, 101]] = d[[101, 100]]  # a permutation keeps every sum
+    assert _full_digest((k, d)) != base
+    assert _full_digest((k[:0], d[:0])) == _full_digest((k[:0], d[:0]))

@@ -637,6 +637,90 @@ def test_per_call_image_cache_is_bit_identical_and_counts_hits(gpu_device, sg_sd
 
 
 @pytest.mark.parametrize("which", ["superglue", "lightglue"])
+def test_image_cache_cannot_serve_an_array_overwritten_in_place(gpu_device, sg_sd, which):
+    """the cache's lookup key samples 36 rows; an image whose descriptors are overwritten IN PLACE everywhere else keeps that
+    key. Every hit is therefore verified against a checksum over all bytes of the arrays while the GPU works on the pair
+    (``_entries_still_valid``): the stale entry is dropped, the pair is redone from the arrays, and the call returns what an engine without
+    a cache returns for the new content -- by default, with no switch."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+
+    n = 1500
+    k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(n, 1400, (480, 640), (480, 640), seed=310)
+    if which == "superglue":
+        cached, plain = ME.SuperGlueEngine(sg_sd, gpu_device), ME.SuperGlueEngine(sg_sd, gpu_device)
+        call = lambda e: e.match_pair(k0, s0, d0, k1, s1, d1, (480, 640), (480, 640))  # noqa: E731
+        arrays = (k0, s0, d0)
+    else:
+        sd = synthetic.synthetic_lightglue_state_dict()
+        cached, plain = ME.LightGlueEngine(sd, gpu_device), ME.LightGlueEngine(sd, gpu_device)
+        call = lambda e: e.match_pair(k0, d0, k1, d1, (480, 640), (480, 640))  # noqa: E731
+        arrays = (k0, d0)
+    plain.image_cache_capacity = 0
+    before = call(cached)
+    assert (cached.image_cache_misses, cached.image_cache_hits, cached.image_cache_stale) == (2, 0, 0)
+    key_before = ME._MatcherBase._image_key(arrays, (480, 640))
+    sampled = np.unique(np.concatenate([np.arange(10), np.arange(n - 10, n), np.linspace(0, n - 1, 16).astype(np.int64)]))
+    rest = np.setdiff1d(np.arange(n), sampled)
+    d0[rest] = d0[rest][::-1].copy()  # every row the lookup key does not sample: reversed in place (unit rows stay unit rows)
+    assert ME._MatcherBase._image_key(arrays, (480, 640)) == key_before  # the cheap key cannot tell
+    after, fresh = call(cached), call(plain)
+    assert cached.image_cache_stale == 1 and cached.image_cache_misses == 3  # found stale, redone from the arrays
+    for key in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+        np.testing.assert_array_equal(after[key], fresh[key])
+    assert not np.array_equal(after["matches0"], before["matches0"])
+    again = call(cached)  # the redone entry is a valid one
+    assert cached.image_cache_stale == 1 and cached.image_cache_misses == 3
+    np.testing.assert_array_equal(again["matches0"], fresh["matches0"])
+
+
+@pytest.mark.parametrize("which", ["superglue", "lightglue"])
+def test_threads_matching_pairs_that_share_an_image_are_bit_identical(gpu_device, sg_sd, which):
+    """an image entry made on one lane's stream is consumed on another lane's as soon as it is in the cache; the event
+    consumers wait for must cover the entry's keypoint / score clones as well as the per-image block's output. Six pairs over four images
+    -- every image in three pairs -- from three threads at once, from a cold cache, ten times: every result equals the single-threaded,
+    uncached call bit for bit."""
+    import threading
+
+    from gtsfm_amd.runtime import matcher_engine as ME
+
+    imgs = []
+    for seed, n in enumerate((2100, 1800, 2048, 1500)):
+        k, s, d, *_ = synthetic.synthetic_pair_features(n, 8, (480, 640), (480, 640), seed=400 + seed)
+        imgs.append((k, s, d))
+    pairs = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    if which == "superglue":
+        eng, plain = ME.SuperGlueEngine(sg_sd, gpu_device), ME.SuperGlueEngine(sg_sd, gpu_device)
+        call = lambda e, a, b: e.match_pair(a[0], a[1], a[2], b[0], b[1], b[2], (480, 640), (480, 640))  # noqa: E731
+    else:
+        sd = synthetic.synthetic_lightglue_state_dict()
+        eng, plain = ME.LightGlueEngine(sd, gpu_device), ME.LightGlueEngine(sd, gpu_device)
+        call = lambda e, a, b: e.match_pair(a[0], a[2], b[0], b[2], (480, 640), (480, 640))  # noqa: E731
+    plain.image_cache_capacity = 0
+    want = {p: call(plain, imgs[p[0]], imgs[p[1]]) for p in pairs}
+    for rep in range(10):
+        eng.release_lanes()  # cold cache: every round produces the entries afresh on whichever lane gets there first
+        got, errors = {}, []
+
+        def worker(tid):
+            try:
+                for p in pairs[tid::3]:
+                    got[p] = call(eng, imgs[p[0]], imgs[p[1]])
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for p in pairs:
+            for key in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+                np.testing.assert_array_equal(got[p][key], want[p][key], err_msg=f"round {rep}, pair {p}, {key}")
+    assert eng.image_cache_stale == 0
+
+
+@pytest.mark.parametrize("which", ["superglue", "lightglue"])
 def test_plugin_match_from_several_threads_equals_one_at_a_time(gpu_device, sg_sd, tmp_path, which):
     """GTSfM's ``--threads_per_worker`` (gtsfm/runner.py:155,436) lets several Dask threads call ``match`` on ONE scattered matcher
     object at once. The engine hands every concurrent call a lane of its own (workspace, staging buffers, stream; shared weights):
@@ -1039,3 +1123,81 @@ def test_single_pair_schedules_are_bit_identical_to_the_batch_schedules(gpu_devi
     assert (default["matches0"] > -1).sum() > 50
     if matcher == "lightglue":
         assert default["kept"][0] < n0  # point pruning was active: the GEMMs ran on per-tile live counts
+
+
+@pytest.mark.parametrize("shapes", [[(300, 257)], [(129, 130), (2048, 1900), (17, 640)], [(5000, 4800), (2100, 5000)]])
+def test_lightglue_assignment_standalone_vs_oracle(lib, gpu_device, shapes):
+    """``gtsfm_lg_assignment_f32`` -- the forward's last stage alone (the two log-softmax sweeps, then one read of the matrix for the mutual
+    arg-maxima and the 0.1 filter) -- on seeded similarity matrices and matchability logits against the oracle's
+    ``sigmoid_log_double_softmax`` + ``filter_matches`` (restating upstream LightGlue): match indices identical on
+    both sides, scores within 1e-5; ragged batches mix the one-wave, four-wave and eight-wave sweep tiers; ``stages`` 1 then 2 equals 3."""
+    from gtsfm_amd.runtime import lib as L
+
+    rng = np.random.default_rng(len(shapes) * 100 + shapes[0][0])
+    m = np.array([s[0] for s in shapes], dtype=np.int32)
+    n = np.array([s[1] for s in shapes], dtype=np.int32)
+    cap = lambda v: -(-int(v) // 128) * 128  # noqa: E731
+    rows = sum(cap(a) + cap(b) for a, b in shapes)
+    sims, zs, sim_flat = [], [], []
+    zlogit = np.zeros(rows, dtype=np.float32)
+    row = 0
+    for a, b in shapes:
+        sim = rng.normal(0.0, 4.0, (a, b)).astype(np.float32)
+        hit = rng.permutation(min(a, b))[: min(a, b) // 2]
+        sim[hit, hit] += 25.0  # mutual maxima that pass the filter
+        z0, z1 = rng.normal(1.0, 2.0, a).astype(np.float32), rng.normal(1.0, 2.0, b).astype(np.float32)
+        ld = (b + 3) // 4 * 4
+        padded = np.zeros((a, ld), dtype=np.float32)
+        padded[:, :b] = sim
+        sim_flat.append(padded.reshape(-1))
+        zlogit[row : row + a] = z0
+        zlogit[row + cap(a) : row + cap(a) + b] = z1
+        sims.append(sim), zs.append((z0, z1, row))
+        row += cap(a) + cap(b)
+    sim_dev = torch.from_numpy(np.concatenate(sim_flat)).to(gpu_device)
+    zl_dev = torch.from_numpy(zlogit).to(gpu_device)
+    ws = torch.empty(int(lib.gtsfm_lg_assignment_workspace_bytes(len(shapes), m.ctypes.data, n.ctypes.data)), dtype=torch.uint8, device=gpu_device)
+    stream = torch.cuda.current_stream(gpu_device).cuda_stream
+
+    def run(stages):
+        matches = torch.full((rows,), -7, dtype=torch.int32, device=gpu_device)
+        ms = torch.full((rows,), -7.0, dtype=torch.float32, device=gpu_device)
+        for st in stages:
+            L.check(lib.gtsfm_lg_assignment_f32(sim_dev.data_ptr(), len(shapes), m.ctypes.data, n.ctypes.data, zl_dev.data_ptr(), 0.1, st, ws.data_ptr(), ws.numel(),
+                                                matches.data_ptr(), ms.data_ptr(), stream), "gtsfm_lg_assignment_f32")
+        return matches.cpu().numpy(), ms.cpu().numpy()
+
+    got_m, got_s = run([3])
+    two_m, two_s = run([1, 2])
+    np.testing.assert_array_equal(got_m, two_m)
+    np.testing.assert_array_equal(got_s, two_s)
+    total = 0
+    for (a, b), sim, (z0, z1, row) in zip(shapes, sims, zs):
+        t = torch.from_numpy
+        with torch.no_grad():
+            scores = lgo.sigmoid_log_double_softmax(t(sim)[None], t(z0)[None, :, None], t(z1)[None, :, None])
+            m0, m1, s0, s1 = lgo.filter_matches(scores, 0.1)
+        np.testing.assert_array_equal(got_m[row : row + a], m0[0].numpy())
+        np.testing.assert_array_equal(got_m[row + cap(a) : row + cap(a) + b], m1[0].numpy())
+        np.testing.assert_allclose(got_s[row : row + a], s0[0].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(got_s[row + cap(a) : row + cap(a) + b], s1[0].numpy(), rtol=0, atol=1e-5)
+        total += int((m0[0] > -1).sum())
+    assert total > 10 * len(shapes)
+
+
+def test_layernorm_gelu_standalone_vs_aten(lib, gpu_device):
+    """``gtsfm_layernorm_gelu_f32`` (LightGlue's FFN normalisation + activation, in place) against ATen's layer_norm + exact gelu on the CPU."""
+    from gtsfm_amd.runtime import lib as L
+
+    torch.manual_seed(5)
+    rows, ld = 1234, 520
+    x = torch.randn((rows, ld)) * 3.0 + 0.5
+    gamma, beta = torch.rand(512) + 0.5, torch.randn(512) * 0.2
+    want = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x[:, :512], (512,), gamma, beta))
+    xd, gd, bd = x.to(gpu_device), gamma.to(gpu_device), beta.to(gpu_device)
+    scratch = torch.empty(64, dtype=torch.uint8, device=gpu_device)
+    L.check(lib.gtsfm_layernorm_gelu_f32(xd.data_ptr(), ld, rows, gd.data_ptr(), bd.data_ptr(), scratch.data_ptr(), torch.cuda.current_stream(gpu_device).cuda_stream),
+            "gtsfm_layernorm_gelu_f32")
+    got = xd.cpu()
+    assert float((got[:, :512] - want).abs().max()) < 2e-5
+    assert torch.equal(got[:, 512:], x[:, 512:])  # columns beyond 512 are not touched

@@ -1,5 +1,6 @@
 """PMC workload (GPU box, run under rocprofv3 --pmc ...): a few launches of ONE kernel at its workload shape.
-    python tools/pmc_kernels.py attention [N pairs] | attention_x3 [N pairs] | gemm ROWS K N | sinkhorn [N pairs] | conv | all"""
+    python tools/pmc_kernels.py attention [N pairs] | attention_x3 [N pairs] | gemm ROWS K N | sinkhorn [N pairs] | lg_assign [N pairs] | conv | all
+"all" = every kernel bench.py prints a `traffic` figure for, at the headline's launch shapes (16-pair chunks at the 5000-keypoint cap)."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -15,8 +16,11 @@ if what == "attention_x3":
 if what == "gemm":
     bench.measure_gemm_roofline(lib, dev, *num, reps=4)
 if what == "all":
-    for k, n in ((256, 768), (512, 512), (512, 256)):
+    for k, n in ((256, 768), (512, 512), (512, 256), (256, 512)):
         bench.measure_gemm_roofline(lib, dev, 163840, k, n, reps=4)
+    bench.measure_score_gemm_roofline(lib, dev, 5000, 16)
+if what in ("lg_assign", "all"):
+    bench.measure_lg_assignment_roofline(lib, dev, *(num or [5000, 16]), reps=4)
 if what in ("sinkhorn", "all"):
     bench.measure_sinkhorn_roofline(lib, dev, *(num or [5000, 16]), iters=4)
 if what in ("conv", "all"):
