@@ -381,7 +381,11 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(con
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int col = 4 * (lane + 64 * c);
-        bj[c] = cj[c] = za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cj[c] = za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // columns beyond n (the row's padding to 4 floats, the chunks past the matrix) carry a column term that turns every value into
+        // -inf or NaN -- SuperGlue adds b_j (-inf), LightGlue subtracts it (+inf) -- so that no comparison below can select them whatever the
+        // padding holds: the row loop needs no per-element bounds test (compiled as a branch per element until round 5: 0.26 of the roof)
+        bj[c] = SG ? f32x4{NEG, NEG, NEG, NEG} : f32x4{-NEG, -NEG, -NEG, -NEG};
         cbv[c] = f32x4{NEG, NEG, NEG, NEG};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -406,27 +410,22 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(con
             const int col = 4 * (lane + 64 * c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (col + e < n) {
-                    const float val = assign_value<SG>(zz[c][e], a_i, bj[c][e], norm, c_i, cj[c][e]);
-                    if (val > best) {  // columns ascend within a lane: the first maximum wins
-                        best = val;
-                        bidx = col + e;
-                    }
-                    if (val > cbv[c][e]) {  // rows ascend within a wave
-                        cbv[c][e] = val;
-                        cbi[c][e] = i;
-                    }
-                }
+                const float val = assign_value<SG>(zz[c][e], a_i, bj[c][e], norm, c_i, cj[c][e]);  // -inf / NaN beyond column n: never selected
+                const bool row_better = val > best;  // columns ascend within a lane: the first maximum wins
+                best = row_better ? val : best;
+                bidx = row_better ? col + e : bidx;
+                const bool col_better = val > cbv[c][e];  // rows ascend within a wave
+                cbv[c][e] = col_better ? val : cbv[c][e];
+                cbi[c][e] = col_better ? i : cbi[c][e];
             }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const float ob = __shfl_xor(best, off, 64);
             const int oj = __shfl_xor(bidx, off, 64);
-            if (ob > best || (ob == best && oj < bidx)) {
-                best = ob;
-                bidx = oj;
-            }
+            const bool take_ob = ob > best || (ob == best && oj < bidx);  // selects, not a branch
+            best = take_ob ? ob : best;
+            bidx = take_ob ? oj : bidx;
         }
         if (lane == 0) {
             max0[s0.row_off + i] = best;
@@ -462,10 +461,9 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(con
         for (int w = 1; w < 4; ++w) {
             const float ov = red_v[w][j];
             const int oi = red_i[w][j];
-            if (ov > bv || (ov == bv && oi < bi)) {
-                bv = ov;
-                bi = oi;
-            }
+            const bool take_ov = ov > bv || (ov == bv && oi < bi);  // selects, not a branch
+            bv = take_ov ? ov : bv;
+            bi = take_ov ? oi : bi;
         }
         part[j] = bv;
         reinterpret_cast<int*>(part)[ld + j] = bi;
@@ -499,10 +497,9 @@ __global__ __launch_bounds__(256) void extract_cols_kernel(const PairDesc* __res
     for (; b < nblk; ++b) {
         const float ov = part[b * bs];
         const int oi = reinterpret_cast<const int*>(part)[b * bs + pd.ld];
-        if (ov > bv || (ov == bv && oi < bi)) {
-            bv = ov;
-            bi = oi;
-        }
+        const bool take_ov = ov > bv || (ov == bv && oi < bi);  // selects, not a branch
+        bv = take_ov ? ov : bv;
+        bi = take_ov ? oi : bi;
     }
     idx1[s1.row_off + j] = (bi == SW_NO_INDEX) ? 0 : bi;  // all-NaN column: stay in range
 }
@@ -759,7 +756,11 @@ __global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float*
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int col = 256 * (wave + NW * c) + 4 * lane;
-        bj[c] = cj[c] = za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cj[c] = za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // columns beyond n (the row's padding to 4 floats, the chunks past the matrix) carry a column term that turns every value into
+        // -inf or NaN -- SuperGlue adds b_j (-inf), LightGlue subtracts it (+inf) -- so that no comparison below can select them whatever the
+        // padding holds: the row loop needs no per-element bounds test (compiled as a branch per element until round 5: 0.26 of the roof)
+        bj[c] = SG ? f32x4{NEG, NEG, NEG, NEG} : f32x4{-NEG, -NEG, -NEG, -NEG};
         cbv[c] = f32x4{NEG, NEG, NEG, NEG};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -782,27 +783,22 @@ __global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float*
             const int col = 256 * (wave + NW * c) + 4 * lane;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (col + e < n) {
-                    const float val = assign_value<SG>(zz[c][e], a_i, bj[c][e], norm, c_i, cj[c][e]);
-                    if (val > best) {  // columns ascend within a lane: the first maximum wins
-                        best = val;
-                        bidx = col + e;
-                    }
-                    if (val > cbv[c][e]) {  // rows ascend
-                        cbv[c][e] = val;
-                        cbi[c][e] = i;
-                    }
-                }
+                const float val = assign_value<SG>(zz[c][e], a_i, bj[c][e], norm, c_i, cj[c][e]);  // -inf / NaN beyond column n: never selected
+                const bool row_better = val > best;  // columns ascend within a lane: the first maximum wins
+                best = row_better ? val : best;
+                bidx = row_better ? col + e : bidx;
+                const bool col_better = val > cbv[c][e];  // rows ascend
+                cbv[c][e] = col_better ? val : cbv[c][e];
+                cbi[c][e] = col_better ? i : cbi[c][e];
             }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const float ob = __shfl_xor(best, off, 64);
             const int oj = __shfl_xor(bidx, off, 64);
-            if (ob > best || (ob == best && oj < bidx)) {
-                best = ob;
-                bidx = oj;
-            }
+            const bool take_ob = ob > best || (ob == best && oj < bidx);  // selects, not a branch
+            best = take_ob ? ob : best;
+            bidx = take_ob ? oj : bidx;
         }
         if (lane == 0) xv[slot][wave] = best, xi[slot][wave] = bidx;
         __syncthreads();
@@ -813,10 +809,9 @@ __global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float*
             for (int w = 1; w < NW; ++w) {
                 const float ov = xv[slot][w];
                 const int oi = xi[slot][w];
-                if (ov > bv || (ov == bv && oi < bi)) {
-                    bv = ov;
-                    bi = oi;
-                }
+                const bool take_ov = ov > bv || (ov == bv && oi < bi);  // selects, not a branch
+                bv = take_ov ? ov : bv;
+                bi = take_ov ? oi : bi;
             }
             max0[s0.row_off + i] = bv;
             idx0[s0.row_off + i] = (bi == SW_NO_INDEX) ? 0 : bi;  // all-NaN row: stay in range

@@ -118,3 +118,38 @@ def test_default_workload_helpers():
     assert (args.pairs, args.images, args.pair_chunk) == (1000, 46, 32)
     args = bench.parse_args(["--mode", "scene"])
     assert (args.pairs, args.images, args.matcher) == (5000, 101, "superglue")
+
+
+def test_recorded_bench_line_is_hygienic():
+    """The driver-command line recorded for this round (profiles/r05_final_bench_default.json): no roofline fraction above 1 anywhere in
+    the line (an algorithmic fp32 rate is never divided by the fp32 roof for a kernel that executes bf16 MFMAs), every `traffic` figure cites
+    a counter file collected THIS round, the headline carries `roofline` + `cpu_baseline`, and algorithmic / executed TFLOP/s are told apart."""
+    path = REPO / "profiles" / "r05_final_bench_default.json"
+    if not path.exists():
+        pytest.skip("profiles/r05_final_bench_default.json not recorded yet")
+    line = json.loads([ln for ln in path.read_text().splitlines() if ln.startswith("{")][-1])
+    fracs, notes = [], []
+
+    def walk(node, where):
+        if isinstance(node, dict):
+            if "frac" in node and isinstance(node["frac"], (int, float)):
+                fracs.append((where, node["frac"]))
+            if node.get("traffic_note"):
+                notes.append((where, node["traffic_note"]))
+            if node.get("traffic") is not None:
+                assert node.get("traffic_note"), f"{where}: a traffic figure without its source"
+            for k, v in node.items():
+                walk(v, f"{where}.{k}")
+        elif isinstance(node, list):
+            for i, v in enumerate(node):
+                walk(v, f"{where}[{i}]")
+
+    walk(line, "line")
+    assert fracs and all(0.0 < f <= 1.0 for _, f in fracs), [x for x in fracs if not 0.0 < x[1] <= 1.0]
+    assert notes and all("profiles/r05_" in n for _, n in notes), [x for x in notes if "profiles/r05_" not in x[1]]
+    assert line["roofline"]["frac"] == pytest.approx(line["roofline"]["achieved"] / line["roofline"]["peak"], rel=2e-3)
+    assert "cpu_baseline" in line and line["cpu_baseline"]["kind"] in ("port", "reference")
+    assert "algorithmic_tflops" in line and "executed_tflops" in line and "tflops" not in line
+    assert line["executed_tflops"] < line["algorithmic_tflops"] < 157.3
+    kernels = " ".join(str(r.get("kernel")) for r in line["roofline_other"])
+    assert "extract_rows" in kernels and "layernorm_gelu_kernel" in kernels  # the kernel furthest below its roof is in the line
