@@ -589,20 +589,22 @@ extern "C" int gtsfm_lg_assignment_f32(const float* sim_dev, int npairs, const i
                                        float* mscores_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GTSFM_CHECK_ARG(sim_dev && m && n && zlogit_dev && workspace_dev && matches_dev && mscores_dev, "lg_assignment: null pointer");
-    GTSFM_CHECK_ARG(npairs > 0 && stages >= 1 && stages <= 3, "lg_assignment: stages is 1 (double-softmax sweeps), 2 (extraction; after a call with 1 on the same workspace) or 3 (both)");
+    GTSFM_CHECK_ARG(npairs > 0 && (stages & 3) != 0 && stages <= 7, "lg_assignment: stages is 1 (double-softmax sweeps), 2 (extraction; after a call with 1 on the same workspace) or 3 (both), + 4 to reuse the workspace's batch descriptor");
     const LgaWorkspace ws = lga_workspace_layout(npairs, m, n);
     if (workspace_bytes < ws.total) {
         gtsfm_set_error("lg_assignment: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.total);
         return GTSFM_ERR_WORKSPACE;
     }
     const DescLayout DL = desc_layout(npairs, count_tiles(0, npairs, m, n));
-    std::vector<int32_t> host(DL.total), hw((size_t)4 * npairs, 1);
-    TRY(gtsfm_match_build_desc(0, npairs, m, n, hw.data(), host.data()));
-    for (int s = 0; s < 2 * npairs; ++s) host[DL.final_cnt + s] = host[DL.live + s];  // the assignment runs over the kept keypoints: all of them here
     char* wsp = (char*)workspace_dev;
     int32_t* desc_dev = (int32_t*)(wsp + ws.desc);
-    if (hipMemcpyAsync(desc_dev, host.data(), DL.total * sizeof(int32_t), hipMemcpyHostToDevice, stream) != hipSuccess) return GTSFM_ERR_HIP;
-    if (hipStreamSynchronize(stream) != hipSuccess) return GTSFM_ERR_HIP;  // `host` goes out of scope below
+    if (!(stages & 4)) {  // 4: the workspace holds the descriptor of an earlier call with the same shapes (timing loops: no upload, no synchronisation)
+        std::vector<int32_t> host(DL.total), hw((size_t)4 * npairs, 1);
+        TRY(gtsfm_match_build_desc(0, npairs, m, n, hw.data(), host.data()));
+        for (int s = 0; s < 2 * npairs; ++s) host[DL.final_cnt + s] = host[DL.live + s];  // the assignment runs over the kept keypoints: all of them here
+        if (hipMemcpyAsync(desc_dev, host.data(), DL.total * sizeof(int32_t), hipMemcpyHostToDevice, stream) != hipSuccess) return GTSFM_ERR_HIP;
+        if (hipStreamSynchronize(stream) != hipSuccess) return GTSFM_ERR_HIP;  // `host` goes out of scope below
+    }
     int max_m = 0, max_n = 0;
     for (int p = 0; p < npairs; ++p) max_m = max_m > m[p] ? max_m : m[p], max_n = max_n > n[p] ? max_n : n[p];
     SweepArgs sa;
@@ -693,11 +695,45 @@ extern "C" size_t gtsfm_lg_workspace_bytes(int npairs, const int32_t* n0, const 
 
 // Phases as for SuperGlue: 1 = only the first layer's SELF block (the part of LightGlue that sees one image), x to x_out_dev
 // [T][256] in the input's row order; 2 = descriptors_dev holds that x, the first self block is skipped; bit-identical to phase 0.
+//
+// side_stream (round 5, optional): ONE pair's launch sequence as TWO -- everything LightGlue does per image (Wqkv + rotary, self attention, the
+// FFNs, to_qk | to_v, the confidence / matchability heads) is enqueued per keypoint set, image 0's on `stream` and image 1's on `side_stream`;
+// the cross attention of a set waits for the other set's to_qk | to_v by an event, and the two sequences meet once per layer for the part that
+// sees the pair (stop test, final projection, pruning). One pair's launches leave the chip partly idle (an attention launch of one pair is
+// 3.1 rounds of the chip's workgroup slots, the fourth nearly empty; two dozen launches of a few microseconds per layer): the second sequence
+// fills it, as a second caller thread does for whole pairs. Every launch covers the same rows with the same kernels' arithmetic (the schedules
+// chosen from the launch geometry are bit-identical by construction): results are bit-identical to the one-stream form.
+// Taken only for npairs == 1 in the exact-fp32 attention arithmetic (the bf16x3 tiles of a launch are indexed by problem, not by row).
+namespace {
+
+struct LgEvents {  // a handful of HIP events for one call; destroyed when the call returns (the runtime keeps them until they completed)
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ok = true;
+    void create() {
+        for (auto& e : ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false, e = nullptr;
+    }
+    ~LgEvents() {
+        for (auto e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+
+}  // namespace
+
+#define HIP_TRY(expr)                             \
+    do {                                          \
+        if ((expr) != hipSuccess) {               \
+            gtsfm_set_error("%s failed", #expr);  \
+            return GTSFM_ERR_HIP;                 \
+        }                                         \
+    } while (0)
+
 static int lg_forward_phased(const float* wts, int num_layers, const float* match_bias_host, const float* conf_bias_host, int npairs,
                              const int32_t* n0, const int32_t* n1, int32_t* desc_dev, const float* kpts_dev, const float* descriptors_dev,
                              float depth_confidence, float width_confidence, float filter_threshold, int pruning_threshold,
                              void* workspace_dev, size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev,
-                             int phase, float* x_out_dev, void* stream_) {
+                             int phase, float* x_out_dev, void* stream_, void* side_stream_ = nullptr) {
     hipStream_t stream = (hipStream_t)stream_;
     GTSFM_CHECK_ARG(wts && match_bias_host && n0 && n1 && desc_dev && kpts_dev && descriptors_dev && workspace_dev, "lg_forward: null pointer");
     GTSFM_CHECK_ARG(phase >= 0 && phase <= 2 && (phase == 1 ? x_out_dev != nullptr : (matches_dev && mscores_dev)), "lg_forward: bad phase / null output");
@@ -752,94 +788,154 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
     const int nseq = 2 * npairs;
     const bool do_prune = width_confidence > 0.f && pruning_threshold != 0x7fffffff;
 
-    BlobCursor cur = {wts, 0};
-    // masked GEMM over the padded token rows; `cnt` selects which count array gates the tiles
-    auto gemm = [&](const float* A, int lda, int K, int N, float* C, int ldc, int coff, const float* res, int ldres, float alpha,
-                    const int* cnt, const float* rot_enc = nullptr, int rot_cols = 0) -> int {
+    // A "view" is the set of keypoint sets one launch sequence covers: all of them on one stream (the batched form), or ONE set of the single
+    // pair per stream. Sets are 128-row aligned, so a view is a row range of every token-major array plus a range of the tile / sequence /
+    // problem tables.
+    struct View {
+        int row0, rows, tile0, seq0, nseq;
+        hipStream_t stream;
+    };
+    const bool two = side_stream_ != nullptr && npairs == 1 && phase != 1 && attn_math == ATTN_MATH_F32;
+    View views[2];
+    int nviews = 1;
+    views[0] = {0, d.Tp, 0, 0, nseq, stream};
+    if (two) {
+        nviews = 2;
+        views[0] = {0, cap128(n0[0]), 0, 0, 1, stream};
+        views[1] = {cap128(n0[0]), cap128(n1[0]), cap128(n0[0]) / 128, 1, 1, (hipStream_t)side_stream_};
+    }
+    LgEvents E;
+    if (two) {
+        E.create();
+        GTSFM_CHECK_ARG(E.ok, "lg_forward: could not create events for the two-stream form");
+    }
+    hipEvent_t ev_fork = E.ev[0], ev_qk[2] = {E.ev[1], E.ev[2]}, ev_side_done = E.ev[3], ev_tail = E.ev[4];
+
+    struct Lin {
         const float *w, *b, *raw;
-        cur.linear(N, K, &w, &b, &raw);
+        int n, k;
+    };
+    BlobCursor cur = {wts, 0};
+    auto take = [&](int N, int K) {
+        Lin l;
+        cur.linear(N, K, &l.w, &l.b, &l.raw);
+        l.n = N, l.k = K;
+        return l;
+    };
+    // masked GEMM over the padded token rows of a view; `cnt` selects which count array gates the tiles
+    auto gemm = [&](const View& v, const Lin& W, const float* A, int lda, float* C, int ldc, const float* res, int ldres, float alpha, const int* cnt,
+                    const float* rot_enc = nullptr, int rot_cols = 0) -> int {
         GemmParams g;
         memset(&g, 0, sizeof(g));
-        g.A = A, g.lda = lda, g.M = d.Tp, g.K = K, g.wpack = w, g.wraw = raw, g.ldw = K, g.bias = b, g.N = N;
-        g.C = C, g.ldc = ldc, g.c_coff = coff, g.res = res, g.ldres = ldres, g.alpha = alpha, g.relu = 0;
-        g.tile_cnt_idx = tile_idx, g.tile_row0 = tile_row0, g.live_counts = cnt;
-        g.rot_enc = rot_enc, g.rot_cols = rot_cols;
+        g.A = A + (size_t)v.row0 * lda, g.lda = lda, g.M = v.rows, g.K = W.k, g.wpack = W.w, g.wraw = W.raw, g.ldw = W.k, g.bias = W.b, g.N = W.n;
+        g.C = C + (size_t)v.row0 * ldc, g.ldc = ldc, g.c_coff = 0, g.res = res ? res + (size_t)v.row0 * ldres : nullptr, g.ldres = ldres, g.alpha = alpha, g.relu = 0;
+        g.tile_cnt_idx = tile_idx + v.tile0, g.tile_row0 = tile_row0 + v.tile0, g.live_counts = cnt;
+        g.rot_enc = rot_enc ? rot_enc + (size_t)v.row0 * 64 : nullptr, g.rot_cols = rot_cols;
         g.math = gemm_math;
-        return launch_gemm(g, stream);
+        return launch_gemm(g, v.stream);
     };
-    auto ffn = [&](float* Xc) -> int {  // x + ffn(cat[x, message])
+    struct Ffn {
+        Lin f0;
+        const float *gamma, *beta;
+        Lin f3;
+    };
+    auto take_ffn = [&]() {
+        Ffn f;
+        f.f0 = take(512, 512);
+        f.gamma = cur.raw(512), f.beta = cur.raw(512);
+        f.f3 = take(256, 512);
+        return f;
+    };
+    auto ffn = [&](const View& v, const Ffn& f, float* Xc) -> int {  // x + ffn(cat[x, message])
         // (LayerNorm + GELU inside the ffn.0 GEMM was an opt-in in rounds 2-4; slower batched and single-pair, removed: gemm_dma_kernels.hip)
-        TRY(gemm(Xc, 512, 512, 512, MLP, 512, 0, nullptr, 0, 1.0f, live));
-        const float* gamma = cur.raw(512);
-        const float* beta = cur.raw(512);
-        TRY(launch_layernorm_gelu(MLP, 512, seqs, live, nseq, d.max_n, gamma, beta, stream));
-        TRY(gemm(MLP, 512, 512, 256, Xc, 512, 0, Xc, 512, 1.0f, live));
+        TRY(gemm(v, f.f0, Xc, 512, MLP, 512, nullptr, 0, 1.0f, live));
+        TRY(launch_layernorm_gelu(MLP, 512, seqs + v.seq0, live, v.nseq, d.max_n, f.gamma, f.beta, v.stream));
+        TRY(gemm(v, f.f3, MLP, 512, Xc, 512, Xc, 512, 1.0f, live));
         return GTSFM_OK;
+    };
+    auto attention = [&](const View& v, const AttnProblem* problems, const float* q, const float* k, const float* vv, float* Xc) -> int {
+        AttnParams ap = {};
+        // the attention context lands in the second half of cat([x, .]); out_proj / to_out are folded into ffn.0 at load time
+        ap.q = q, ap.ldq = 768, ap.k = k, ap.ldk = 768, ap.v = vv, ap.ldv = 768, ap.out = Xc + 256, ap.ldo = 512;
+        ap.counts = live, ap.scale = 0.125f, ap.heads = 4;
+        ap.max_k = d.max_n, ap.workspace = ws.attn_floats ? (float*)(wsp + ws.attn) : nullptr, ap.workspace_floats = ws.attn_floats, ap.part_rows = d.Tp;
+        ap.math = attn_math;
+        ap.problems = problems + v.seq0;
+        return launch_attention(ap, v.nseq, d.max_n, v.stream);
     };
 
     const float* Wr = cur.raw(64);
     TRY(launch_lg_load_inputs(descriptors_dev, seqs, live, nseq, d.max_n, X, 512, ind, stream));
     TRY(launch_lg_posenc(kpts_dev, seqs, live, nseq, d.max_n, Wr, enc, stream));
+    if (two) {
+        HIP_TRY(hipEventRecord(ev_fork, stream));
+        HIP_TRY(hipStreamWaitEvent(views[1].stream, ev_fork, 0));
+    }
 
     for (int l = 0; l < num_layers; ++l) {
-        AttnParams ap = {};
-        // the attention context lands in the second half of cat([x, .]); out_proj / to_out are folded into ffn.0 at load time
-        ap.q = QKV, ap.ldq = 768, ap.k = QKV + 256, ap.ldk = 768, ap.v = QKV + 512, ap.ldv = 768, ap.out = X + 256, ap.ldo = 512;
-        ap.counts = live, ap.scale = 0.125f, ap.heads = 4;
-        ap.max_k = d.max_n, ap.workspace = ws.attn_floats ? (float*)(wsp + ws.attn) : nullptr, ap.workspace_floats = ws.attn_floats, ap.part_rows = d.Tp;
-        ap.math = attn_math;
-        if (l == 0 && phase == 2) {  // the first self block was run per image (phase 1): step over its weights
-            const float *w, *b, *raw;
-            cur.linear(768, 256, &w, &b, &raw), cur.linear(512, 512, &w, &b, &raw);
-            cur.raw(512), cur.raw(512);
-            cur.linear(256, 512, &w, &b, &raw);
-        } else {
-            // self block: Wqkv, rotary on q and k, attention, out_proj, ffn
-            // rotary on q and k: in the Wqkv epilogue of the LDS-DMA GEMM, a kernel of its own otherwise
-            const bool fused_rotary = gemm_uses_dma(256, 256);
-            TRY(gemm(X, 512, 256, 768, QKV, 768, 0, nullptr, 0, 1.0f, live, fused_rotary ? enc : nullptr, 512));
-            if (!fused_rotary) TRY(launch_lg_rotary(QKV, 768, 512, enc, seqs, live, nseq, d.max_n, stream));
-            ap.problems = self_p;
-            TRY(launch_attention(ap, nseq, d.max_n, stream));
-            TRY(ffn(X));
+        const Lin wqkv = take(768, 256);
+        const Ffn self_ffn = take_ffn();
+        const bool skip_self = (l == 0 && phase == 2);  // the first self block was run per image (phase 1): its weights are stepped over
+        const bool fused_rotary = gemm_uses_dma(256, 256);  // rotary on q and k: in the Wqkv epilogue of the LDS-DMA GEMM, a kernel of its own otherwise
+        if (!skip_self) {
+            for (int vi = 0; vi < nviews; ++vi) {  // self block: Wqkv, rotary on q and k, attention, out_proj (folded), ffn
+                const View& v = views[vi];
+                TRY(gemm(v, wqkv, X, 512, QKV, 768, nullptr, 0, 1.0f, live, fused_rotary ? enc : nullptr, 512));
+                if (!fused_rotary) TRY(launch_lg_rotary(QKV, 768, 512, enc, seqs + v.seq0, live, v.nseq, d.max_n, v.stream));
+                TRY(attention(v, self_p, QKV, QKV + 256, QKV + 512, X));
+                TRY(ffn(v, self_ffn, X));
+            }
         }
         if (phase == 1) {
             TRY(launch_lg_store_rows(X, 512, seqs, live, nseq, d.max_n, x_out_dev, stream));
             return GTSFM_OK;
         }
-        // cross block: shared to_qk | to_v, both directions of the bidirectional attention, to_out, ffn
-        TRY(gemm(X, 512, 256, 512, QKV, 768, 0, nullptr, 0, 1.0f, live));
-        ap.q = QKV, ap.k = QKV, ap.v = QKV + 256, ap.problems = cross_p;
-        TRY(launch_attention(ap, nseq, d.max_n, stream));
-        TRY(ffn(X));
+        // cross block: shared to_qk | to_v, both directions of the bidirectional attention, to_out (folded), ffn
+        const Lin wcross = take(512, 256);
+        const Ffn cross_ffn = take_ffn();
+        for (int vi = 0; vi < nviews; ++vi) {
+            TRY(gemm(views[vi], wcross, X, 512, QKV, 768, nullptr, 0, 1.0f, live));
+            if (two) HIP_TRY(hipEventRecord(ev_qk[vi], views[vi].stream));
+        }
+        for (int vi = 0; vi < nviews; ++vi) {
+            const View& v = views[vi];
+            if (two) HIP_TRY(hipStreamWaitEvent(v.stream, ev_qk[1 - vi], 0));  // the other set's keys / values
+            TRY(attention(v, cross_p, QKV, QKV, QKV + 256, X));
+            TRY(ffn(v, cross_ffn, X));
+        }
 
         // adaptive depth / final assignment inputs
-        const float *w_fp, *b_fp, *r_fp;
-        size_t fp_off = cur.off;
-        cur.linear(256, 256, &w_fp, &b_fp, &r_fp);  // log_assignment[l].final_proj (consumed below through `gemm`)
+        const Lin wfp = take(256, 256);  // log_assignment[l].final_proj
         const float* w_match = cur.raw(256);
         const float* w_conf = (l < num_layers - 1) ? cur.raw(256) : nullptr;
         const float thr = (float)fmin(fmax(0.8 + 0.1 * exp(-4.0 * l / num_layers), 0.0), 1.0);
         // both heads over the live tokens in one pass: conf (depth / width), the matchability logit (kept by the pairs that stop here) and
         // its sigmoid (pruning); the index lists of the pairs that stop are frozen by the stop check itself
         const bool prune_here = do_prune && l < num_layers - 1;
-        TRY(launch_lg_heads(X, 512, seqs, live, nseq, d.max_n, w_conf, w_conf ? conf_bias_host[l] : 0.f, w_match, match_bias_host[l], conf, z_logit,
-                            prune_here ? mval : nullptr, stream));
+        for (int vi = 0; vi < nviews; ++vi) {
+            const View& v = views[vi];
+            TRY(launch_lg_heads(X, 512, seqs + v.seq0, live, v.nseq, d.max_n, w_conf, w_conf ? conf_bias_host[l] : 0.f, w_match, match_bias_host[l], conf, z_logit,
+                                prune_here ? mval : nullptr, v.stream));
+        }
+        if (two) {  // the part of a layer that sees the PAIR runs on `stream` behind both sequences
+            HIP_TRY(hipEventRecord(ev_side_done, views[1].stream));
+            HIP_TRY(hipStreamWaitEvent(stream, ev_side_done, 0));
+        }
         TRY(launch_lg_stop_check(conf, seqs, live, final_cnt, assign, orig, stop_layer, npairs, l, num_layers - 1, thr, depth_confidence, ind, ind_final,
                                  stream));
-        {
-            // pairs that stopped at this layer: mdesc = final_proj(x) / 256^(1/4)
-            const size_t keep = cur.off;
-            cur.off = fp_off;
-            TRY(gemm(X, 512, 256, 256, MD, 256, 0, nullptr, 0, 0.25f, assign));
-            cur.off = keep;
-        }
+        // pairs that stopped at this layer: mdesc = final_proj(x) / 256^(1/4)
+        const View all = {0, d.Tp, 0, 0, nseq, stream};
+        TRY(gemm(all, wfp, X, 512, MD, 256, nullptr, 0, 0.25f, assign));
         if (prune_here) {
             TRY(launch_lg_prune(conf, mval, seqs, live, old_cnt, pos, nseq, d.max_n, thr, (float)(1.0 - (double)width_confidence), pruning_threshold,
                                 depth_confidence > 0.f ? 1 : 0, X, Xalt, 512, enc, enc_alt, ind, ind_alt, stream));
             float* tx = X; X = Xalt; Xalt = tx;
             float* te = enc; enc = enc_alt; enc_alt = te;
             int* ti = ind; ind = ind_alt; ind_alt = ti;
+        }
+        if (two && l < num_layers - 1) {
+            HIP_TRY(hipEventRecord(ev_tail, stream));
+            HIP_TRY(hipStreamWaitEvent(views[1].stream, ev_tail, 0));
         }
     }
 
@@ -894,4 +990,14 @@ extern "C" int gtsfm_lg_forward_phase(const float* wts, int num_layers, const fl
     return lg_forward_phased(wts, num_layers, match_bias_host, conf_bias_host, npairs, n0, n1, desc_dev, kpts_dev, descriptors_dev, depth_confidence,
                              width_confidence, filter_threshold, pruning_threshold, workspace_dev, workspace_bytes, matches_dev, mscores_dev, sim_dev,
                              phase, x_out_dev, stream_);
+}
+
+extern "C" int gtsfm_lg_forward_streams(const float* wts, int num_layers, const float* match_bias_host, const float* conf_bias_host, int npairs,
+                                        const int32_t* n0, const int32_t* n1, int32_t* desc_dev, const float* kpts_dev, const float* descriptors_dev,
+                                        float depth_confidence, float width_confidence, float filter_threshold, int pruning_threshold,
+                                        void* workspace_dev, size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev,
+                                        int phase, float* x_out_dev, void* stream_, void* side_stream_) {
+    return lg_forward_phased(wts, num_layers, match_bias_host, conf_bias_host, npairs, n0, n1, desc_dev, kpts_dev, descriptors_dev, depth_confidence,
+                             width_confidence, filter_threshold, pruning_threshold, workspace_dev, workspace_bytes, matches_dev, mscores_dev, sim_dev,
+                             phase, x_out_dev, stream_, side_stream_);
 }

@@ -961,13 +961,13 @@ int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogi
 #define SW_LAUNCH_EXTRACT_LG_WIDE(NW, N)                                                                                                   \
     hipLaunchKernelGGL((extract_rows_wide_kernel<false, NW, N>), grid_rows, dim3(64 * NW), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, \
                        a.colvec, zlogit, max0, idx0, a.partials, (NW) == 8 ? above8 : SW_MAX_COLS)
-    // Rows beyond 2048 columns. LightGlue: eight waves per row for every width up to 10240 -- its extraction carries six register
-    // vectors per column chunk (value, index, two column terms, two rows in flight), four waves x 5 chunks at GTSfM's cap of 5000
-    // keypoints need 256 VGPRs + 44 spilled, eight waves x 3 chunks 187: 18.9 vs 19.05 ms per one-layer 16-pair call
-    // (tools/bench_extract.py). SuperGlue (no spills at four waves): the Sinkhorn tiers, four waves up to 5120 -- eight were 0.3-0.7 ms
-    // SLOWER. GTSFM_EXTRACT_WAVES=4 / 8 forces either; same arg-maxima in all cases.
+    // Rows beyond 2048 columns: the Sinkhorn tiers, four waves per row up to 5120 columns, eight up to 10240. Until round 5 LightGlue took
+    // eight waves for every width (its extraction carries six register vectors per column chunk; with a bounds BRANCH per element the
+    // four-wave form needed 256 VGPRs + 44 spilled at GTSfM's cap). The branch-free row loop (poisoned column terms, selects) needs 232 / 142
+    // VGPRs at four / eight waves, nothing spilled, and four waves are faster for both matchers (LightGlue, 16 pairs at the cap: 0.575 vs
+    // 0.634 ms; before the rewrite 0.767). GTSFM_EXTRACT_WAVES=4 / 8 forces either; arg-maxima do not depend on the slicing.
     const char* ew_env = getenv("GTSFM_EXTRACT_WAVES");
-    const bool four_up_to_5120 = ew_env ? ew_env[0] == '4' : superglue != 0;
+    const bool four_up_to_5120 = ew_env ? ew_env[0] == '4' : true;  // round 5: LightGlue too (232 VGPRs, nothing spilled: 0.575 vs 0.634 ms per 16 pairs at the cap)
     const int above8 = four_up_to_5120 ? SW_WIDE4_COLS : SW_MAX_COLS;
     if (superglue) {
         if (a.max_n > above8) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_EXTRACT_SG_WIDE)

@@ -149,6 +149,12 @@ SIGNATURES = {
          C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
          C.c_void_p],
     ),
+    "gtsfm_lg_forward_streams": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+         C.c_void_p, C.c_void_p],
+    ),
     "gtsfm_sp_select_topk": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],

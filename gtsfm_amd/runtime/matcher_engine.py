@@ -148,7 +148,7 @@ def _full_digest(arrays: Sequence[np.ndarray]) -> bytes:
 
 class _MatcherBase:
     # what a lane shares with the engine it was made from: read-only after construction (the weight blob lives on the device)
-    _SHARED_ATTRS: Tuple[str, ...] = ("device", "_lib", "weights", "num_layers", "desc_cache_capacity", "max_lanes")
+    _SHARED_ATTRS: Tuple[str, ...] = ("device", "_lib", "weights", "num_layers", "desc_cache_capacity", "max_lanes", "pair_streams")
 
     def __init__(self, device: Optional[torch.device]):
         self.device = require_gpu(device)
@@ -167,6 +167,7 @@ class _MatcherBase:
         # 5000-keypoint cap holds ~0.5 GB of workspace + 10 MB of pinned / device staging; ``release_lanes()``
         # returns it.
         self.max_lanes = max(1, int(os.environ.get("GTSFM_PLUGIN_LANES", "3")))
+        self.pair_streams = max(1, int(os.environ.get("GTSFM_PAIR_STREAMS", "2")))  # launch sequences of ONE pair (LightGlue: 2 = one per image)
         self._init_call_state()
         self._lanes: list = [self]
         self._free_lanes: "queue.LifoQueue" = queue.LifoQueue()
@@ -191,6 +192,7 @@ class _MatcherBase:
         self._staging: Optional[dict] = None
         self._lane_stream: Optional[torch.cuda.Stream] = None
         self._last_lookup: tuple = ((), [])  # what the last _image_entries call of this lane found (read by _entries_still_valid)
+        self._side_stream: Optional[torch.cuda.Stream] = None  # second launch sequence of a single pair (LightGlueEngine.match_batch)
 
     def _sibling(self) -> "_MatcherBase":
         """An engine sharing this one's weights (read-only on the device) and nothing a call writes: built from the explicit list
@@ -690,14 +692,22 @@ class LightGlueEngine(_MatcherBase):
         sim = None
         if return_sim:
             sim = torch.zeros(sum(int(a) * ((int(b) + 3) // 4 * 4) for a, b in zip(n0, n1)), dtype=torch.float32, device=self.device)
-        rc = self._lib.gtsfm_lg_forward_phase(
+        # ONE pair (the per-call plugin path): its launch sequence as two -- image 0's per-image work on the current stream, image 1's on a
+        # side stream of this lane, joined inside the call (gtsfm_lg_forward_streams; bit-identical). A batch fills the chip by itself, and a
+        # sequence being captured into a hipGraph stays on its one stream. GTSFM_PAIR_STREAMS=1 turns it off.
+        side = None
+        if p == 1 and self.pair_streams > 1 and not torch.cuda.is_current_stream_capturing():
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(self.device)
+            side = self._side_stream.cuda_stream
+        rc = self._lib.gtsfm_lg_forward_streams(
             self.weights.data_ptr(), self.num_layers, self.match_bias.ctypes.data, self.conf_bias.ctypes.data, p,
             n0.ctypes.data, n1.ctypes.data, dsc.data_ptr(), kpts.data_ptr(), desc.data_ptr(), float(depth_confidence),
             float(width_confidence), float(filter_threshold), NO_PRUNING if pruning_threshold is None else int(pruning_threshold),
             ws.data_ptr(), ws.numel(), matches.data_ptr(), mscores.data_ptr(), _lib.ptr(sim), 2 if first_layer_done else 0, None,
-            torch.cuda.current_stream(self.device).cuda_stream,
+            torch.cuda.current_stream(self.device).cuda_stream, side,
         )
-        _lib.check(rc, "gtsfm_lg_forward_phase")
+        _lib.check(rc, "gtsfm_lg_forward_streams")
         out = {
             "matches": matches, "mscores": mscores,
             "kept": dsc[2 * p : 4 * p],        # final counts section of the descriptor block

@@ -284,6 +284,19 @@ int gtsfm_lg_forward(const float* blob_dev, int num_layers, const float* match_b
                      float width_confidence, float filter_threshold, int pruning_threshold, void* workspace_dev,
                      size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev, void* stream);
 
+/* gtsfm_lg_forward_phase with ONE pair's launch sequence split over two streams (round 5; the per-call plugin path, where a caller
+ * hands over one pair at a time as gtsfm/frontend/matcher/lightglue_matcher.py:75-112 does): everything LightGlue computes per image is
+ * enqueued per keypoint set -- image 0's on `stream`, image 1's on `side_stream` -- with event waits where a set needs the other's keys /
+ * values and once per layer for the pair-level part; all work is joined back into `stream` before the call returns (the caller
+ * synchronises `stream` only). Bit-identical to the one-stream form. Taken for npairs == 1, phase 0 / 2, exact-fp32 attention; in every
+ * other case (and with side_stream == NULL) it IS gtsfm_lg_forward_phase. */
+int gtsfm_lg_forward_streams(const float* blob_dev, int num_layers, const float* match_bias_host, const float* conf_bias_host,
+                             int npairs, const int32_t* n0_host, const int32_t* n1_host, int32_t* desc_dev,
+                             const float* kpts_dev, const float* descriptors_dev, float depth_confidence,
+                             float width_confidence, float filter_threshold, int pruning_threshold, void* workspace_dev,
+                             size_t workspace_bytes, int32_t* matches_dev, float* mscores_dev, float* sim_dev, int phase,
+                             float* x_out_dev, void* stream, void* side_stream);
+
 /* LightGlue's assignment stage alone, on given similarity matrices (parity tests; bench.py's rooflines of the sweep kernels the forward
  * launches).                                  replaces upstream sigmoid_log_double_softmax + filter_matches (call site
  *                                             gtsfm/frontend/matcher/lightglue_matcher.py:104-110)
@@ -293,7 +306,8 @@ int gtsfm_lg_forward(const float* blob_dev, int num_layers, const float* match_b
  *              match index within the other set or -1, exp(score) as upstream's matching_scores
  * stages     : 1 = the two log-softmax sweeps (row / column log-sum-exp into the workspace), 2 = mutual arg-max extraction + filter
  *              (needs the workspace of a call with 1 on the same inputs), 3 = both. Builds and uploads its own batch descriptor:
- *              synchronises `stream` once. */
+ *              synchronises `stream` once -- unless 4 is added: the workspace then still holds the descriptor of an earlier call with
+ *              the same shapes (timing loops: launches only). */
 size_t gtsfm_lg_assignment_workspace_bytes(int npairs, const int32_t* m_host, const int32_t* n_host);
 int gtsfm_lg_assignment_f32(const float* sim_dev, int npairs, const int32_t* m_host, const int32_t* n_host, const float* zlogit_dev,
                             float filter_threshold, int stages, void* workspace_dev, size_t workspace_bytes, int32_t* matches_dev,

@@ -161,5 +161,9 @@ def test_superpoint_is_bit_identical_under_the_gemm_switch(gpu_device, monkeypat
     monkeypatch.setenv("GTSFM_ATTENTION_MATH", "bf16x3")
     switched = eng.forward(imgs, return_score_maps=True)
     assert int(exact["count"].min()) > 100
-    for key in ("count", "xy", "scores", "descriptors", "dense_scores", "nms_scores"):
+    for key in ("count", "dense_scores", "nms_scores"):
         assert torch.equal(exact[key], switched[key]), key
+    for i in range(imgs.shape[0]):  # rows beyond an image's count are uninitialised capacity
+        k = int(exact["count"][i])
+        for key in ("xy", "scores", "descriptors"):
+            assert torch.equal(exact[key][i, :k], switched[key][i, :k]), (key, i)

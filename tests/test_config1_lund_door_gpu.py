@@ -29,18 +29,22 @@ NUM_IMAGES = 12
 
 # What the run SAW, not only that it passed: every count a tolerance below could hide is recorded here and written to
 # gpurun_out/config1_observed.json (copied to profiles/r05_config1_observed.json), and the asserts hold the run to the values observed on
-# MI355X -- zero stray keypoints, zero threshold-borderline matches, zero matches0 disagreements for the plugin path against the reference's
-# arrays. ``Keypoints.__eq__`` = ``np.array_equal`` is the reference's own bar
+# MI355X (round 5, profiles/r05_config1_observed.json) -- zero stray keypoints in all 12 frames, 64 of 66 match arrays array_equal and exactly
+# two threshold-borderline matches (one each in two pairs, of 8454), zero matches0 disagreements on the fully compared pairs. ``Keypoints.__eq__`` = ``np.array_equal`` is the reference's own bar
 # (tests/repro_tests/frontend/detector_descriptor/reproducibility_base.py:25-36).
 OBSERVED = {}
 EXPECTED_STRAY_KEYPOINTS_PER_FRAME = 0      # plugin path and batched generator, all 12 frames
-EXPECTED_BORDERLINE_MATCHES = 0             # plugin path, all 66 pairs: (K, 2) arrays array_equal to the reference's
+# plugin path, all 66 pairs: 64 of the (K, 2) arrays are array_equal to the reference's; pairs (3, 9) and (4, 7) differ in ONE match each (of 8454),
+# and for both the test proves the cause: the match's score sits within 2e-4 of the 0.2 threshold in the reference's own output or in the HIP
+# path's (scores agree to 6.9e-6; a contract of 1e-4 on scores cannot decide a comparison against a constant closer than that)
+EXPECTED_BORDERLINE_MATCHES = 2
+EXPECTED_PAIRS_WITH_A_BORDERLINE_MATCH = [[3, 9, 1], [4, 7, 1]]
 EXPECTED_MATCHES0_DISAGREEMENTS = 0         # plugin path, the 11 pairs whose full matches0 / score vectors are compared
 # generators that feed the matcher the keypoints in THEIR OWN order (detection order / this process's get_top_k order): the order enters the
 # fp32 sums of attention and Sinkhorn, scores move in the sixth digit, a match AT the 0.2 threshold may fall on the other side. The numbers
 # below are the symmetric differences observed on MI355X over all edges; the run must reproduce them exactly.
-EXPECTED_BATCHED_GENERATOR_DIFFERING = None   # None = not pinned yet: recorded, bounded by 0.2 % of the matches
-EXPECTED_PER_PAIR_GENERATOR_DIFFERING = None
+EXPECTED_BATCHED_GENERATOR_DIFFERING = 1      # of 8454 matches over 66 pairs: pair (4, 7), the same borderline match as above
+EXPECTED_PER_PAIR_GENERATOR_DIFFERING = 0     # of 2106 matches over the first 22 pairs
 
 
 def _exact_fp32() -> bool:
@@ -220,6 +224,7 @@ def test_all_66_pairs_through_the_matcher_plugin_equal_the_reference(golden, ima
     assert plugins["calls"]["sg"] == 66 and total > 3000
     if _exact_fp32():
         assert borderline == EXPECTED_BORDERLINE_MATCHES, f"{borderline} threshold-borderline matches differ over {total}: {differing_pairs}"
+        assert differing_pairs == EXPECTED_PAIRS_WITH_A_BORDERLINE_MATCH, differing_pairs
         assert m0_disagreements == EXPECTED_MATCHES0_DISAGREEMENTS, m0_disagreements
     else:
         assert borderline <= 3, f"{borderline} threshold-borderline matches differ over {total}"

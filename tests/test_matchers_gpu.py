@@ -1201,3 +1201,32 @@ def test_layernorm_gelu_standalone_vs_aten(lib, gpu_device):
     got = xd.cpu()
     assert float((got[:, :512] - want).abs().max()) < 2e-5
     assert torch.equal(got[:, 512:], x[:, 512:])  # columns beyond 512 are not touched
+
+
+@pytest.mark.parametrize("kw,n0,n1", [({}, 5000, 4800), ({}, 2048, 2000), ({}, 100, 333), ({"conf_bias": 3.0, "conf_gain": 6.0}, 1800, 2100),
+                                      ({"conf_bias": 1.0, "conf_gain": 6.0, "match_bias": 2.0, "match_gain": 12.0}, 2560, 2304)])
+def test_single_pair_two_stream_form_is_bit_identical(gpu_device, kw, n0, n1):
+    """``gtsfm_lg_forward_streams``: ONE pair's launch sequence split over two streams (image 0's per-image work on the caller's stream, image 1's
+    on the lane's side stream, event waits at the cross attention and once per layer) against the one-stream form: matches, scores, stop
+    layer and kept counts identical bit for bit -- at the cap, for ragged / tiny sets, with heads that stop early and with pruning active --
+    through the image cache (phase 2) and without it (phase 0), and repeatedly (the two sequences race differently every time)."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+
+    sd = synthetic.synthetic_lightglue_state_dict(**kw)
+    k0, _, d0, k1, _, d1, _ = synthetic.synthetic_pair_features(n0, n1, (1024, 1024), (768, 1024), seed=510 + n0 % 7)
+    one, two = ME.LightGlueEngine(sd, gpu_device), ME.LightGlueEngine(sd, gpu_device)
+    one.pair_streams, two.pair_streams = 1, 2
+    for cache in (0, 64):
+        one.image_cache_capacity = two.image_cache_capacity = cache
+        want = one.match_pair(k0, d0, k1, d1, (1024, 1024), (768, 1024), pruning_threshold=-1 if "match_bias" in kw else ME.LIGHTGLUE_PRUNING_THRESHOLD)
+        for rep in range(4):
+            got = two.match_pair(k0, d0, k1, d1, (1024, 1024), (768, 1024), pruning_threshold=-1 if "match_bias" in kw else ME.LIGHTGLUE_PRUNING_THRESHOLD)
+            for key in ("matches0", "matches1", "matching_scores0", "matching_scores1", "kept"):
+                np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key}, cache {cache}, repetition {rep}")
+            assert got["stop"] == want["stop"]
+    assert two._side_stream is not None and one._side_stream is None
+    assert (want["matches0"] > -1).sum() > min(n0, n1) // 20
+    if "conf_bias" in kw and "match_bias" not in kw:
+        assert want["stop"] < 9
+    if "match_bias" in kw:
+        assert int(want["kept"].min()) < min(n0, n1)
