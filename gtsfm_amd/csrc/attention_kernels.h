@@ -32,6 +32,7 @@ struct AttnParams {
     int math;                      // ATTN_MATH_F32 (exact fp32 MFMA, the default) or ATTN_MATH_BF16X3 (three-way bf16 split of both products, fp32 accumulate)
     int qtiles, nproblems, nseg;   // filled by the launcher
     int lds_has_oc;                // "
+    int xcd_rep;                   // " (XCDs one (problem, head) group's workgroups are dealt over: > 1 for launches with fewer than 8 groups)
     float* part_o;                 // "
     float* part_ml;                // "
     float* park;                   // "

@@ -157,13 +157,17 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? ATD_WGS_PER_CU : 1) void atten
     // XCD-aware block order (speed only): workgroups are dispatched round-robin over the 8 XCDs, each with a private L2. All
     // query tiles (and segments) of one (problem, head) share the same K / V, so they get linear ids that are congruent
     // mod 8 -> same XCD -> K / V are fetched into ONE L2 instead of eight.
+    // Fewer than 8 (problem, head) groups in the launch (one keypoint set of a single pair: 4): a group's workgroups are dealt over
+    // xcd_rep = 8 / groups XCDs instead of leaving the others idle (round 5; until then such a launch ran on half the chip).
     const int b = blockIdx.x;
     const int groups = p.heads * p.nproblems;
     const int k_in_xcd = b >> 3;
     const int per_group = SPLIT ? p.qtiles * p.nseg : p.qtiles;
-    const int g = (k_in_xcd / per_group) * 8 + (b & 7);
+    const int rep = p.xcd_rep > 1 ? p.xcd_rep : 1;
+    const int g = rep > 1 ? (b & 7) / rep : (k_in_xcd / per_group) * 8 + (b & 7);
     if (g >= groups) return;
-    const int within = k_in_xcd % per_group;  // split: segment-major, the query tiles of one segment run side by side
+    const int within = rep > 1 ? k_in_xcd * rep + (b & 7) % rep : k_in_xcd % per_group;  // split: segment-major, the query tiles of one segment run side by side
+    if (within >= per_group) return;
     const int seg_of_wg = SPLIT ? within / p.qtiles : 0;
     const int h = g % p.heads;
     const AttnProblem pr = p.problems[g / p.heads];
@@ -925,6 +929,8 @@ static int at_fused_waves() {  // GTSFM_ATTENTION_WAVES = 4 | 8 (read per launch
     const char* env = getenv("GTSFM_ATTENTION_WAVES");
     return env && env[0] == '8' ? 8 : (env && env[0] == '4' ? 4 : ATD_FUSED_WAVES);
 }
+// XCDs a (problem, head) group's workgroups are dealt over when the launch has fewer than 8 groups (1, 2 or 4: the divisors of 8); 1 otherwise
+static int at_xcd_rep(int groups) { return (groups > 0 && groups < 8 && 8 % groups == 0) ? 8 / groups : 1; }
 static int at_fused_grid(int nproblems, int heads, int max_q) { return ceil_div(heads * nproblems, 8) * 8 * ceil_div(max_q, 32 * at_fused_waves()); }
 
 int attention_math_from_env() {  // read per call: GTSFM_ATTENTION_MATH = "bf16x3" selects the split-bf16 products, anything else exact fp32
@@ -972,7 +978,7 @@ static int launch_attention_x3(const AttnParams& p, int nproblems, int max_q, hi
     bool split = p.force_split > 0 || (p.force_split == 0 && at_wants_split(nproblems, p.heads, max_q, max_k));
     if (nseg < 2) split = false;
     if (split && p.force_split <= 0 && (p.part_rows == 0 || rest_floats < need_split)) split = false;
-    q.park = nullptr, q.lds_has_oc = 0;
+    q.park = nullptr, q.lds_has_oc = 0, q.xcd_rep = 1;
     if (split) {
         q.nseg = nseg;
         GTSFM_CHECK_ARG(p.part_rows > 0 && rest_floats >= need_split, "attention (bf16x3): workspace too small for the split schedule (%zu < %zu floats)", rest_floats, need_split);
@@ -1004,7 +1010,7 @@ int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t 
     AttnParams q = p;
     q.qtiles = ceil_div(max_q, AT_QB);
     q.nproblems = nproblems;
-    q.park = nullptr, q.lds_has_oc = 0;
+    q.park = nullptr, q.lds_has_oc = 0, q.xcd_rep = 1;
     const int groups = p.heads * nproblems;
     const int max_k = p.max_k > 0 ? p.max_k : max_q;
     const size_t tile_bytes = (size_t)ATD_LDS_TILE_FLOATS * sizeof(float);
@@ -1016,14 +1022,16 @@ int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t 
         GTSFM_CHECK_ARG(p.part_rows > 0 && p.workspace_floats >= need, "attention: workspace too small for the split schedule (%zu < %zu floats)", p.workspace_floats, need);
         q.part_o = p.workspace;
         q.part_ml = p.workspace + (size_t)q.nseg * p.part_rows * p.heads * 64;
-        dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles * q.nseg);
+        q.xcd_rep = at_xcd_rep(groups);
+        dim3 grid(q.xcd_rep > 1 ? ceil_div(q.qtiles * q.nseg, q.xcd_rep) * 8 : ceil_div(groups, 8) * 8 * q.qtiles * q.nseg);
         hipLaunchKernelGGL((attention_dma_kernel<true, 4>), grid, dim3(256), tile_bytes, stream, q);
         hipLaunchKernelGGL(attention_combine_kernel, dim3(ceil_div(max_q, 4), nproblems), dim3(256), 0, stream, q);
     } else {
         q.nseg = 1;
         const int nwv = at_fused_waves();
         q.qtiles = ceil_div(max_q, 32 * nwv);
-        dim3 grid(at_fused_grid(nproblems, p.heads, max_q));
+        q.xcd_rep = ATD_PARK_GLOBAL ? 1 : at_xcd_rep(groups);  // (the double-buffered build's parking slabs are sized for the plain block order)
+        dim3 grid(q.xcd_rep > 1 ? ceil_div(q.qtiles, q.xcd_rep) * 8 : at_fused_grid(nproblems, p.heads, max_q));
         size_t lds_bytes = tile_bytes;
         if (ATD_PARK_GLOBAL && p.workspace && p.workspace_floats >= (size_t)grid.x * (ATD_OC_FLOATS / 4 * nwv)) {
             q.park = p.workspace;  // (double-buffered build) merged state between segments in the workspace: two workgroups per CU

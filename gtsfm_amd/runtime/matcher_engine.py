@@ -167,7 +167,11 @@ class _MatcherBase:
         # 5000-keypoint cap holds ~0.5 GB of workspace + 10 MB of pinned / device staging; ``release_lanes()``
         # returns it.
         self.max_lanes = max(1, int(os.environ.get("GTSFM_PLUGIN_LANES", "3")))
-        self.pair_streams = max(1, int(os.environ.get("GTSFM_PAIR_STREAMS", "2")))  # launch sequences of ONE pair (LightGlue: 2 = one per image)
+        # launch sequences of ONE pair (LightGlue: 2 = one per image, gtsfm_lg_forward_streams). Built in round 5, bit-identical, and OFF by
+        # default: the two sequences must meet four times per layer, and a cross-stream event wait costs ~40 us on this runtime -- measured
+        # 10.85 vs 10.97 ms per pair at the 5000-keypoint cap (the overlap wins 1.5 ms and the 36 waits take 1.4 back) and 4.28 vs 2.89 ms at
+        # N = 2048. Two caller threads, which share nothing, do gain: 103 vs 91 pairs/s.
+        self.pair_streams = max(1, int(os.environ.get("GTSFM_PAIR_STREAMS", "1")))
         self._init_call_state()
         self._lanes: list = [self]
         self._free_lanes: "queue.LifoQueue" = queue.LifoQueue()
@@ -692,9 +696,10 @@ class LightGlueEngine(_MatcherBase):
         sim = None
         if return_sim:
             sim = torch.zeros(sum(int(a) * ((int(b) + 3) // 4 * 4) for a, b in zip(n0, n1)), dtype=torch.float32, device=self.device)
-        # ONE pair (the per-call plugin path): its launch sequence as two -- image 0's per-image work on the current stream, image 1's on a
-        # side stream of this lane, joined inside the call (gtsfm_lg_forward_streams; bit-identical). A batch fills the chip by itself, and a
-        # sequence being captured into a hipGraph stays on its one stream. GTSFM_PAIR_STREAMS=1 turns it off.
+        # ONE pair (the per-call plugin path) can run its launch sequence as two -- image 0's per-image work on the current stream, image 1's
+        # on a side stream of this lane, joined inside the call (gtsfm_lg_forward_streams; bit-identical; opt-in: GTSFM_PAIR_STREAMS=2, see
+        # _init_host_state for why it is not the default). A batch fills the chip by itself, and a sequence being captured into a hipGraph
+        # stays on its one stream.
         side = None
         if p == 1 and self.pair_streams > 1 and not torch.cuda.is_current_stream_capturing():
             if self._side_stream is None:
