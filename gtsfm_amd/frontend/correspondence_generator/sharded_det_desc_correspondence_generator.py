@@ -86,12 +86,15 @@ class ShardedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         backend: str = "nccl",
         pipeline_factory: Optional[Callable[..., Any]] = None,
         pipeline_options: Optional[Dict[str, Any]] = None,
+        always_launch: bool = False,
     ) -> None:
         """``num_gpus``: ranks to start in launcher mode (None = every visible GPU); ignored when the caller is already part of a process
         group. ``pair_batch``: pairs per matcher launch sequence (0 = by keypoint count: 32 up to 2560 keypoints, 16 at the 5000 cap).
         ``pipeline_options``: extra ``FrontEndPipeline`` arguments (``num_streams``, ``use_graphs``, ``share_first_layer``).
         ``pipeline_factory(generator, device) -> pipeline``: replaces the HIP pipeline (CPU plumbing tests with stand-in kernels; must be
-        a picklable top-level callable in launcher mode); the plugins' models are then never built and no weights are broadcast."""
+        a picklable top-level callable in launcher mode); the plugins' models are then never built and no weights are broadcast.
+        ``always_launch``: start rank processes even for one GPU (keeps the calling process free of device state; also how the launcher path
+        is exercised on a one-GPU box)."""
         if pipeline_factory is None:
             if not isinstance(detector_descriptor, SuperPointDetectorDescriptor):
                 raise TypeError("ShardedDetDescCorrespondenceGenerator needs gtsfm_amd's SuperPointDetectorDescriptor")
@@ -105,6 +108,7 @@ class ShardedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         self._backend = backend
         self._pipeline_factory = pipeline_factory
         self._pipeline_options = dict(pipeline_options or {})
+        self._always_launch = bool(always_launch)
         self._pipe = None  # per process: FrontEndPipeline over this rank's engines
         self._pool = None  # launcher mode: the rank processes
         self.last_scene: Optional[SceneResult] = None
@@ -228,7 +232,7 @@ class ShardedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
     ) -> Tuple[List[Keypoints], Dict[Tuple[int, int], np.ndarray]]:
         pairs = [(int(i1), int(i2)) for (i1, i2) in visibility_graph]
         rank, world = parallel.world_info()
-        if parallel._dist() is None and self._world_to_launch() > 1:
+        if parallel._dist() is None and (self._world_to_launch() > 1 or self._always_launch):
             imgs = BatchedDetDescCorrespondenceGenerator._resolve(client, images)
             return self._launcher().run(imgs, pairs)
         imgs = BatchedDetDescCorrespondenceGenerator._resolve(client, images)

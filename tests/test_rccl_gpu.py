@@ -78,6 +78,30 @@ def test_sharded_generator_class_through_rccl_equals_the_single_process_generato
 
 
 @pytest.mark.gpu
+def test_sharded_generator_launcher_mode_on_the_device(gpu_device, tmp_path):
+    """LAUNCHER mode on real hardware, with the one rank a one-GPU box allows: the class spawns its rank process ("spawn": a fresh
+    interpreter), ships it the pickled generator (plugins without device state) and the rank's images, the rank joins an RCCL process group,
+    builds its engines, runs the scene and hands the result back -- equal to the in-process run; a second scene reuses the rank; close() ends it."""
+    sys.path.insert(0, str(REPO / "tests"))
+    import rccl_sharded_one_rank as helper
+
+    inproc = helper.build(str(tmp_path), "lightglue", 1)
+    images, pairs = helper.scene()
+    want = helper.digest(*inproc.generate_correspondences(None, images, pairs), pairs)
+    gen = helper.build(str(tmp_path), "lightglue", 1)
+    gen._always_launch = True
+    try:
+        got = helper.digest(*gen.generate_correspondences(None, images, pairs), pairs)
+        assert got == want and gen._pool is not None and gen._pool.world == 1 and gen._pipe is None  # the caller holds no device state of its own
+        again = helper.digest(*gen.generate_correspondences(None, images[:5], [p for p in pairs if 5 not in p]), [p for p in pairs if 5 not in p])
+        assert again["keypoints"] == want["keypoints"][:5]
+        procs = list(gen._pool._procs)
+    finally:
+        gen.close()
+    assert gen._pool is None and all(not p.is_alive() for p in procs)
+
+
+@pytest.mark.gpu
 def test_two_ranks_on_one_device_if_rccl_allows_it(gpu_device):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
