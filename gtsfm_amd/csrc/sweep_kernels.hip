@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(con
                                                               const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
                                                               const float* __restrict__ rowvec, const float* __restrict__ colvec,
                                                               const float* __restrict__ zlogit, float* __restrict__ max0,
-                                                              int* __restrict__ idx0, float* __restrict__ partials) {
+                                                              int* __restrict__ idx0, float* __restrict__ partials, int n_max) {
     __shared__ __attribute__((aligned(16))) float red_v[4][NCH * 256];
     __shared__ __attribute__((aligned(16))) int red_i[4][NCH * 256];
     const int p = blockIdx.y;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(con
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
     const int m = counts[s0.cnt_idx], n = counts[s1.cnt_idx];
     const int r0 = blockIdx.x * SW_ROWS;
-    if (r0 >= m || n > SW_MAX_COLS) return;  // wider pairs: extract_rows_wide_kernel
+    if (r0 >= m || n > n_max) return;  // wider pairs: extract_rows_wide_kernel (arg-maxima do not depend on the slicing: the launcher picks the bound)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ld = pd.ld;
     const float* Z = zbuf + pd.z_off;
@@ -729,14 +729,17 @@ __global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __re
     }
 }
 
-template <bool SG, int NW, int NCH>
+template <bool SG, int NW, int NCH, bool NT = false>
 __global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                                     const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
                                                                     const float* __restrict__ rowvec, const float* __restrict__ colvec,
                                                                     const float* __restrict__ zlogit, float* __restrict__ max0,
                                                                     int* __restrict__ idx0, float* __restrict__ partials, int n_above) {
-    __shared__ float xv[2][NW];
-    __shared__ int xi[2][NW];
+    // per row of the block and wave: the best value / column of the wave's slice. The waves of a workgroup never wait for each other inside
+    // the row loop (round 5: a barrier per row made every wave wait for the slowest wave's loads of EVERY row -- 70 % of the wave cycles parked,
+    // profiles/r05_sq_counters.csv); the slices' candidates meet once, after the loop.
+    __shared__ float xv[SW_ROWS][NW];
+    __shared__ int xi[SW_ROWS][NW];
     const int p = blockIdx.y;
     const PairDesc pd = pairs[p];
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
@@ -800,32 +803,22 @@ __global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float*
             best = take_ob ? ob : best;
             bidx = take_ob ? oj : bidx;
         }
-        if (lane == 0) xv[slot][wave] = best, xi[slot][wave] = bidx;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float bv = xv[slot][0];
-            int bi = xi[slot][0];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                const float ov = xv[slot][w];
-                const int oi = xi[slot][w];
-                const bool take_ov = ov > bv || (ov == bv && oi < bi);  // selects, not a branch
-                bv = take_ov ? ov : bv;
-                bi = take_ov ? oi : bi;
-            }
-            max0[s0.row_off + i] = bv;
-            idx0[s0.row_off + i] = (bi == SW_NO_INDEX) ? 0 : bi;  // all-NaN row: stay in range
-        }
+        if (lane == 0) xv[i - r0][wave] = best, xi[i - r0][wave] = bidx;
+        (void)slot;
     };
     const int rend = (r0 + SW_ROWS < m) ? r0 + SW_ROWS : m;
     int i = r0;
-    sw_load_slice<NW, NCH>(Z + (size_t)i * ld, n, wave, lane, za);
+    // One row in flight behind the one being processed. A third register buffer (two rows in flight) was built in round 5: 256 VGPRs + 20 .. 57
+    // spilled at five chunks (the column state -- value, index, two column terms -- is 16 registers per chunk already) and one workgroup per
+    // CU instead of two: not kept. What bounds the kernel is that row time = memory latency (3 us per row at the cap; 70 % of the wave cycles
+    // waiting, VALU issue 18 %: profiles/r05_sq_counters.csv); the way past it is the column state in LDS, not more registers.
+    sw_load_slice<NW, NCH, NT>(Z + (size_t)i * ld, n, wave, lane, za);
 #pragma unroll 1
     for (; i < rend; i += 2) {
-        if (i + 1 < rend) sw_load_slice<NW, NCH>(Z + (size_t)(i + 1) * ld, n, wave, lane, zb);
+        if (i + 1 < rend) sw_load_slice<NW, NCH, NT>(Z + (size_t)(i + 1) * ld, n, wave, lane, zb);
         process(i, za, 0);
         if (i + 1 >= rend) break;
-        if (i + 2 < rend) sw_load_slice<NW, NCH>(Z + (size_t)(i + 2) * ld, n, wave, lane, za);
+        if (i + 2 < rend) sw_load_slice<NW, NCH, NT>(Z + (size_t)(i + 2) * ld, n, wave, lane, za);
         process(i + 1, zb, 1);
     }
     // block partial per column: plane 0 = best value, plane 1 = its row (as int bits), at part_off + block * 2 ld
@@ -836,6 +829,24 @@ __global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float*
         if (col >= n) continue;
         *reinterpret_cast<f32x4*>(part + col) = cbv[c];
         *reinterpret_cast<int4*>(reinterpret_cast<int*>(part) + ld + col) = int4{cbi[c][0], cbi[c][1], cbi[c][2], cbi[c][3]};
+    }
+    // the one barrier of the kernel: every wave's candidates of every row of the block are in LDS; thread r merges row r0 + r over the
+    // waves in ascending order (slices ascend with the wave index within a chunk but interleave across chunks: the tie rule compares indices)
+    __syncthreads();
+    if ((int)threadIdx.x < rend - r0) {
+        const int r = threadIdx.x;
+        float bv = xv[r][0];
+        int bi = xi[r][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const float ov = xv[r][w];
+            const int oi = xi[r][w];
+            const bool take_ov = ov > bv || (ov == bv && oi < bi);  // selects, not a branch
+            bv = take_ov ? ov : bv;
+            bi = take_ov ? oi : bi;
+        }
+        max0[s0.row_off + r0 + r] = bv;
+        idx0[s0.row_off + r0 + r] = (bi == SW_NO_INDEX) ? 0 : bi;  // all-NaN row: stay in range
     }
 }
 
@@ -852,6 +863,11 @@ static bool use_register_rows(int max_n) {
 // Rows of the score matrix behind one block of column partials (sizes the partials buffer: matcher_api.hip)
 int sweep_partial_rows(int max_n, int ext) { return use_register_rows(max_n) ? SW_ROWS : sweep_rows_per_block(max_n + ext); }
 
+// widest row ONE wave holds in the match extraction (4 chunks); GTSFM_EXTRACT_NARROW_COLS = 2048 restores the round-4 bound (A/B measurements)
+static int max_cols_narrow_extract() {
+    const char* env = getenv("GTSFM_EXTRACT_NARROW_COLS");
+    return (env && atoi(env) >= 256 && atoi(env) <= SW_MAX_COLS) ? atoi(env) : 1024;
+}
 static int chunks_for(int max_n) { return max_n <= 256 ? 1 : max_n <= 512 ? 2 : max_n <= 1024 ? 4 : 8; }
 // register chunks per wave of the wide tiers: the batch's widest pair of the tier decides (3 .. 5)
 static int wide_chunks_for(int max_n, int nw) {
@@ -949,34 +965,43 @@ int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogi
     if (a.npairs <= 0 || a.max_m <= 0 || a.max_n <= 0) return GTSFM_OK;
     if (!use_register_rows(a.max_n)) return launch_extract_matches_lds(a, superglue, zlogit, threshold, max0, idx0, idx1, matches, mscores, stream);
     const dim3 grid_rows(ceil_div(a.max_m, SW_ROWS), a.npairs), grid_cols(ceil_div(a.max_n, 256), a.npairs);
+    // One wave per row up to SW_EXTRACT_NARROW_COLS = 1024 columns (4 register chunks), the waves of a workgroup share a row above: four up to
+    // 5120 columns, eight up to 10240. Until round 5 one wave held rows of up to 2048 columns (8 chunks: 256 VGPRs + 81 .. 150 spilled to AGPRs,
+    // 1.7 TB/s at N = 2048) and LightGlue took eight waves for every wider row (with a bounds BRANCH per element its four-wave form needed 256
+    // VGPRs + 44 spilled at GTSfM's cap). The branch-free row loop (poisoned column terms, selects) and the barrier-free wide kernel need 129 ..
+    // 234 VGPRs, nothing spilled; LightGlue, 16 pairs at the cap: 0.767 -> 0.49 ms. Arg-maxima do not depend on how a row is cut into slices,
+    // so -- unlike the Sinkhorn / double-softmax sweeps, whose sums do -- this launcher is free to choose; GTSFM_EXTRACT_WAVES=8 sends every
+    // row above 1024 columns to the eight-wave tier, =4 is the default.
+    const int narrow_max = max_cols_narrow_extract();
 #define SW_LAUNCH_EXTRACT_SG(N)                                                                                                         \
     hipLaunchKernelGGL((extract_rows_kernel<true, N>), grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, \
-                       zlogit, max0, idx0, a.partials)
+                       zlogit, max0, idx0, a.partials, narrow_max)
 #define SW_LAUNCH_EXTRACT_LG(N)                                                                                                          \
     hipLaunchKernelGGL((extract_rows_kernel<false, N>), grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, \
-                       zlogit, max0, idx0, a.partials)
-#define SW_LAUNCH_EXTRACT_SG_WIDE(NW, N)                                                                                                  \
-    hipLaunchKernelGGL((extract_rows_wide_kernel<true, NW, N>), grid_rows, dim3(64 * NW), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, \
-                       a.colvec, zlogit, max0, idx0, a.partials, (NW) == 8 ? above8 : SW_MAX_COLS)
-#define SW_LAUNCH_EXTRACT_LG_WIDE(NW, N)                                                                                                   \
-    hipLaunchKernelGGL((extract_rows_wide_kernel<false, NW, N>), grid_rows, dim3(64 * NW), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, \
-                       a.colvec, zlogit, max0, idx0, a.partials, (NW) == 8 ? above8 : SW_MAX_COLS)
-    // Rows beyond 2048 columns: the Sinkhorn tiers, four waves per row up to 5120 columns, eight up to 10240. Until round 5 LightGlue took
-    // eight waves for every width (its extraction carries six register vectors per column chunk; with a bounds BRANCH per element the
-    // four-wave form needed 256 VGPRs + 44 spilled at GTSfM's cap). The branch-free row loop (poisoned column terms, selects) needs 232 / 142
-    // VGPRs at four / eight waves, nothing spilled, and four waves are faster for both matchers (LightGlue, 16 pairs at the cap: 0.575 vs
-    // 0.634 ms; before the rewrite 0.767). GTSFM_EXTRACT_WAVES=4 / 8 forces either; arg-maxima do not depend on the slicing.
+                       zlogit, max0, idx0, a.partials, narrow_max)
+#define SW_EXTRACT_WIDE_ARGS(NW) grid_rows, dim3(64 * NW), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, zlogit, max0, idx0, a.partials, (NW) == 8 ? above8 : narrow_max
+#define SW_LAUNCH_EXTRACT_SG_WIDE(NW, N)                                                                \
+    if (nt) hipLaunchKernelGGL((extract_rows_wide_kernel<true, NW, N, true>), SW_EXTRACT_WIDE_ARGS(NW)); \
+    else hipLaunchKernelGGL((extract_rows_wide_kernel<true, NW, N, false>), SW_EXTRACT_WIDE_ARGS(NW))
+#define SW_LAUNCH_EXTRACT_LG_WIDE(NW, N)                                                                 \
+    if (nt) hipLaunchKernelGGL((extract_rows_wide_kernel<false, NW, N, true>), SW_EXTRACT_WIDE_ARGS(NW)); \
+    else hipLaunchKernelGGL((extract_rows_wide_kernel<false, NW, N, false>), SW_EXTRACT_WIDE_ARGS(NW))
+    // the extraction is the LAST reader of the matrices: once the launch's matrices exceed the Infinity Cache, nontemporal reads (same values)
+    // leave it to data somebody will read again (see sw_zload; GTSFM_SWEEP_NT_MB as for the Sinkhorn sweeps)
+    const char* nt_env = getenv("GTSFM_SWEEP_NT_MB");
+    const bool nt = (double)a.npairs * a.max_m * a.max_n * 4.0 / (1024.0 * 1024.0) > (nt_env ? atof(nt_env) : 256.0);
     const char* ew_env = getenv("GTSFM_EXTRACT_WAVES");
-    const bool four_up_to_5120 = ew_env ? ew_env[0] == '4' : true;  // round 5: LightGlue too (232 VGPRs, nothing spilled: 0.575 vs 0.634 ms per 16 pairs at the cap)
-    const int above8 = four_up_to_5120 ? SW_WIDE4_COLS : SW_MAX_COLS;
+    const bool four_up_to_5120 = !(ew_env && ew_env[0] == '8');
+    const int above8 = four_up_to_5120 ? SW_WIDE4_COLS : narrow_max;
+    const int narrow_chunks = chunks_for(a.max_n < narrow_max ? a.max_n : narrow_max);
     if (superglue) {
         if (a.max_n > above8) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_EXTRACT_SG_WIDE)
-        if (four_up_to_5120 && a.max_n > SW_MAX_COLS) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_EXTRACT_SG_WIDE)
-        SW_DISPATCH(chunks_for(a.max_n), SW_LAUNCH_EXTRACT_SG)
+        if (four_up_to_5120 && a.max_n > narrow_max) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_EXTRACT_SG_WIDE)
+        SW_DISPATCH(narrow_chunks, SW_LAUNCH_EXTRACT_SG)
     } else {
         if (a.max_n > above8) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_EXTRACT_LG_WIDE)
-        if (four_up_to_5120 && a.max_n > SW_MAX_COLS) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_EXTRACT_LG_WIDE)
-        SW_DISPATCH(chunks_for(a.max_n), SW_LAUNCH_EXTRACT_LG)
+        if (four_up_to_5120 && a.max_n > narrow_max) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_EXTRACT_LG_WIDE)
+        SW_DISPATCH(narrow_chunks, SW_LAUNCH_EXTRACT_LG)
     }
     hipLaunchKernelGGL(extract_cols_kernel, grid_cols, dim3(256), 0, stream, a.pairs, a.seqs, a.counts, a.partials, idx1);
     GTSFM_CHECK_LAUNCH("extract_rows/cols_kernel");

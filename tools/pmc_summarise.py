@@ -39,8 +39,10 @@ def per_launch(tag, needle, launches_per_call=1, which=max):
     wk = [k for k in w if needle in k]
     if not fk or not wk:
         return None
-    fsum = sum(f[k]["sum"] for k in fk) / max(1, sum(f[k]["dispatches"] for k in fk)) * launches_per_call
-    wsum = sum(w[k]["sum"] for k in wk) / max(1, sum(w[k]["dispatches"] for k in wk)) * launches_per_call
+    # a sweep launches every tier its batch can contain (the blocks of the tiers a pair does not belong to return at once): one dispatch of EACH
+    # matching kernel per iteration -> the per-iteration figure is the SUM of the kernels' per-dispatch averages, not their mean
+    fsum = sum(f[k]["avg"] for k in fk) * launches_per_call
+    wsum = sum(w[k]["avg"] for k in wk) * launches_per_call
     return int(2 * 1024 * fsum), int(1024 * wsum)
 
 
@@ -65,7 +67,8 @@ if a:
     traffic[f"attention_dma_kernel@{nseq}x4x{n}"] = {"launch_shape": f"{nseq} sequences x 4 heads, N = {n} (fused schedule)", "fetch_bytes": a[0], "write_bytes": a[1],
                                                    "algorithmic_bytes": 4 * 4 * nseq * n * 256}
 gem = by_grid("all", "gemm_dma_walk_kernel")
-shapes = {(256, 768): None, (512, 512): None, (512, 256): None, (256, 512): None}
+gem2 = by_grid("gemm_163840_256_512", "gemm_dma_walk_kernel")  # 256 -> 512 shares its grid with 512 -> 512: its own pass pair
+shapes = {(256, 768): None, (512, 512): None, (512, 256): None}
 # grids: ceil(mtiles / 8) * 8 * ceil(N / 128) x 1 -> identify by the column-block count; 512 -> 512 and 256 -> 512 share a grid and are told apart by bytes fetched
 mt = -(-rows // 128)
 for (k, nn) in list(shapes):
@@ -77,11 +80,12 @@ for (k, nn), cands in shapes.items():
     if not cands:
         continue
     g, v = cands[0]
-    note = None
-    if (k, nn) in ((512, 512), (256, 512)):  # same grid: the per-dispatch average mixes both shapes; split by algorithmic A bytes
-        note = "grid shared with the other 512-column shape: per-dispatch average over both"
     traffic[f"gemm_dma_walk_kernel@{rows}x{k}x{nn}"] = {"launch_shape": f"{rows} x {k} -> {nn}", "fetch_bytes": v[0], "write_bytes": v[1],
-                                                        "algorithmic_bytes": 4 * (rows * k + nn * k + rows * nn), **({"note": note} if note else {})}
+                                                        "algorithmic_bytes": 4 * (rows * k + nn * k + rows * nn)}
+for g, v in gem2.items():
+    if g.isdigit() and int(g) == (-(-mt // 8) * 8) * 4 * 256:
+        traffic[f"gemm_dma_walk_kernel@{rows}x256x512"] = {"launch_shape": f"{rows} x 256 -> 512", "fetch_bytes": v[0], "write_bytes": v[1],
+                                                          "algorithmic_bytes": 4 * (rows * 256 + 512 * 256 + rows * 512)}
 sg = [(g, v) for g, v in gem.items() if g.isdigit() and int(g) == (-(-(-(-n // 128)) // 8) * 8) * -(-n // 128) * 256]
 if sg:
     traffic[f"gemm_dma_walk_kernel@{n}x256x{n}"] = {"launch_shape": f"score matrix of one pair: {n} x 256 -> {n}", "fetch_bytes": sg[0][1][0], "write_bytes": sg[0][1][1],
