@@ -71,6 +71,12 @@ def image(seed: int) -> np.ndarray:
     return ((cell + fine + ramp) & 255).astype(np.uint8)
 
 
+def cfloat(v) -> str:
+    """A C float literal that reads back to exactly this float32 (nine significant digits; a '.' so that "1f" cannot happen)."""
+    t = f"{float(v):.9g}"
+    return (t if any(ch in t for ch in ".en") else t + ".0") + "f"
+
+
 def main() -> None:
     torch.set_num_threads(4)
     best = None
@@ -104,11 +110,11 @@ def main() -> None:
         " * tests/abi/abi_model_from_c.c, computed by oracle/superpoint_oracle.py (restatement pinned bit-exact on the reference's superpoint.py).",
         f" * Smallest score gap any keypoint decision of this fixture depends on: {score:.2e} (the HIP path agrees with the oracle to ~3e-6). */",
         f"#define ABI_MODEL_H {H}", f"#define ABI_MODEL_W {W}", f"#define ABI_MODEL_SEED {seed}u", f"#define ABI_MODEL_K {len(kp)}",
-        "static const float abi_model_scales[24] = {" + ", ".join(f"{float(s):.9g}f" for s in scales()) + "};",
+        "static const float abi_model_scales[24] = {" + ", ".join(cfloat(s) for s in scales()) + "};",
         "static const int abi_model_shapes[12][3] = {" + ", ".join(f"{{{cout}, {cin}, {k}}}" for _, cout, cin, k in LAYERS) + "};  /* cout, cin, kernel */",
         "static const short abi_model_xy[ABI_MODEL_K][2] = {" + ", ".join(f"{{{int(a)}, {int(b)}}}" for a, b in kp) + "};",
-        "static const float abi_model_scores[ABI_MODEL_K] = {" + ", ".join(f"{float(s):.9g}f" for s in sc) + "};",
-        "static const float abi_model_desc_head[ABI_MODEL_K][4] = {" + ", ".join("{" + ", ".join(f"{float(v):.9g}f" for v in row[:4]) + "}" for row in de) + "};",
+        "static const float abi_model_scores[ABI_MODEL_K] = {" + ", ".join(cfloat(s) for s in sc) + "};",
+        "static const float abi_model_desc_head[ABI_MODEL_K][4] = {" + ", ".join("{" + ", ".join(cfloat(v) for v in row[:4]) + "}" for row in de) + "};",
         "",
     ]
     (REPO / "tests" / "abi" / "abi_model_expected.h").write_text("\n".join(lines))

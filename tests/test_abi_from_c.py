@@ -32,7 +32,7 @@ def _build_c(tmp_path, built_library, source: str, extra=()):
     exe = tmp_path / Path(source).stem
     lib_dir = Path(built_library).parent
     subprocess.run(
-        ["gcc", "-std=c99", "-Wall", "-Werror", f"-I{REPO / 'include'}", *extra, str(REPO / "tests" / "abi" / source), f"-L{lib_dir}", "-lgtsfm_amd",
+        ["gcc", "-std=c99", "-ffp-contract=off", "-Wall", "-Werror", f"-I{REPO / 'include'}", *extra, str(REPO / "tests" / "abi" / source), f"-L{lib_dir}", "-lgtsfm_amd",
          f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-o", str(exe)],
         check=True, capture_output=True, text=True,
     )
@@ -81,6 +81,40 @@ def test_model_level_entry_points_driven_from_c(built_library, tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=300)
     assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
     assert "abi_model_from_c OK" in run.stdout
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
+def test_lightglue_program_compiles_as_c_and_its_header_is_current(built_library, tmp_path):
+    """CPU half of the matcher-level test: the program compiles and links here; the upstream-layout state_dict of the generator still prepares
+    (matcher_engine.lightglue_entries) into exactly the logical entries the C program builds, and the oracle still gives the header's matches."""
+    exe, _ = _build_c(tmp_path, built_library, "abi_lightglue_from_c.c", ["-isystem", "/opt/rocm/include", f"-I{REPO / 'tests' / 'abi'}"])
+    assert exe.exists()
+    import re
+    import sys
+
+    sys.path.insert(0, str(REPO))
+    import numpy as np
+
+    from oracle import make_abi_lightglue_expectation as gen
+
+    header = (REPO / "tests" / "abi" / "abi_lightglue_expected.h").read_text()
+    seed = int(re.search(r"#define ABI_LG_SEED (\d+)u", header).group(1))
+    want0 = np.array(header.split("abi_lg_matches0[ABI_LG_N0] = {")[1].split("}")[0].split(","), dtype=np.int64)
+    gen.check_preparation(seed)
+    out = gen.run_oracle(seed)
+    np.testing.assert_array_equal(out["matches0"][0].numpy(), want0)
+    assert int((want0 > -1).sum()) >= 100 and len(want0) == gen.N0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
+def test_lightglue_entry_points_driven_from_c(built_library, tmp_path):
+    """gtsfm_pack_blob -> gtsfm_match_build_desc -> gtsfm_lg_workspace_bytes -> gtsfm_lg_forward from a C program that owns its device memory and
+    stream: all 580 match indices identical to the oracle's numbers in abi_lightglue_expected.h, matching scores within 1e-4."""
+    exe, env = _build_c(tmp_path, built_library, "abi_lightglue_from_c.c", ["-isystem", "/opt/rocm/include", f"-I{REPO / 'tests' / 'abi'}"])
+    run = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    assert "abi_lightglue_from_c OK" in run.stdout
 
 
 @pytest.mark.gpu
