@@ -21,6 +21,7 @@ The product class that drives these is ``gtsfm_amd.frontend.correspondence_gener
 
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -161,6 +162,12 @@ def exchange_feature_rows(plan: ScenePlan, local: Dict[str, torch.Tensor], gathe
     ``gather_rows(tensor, index)``: how the send buffer is assembled from ``local`` (default ``torch.index_select``; the GPU pipeline passes
     its block-move kernel). Without a process group the table is assembled locally."""
     d = _dist()
+    if d is not None and os.environ.get("GTSFM_SHARD_EXCHANGE", "all_to_all") == "all_gather":
+        # escape hatch (round 2-4's exchange): every rank receives every image, then keeps the rows of its table. Same result, ~R / 2 times the
+        # bytes; for a node whose RCCL build has trouble with ragged all_to_all.
+        full = all_gather_feature_table(local, plan.num_images, keys=keys)
+        rows = torch.tensor([table_index(i, plan.num_images, plan.world) for i in plan.table_images], dtype=torch.int64, device=local[keys[0]].device)
+        return {key: torch.index_select(full[key], 0, rows) for key in keys}
     index = [s for slots in plan.send_slots for s in slots] if d is not None else [i // plan.world for i in plan.table_images]
     some = local[keys[0]]
     idx = torch.tensor(index, dtype=torch.int64, device=some.device)

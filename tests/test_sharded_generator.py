@@ -103,7 +103,11 @@ def _joined_worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-def test_joined_mode_is_a_collective_call_and_every_rank_gets_the_result(tmp_path):
+@pytest.mark.parametrize("exchange", ["all_to_all", "all_gather"])
+def test_joined_mode_is_a_collective_call_and_every_rank_gets_the_result(tmp_path, monkeypatch, exchange):
+    """Both forms of the exchange step: the ragged ``all_to_all_single`` (default: an image goes only to the ranks that match it) and the
+    ``GTSFM_SHARD_EXCHANGE=all_gather`` escape hatch (everything to everybody, then the table rows are selected) give the same tables and results."""
+    monkeypatch.setenv("GTSFM_SHARD_EXCHANGE", exchange)
     world = 3  # a 1 x 3 process grid
     mp.spawn(_joined_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     images, pairs = _scene(11), parallel.exhaustive_pairs(11)[:40]
