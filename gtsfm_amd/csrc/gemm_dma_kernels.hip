@@ -205,7 +205,18 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
             for (int h = 0; h < DM_KC / 16; ++h) {
                 u32x4 a0[3], a1[3], b0[3], b1[3];
                 frag8(sA, ra, h, a0), frag8(sA, ra + 32, h, a1);
+#ifdef GTSFM_X3_ABLATE_WSPLIT  // developer ablation (tools/build_variant.sh; results are garbage): what weights that arrive ALREADY split would save -- the
+                {              // weight fragments are read (same LDS traffic as three bf16 planes would cost: 2 x 16 B here, 3 x 16 B then) but not split
+                    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(sW + rw * DM_KC + dm_swz(rw, 4 * h + 2 * kh) * 4);
+                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(sW + rw * DM_KC + dm_swz(rw, 4 * h + 2 * kh + 1) * 4);
+                    const f32x4 lo5 = *reinterpret_cast<const f32x4*>(sW + (rw + 32) * DM_KC + dm_swz(rw + 32, 4 * h + 2 * kh) * 4);
+                    const f32x4 hi5 = *reinterpret_cast<const f32x4*>(sW + (rw + 32) * DM_KC + dm_swz(rw + 32, 4 * h + 2 * kh + 1) * 4);
+                    b0[0] = __builtin_bit_cast(u32x4, lo4), b0[1] = __builtin_bit_cast(u32x4, hi4), b0[2] = b0[0];
+                    b1[0] = __builtin_bit_cast(u32x4, lo5), b1[1] = __builtin_bit_cast(u32x4, hi5), b1[2] = b1[0];
+                }
+#else
                 frag8(sW, rw, h, b0), frag8(sW, rw + 32, h, b1);
+#endif
                 x3_product(c00, c01, b0, b1, a0);  // weights = MFMA A operand (output columns), activations = B operand: a lane owns an output row
 #pragma unroll
                 for (int i = 0; i < 4; ++i) piece(4 * h + i, na, nw, nA, nW);
