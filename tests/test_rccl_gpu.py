@@ -47,6 +47,27 @@ def test_scene_mode_through_rccl_on_the_device(gpu_device):
 
 
 @pytest.mark.gpu
+def test_replica_mode_under_the_drivers_launcher_through_rccl(gpu_device):
+    """The driver's multi-GPU command shape -- ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N --steps K --warmup W`` -- with the one rank a one-GPU box allows and the process group forced on: rendezvous from the launcher's
+    environment, RCCL weight broadcasts, barrier + max-reduce of the step time, one JSON line from rank 0 in replica mode (weak scaling)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GTSFM_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           str(REPO / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "30", "--keypoints", "1024", "--size", "512", "--no-secondary",
+           "--no-cpu-baseline", "--no-roofline"]
+    run = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(REPO))
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["distributed"] == {"backend": "nccl", "world_size": 1, "collectives": ["broadcast (packed weights)", "barrier", "all_reduce MAX (step time)"]}
+    assert r["n_gpus"] == 1 and r["scaling"] == "weak" and r["config"]["mode"] == "replica" and r["config"]["pairs_per_gpu_per_step"] == 30
+    assert r["value"] > 0 and r["config"]["matches_per_pair"] > 5 and r["steps"] == 2 and r["warmup"] == 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
 def test_sharded_generator_class_through_rccl_equals_the_single_process_generators(gpu_device, matcher, tmp_path):
     """``ShardedDetDescCorrespondenceGenerator.generate_correspondences`` in joined mode on a one-rank RCCL group (subprocess) == the same
