@@ -157,5 +157,6 @@ def test_device_resident_generator_and_verifier_on_the_barn_frames(golden, chain
     # putative matches: the golden chain's (the keypoint ORDER enters LightGlue's fp32 sums; no match of this fixture sits near the filter threshold).
     # verified matches: the verifier draws its samples by match INDEX, and the batched path lists a pair's matches in ITS keypoint order -- another
     # (equally valid) RANSAC run over the same putative set; it may keep a slightly different inlier set
+    # -- observed on MI355X (profiles/r05_config5_barn_observed.json): it keeps exactly the same ones on this fixture; asserted as observed
     assert put_diff == [0, 0, 0]
-    assert all(d <= 6 for d in ver_diff), ver_diff
+    assert ver_diff == [0, 0, 0], ver_diff
