@@ -142,3 +142,35 @@ def test_config1_fixture_oracle_reproduces_the_reference_on_a_frame():
     np.testing.assert_allclose(out["descriptors"].numpy().T[sel[:64]], g["descriptors_head_11"], rtol=0, atol=1e-6)
     # the wrapper's selection (gtsfm/common/keypoints.py:89-110): the 5000 strongest responses
     assert set(np.argpartition(-out["scores"].numpy(), 5000)[:5000].tolist()) == set(sel.tolist())
+
+
+def test_config5_barn_fixture_oracle_chain_on_a_pair():
+    """The front-end slice of BASELINE config 5 (oracle/make_barn_config5_golden.py: the reference's three Barn fixture frames at the COLMAP loader's
+    760 x 1351): the SuperPoint oracle + the restated wrapper top-k reproduce frame 2's stored keypoints, the loader's intrinsics are the EXIF formula
+    rescaled, and the verifier oracle reproduces the stored verified indices of pair (0, 2) from the stored matches (the LightGlue leg, 8 s per pair on
+    the CPU, is re-run by the generator script and under -m gpu)."""
+    import io
+
+    from PIL import Image as PILImage
+
+    from oracle import verifier_oracle
+
+    g = np.load(GOLDEN / "barn_config5_frontend.npz")
+    assert (int(g["height"]), int(g["width"])) == (760, 1351) and int(g["max_resolution"]) == 760 and list(g["names"]) == ["000001.jpg", "000002.jpg", "000003.jpg"]
+    gray = np.asarray(PILImage.open(io.BytesIO(g["gray_png_2"].tobytes())))
+    assert gray.dtype == np.uint8 and gray.shape == (760, 1351)
+    sd = synthetic.synthetic_superpoint_state_dict()
+    with torch.no_grad():
+        out = superpoint_oracle.superpoint_forward(sd, superpoint_oracle.gray_u8_to_tensor(gray))
+    assert out["keypoints"].shape[0] == int(g["k_raw_2"]) > 5000
+    sel = g["sel_2"].astype(np.int64)
+    np.testing.assert_array_equal(out["keypoints"].numpy()[sel].astype(np.int16), g["keypoints_2"])
+    np.testing.assert_allclose(out["scores"].numpy()[sel], g["scores_2"], rtol=0, atol=1e-6)
+    # gtsfm/common/image.py:108-111 at 1920 x 1080, rescaled like gtsfm/loader/loader_base.py:224-233 to 1351 x 760
+    f = 21.0 / 35.0 * 1920 * (1351 / 1920)
+    np.testing.assert_allclose(g["intrinsics"][2], [f, f, 960 * (1351 / 1920), 540 * (760 / 1080)], rtol=1e-12)
+    k0, k2 = g["keypoints_0"].astype(np.float32), g["keypoints_2"].astype(np.float32)
+    ver = verifier_oracle.verify(k0, k2, g["matches_0_2"].astype(np.int64), tuple(g["intrinsics"][0]), tuple(g["intrinsics"][2]), float(g["threshold_px"]), seed=(0 << 32) | 2)
+    np.testing.assert_array_equal(np.asarray(ver["v_corr_idxs"]).astype(np.int64).reshape(-1, 2), g["v_corr_idxs_0_2"].astype(np.int64))
+    np.testing.assert_allclose(np.asarray(ver["R"]), g["R_0_2"], rtol=0, atol=1e-12)
+    assert len(g["matches_0_1"]) + len(g["matches_0_2"]) + len(g["matches_1_2"]) == 70
