@@ -32,7 +32,15 @@ def test_ctypes_binding_covers_header(built_library):
     assert sorted(L.SIGNATURES) == _declared_functions()
     lib = L.load()
     assert lib.gtsfm_abi_version() == 1
-    assert lib.gtsfm_last_error() == b""
+    # the last error is per THREAD and "" on a thread that has not seen one -- read on a fresh thread so that the order in which test files ran in
+    # this process cannot matter (the main thread may carry the message of another test's deliberately bad call)
+    import threading
+
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.gtsfm_last_error()))
+    t.start()
+    t.join()
+    assert seen == [b""]
 
 
 def test_host_side_packers(built_library):
