@@ -525,6 +525,22 @@ __device__ __forceinline__ void sw_load_slice(const float* __restrict__ zr, int 
     }
 }
 
+// The same slice through a buffer resource, with NO branch around any load and ONE 32-bit register of address per chunk: the pair's matrix is
+// the resource, the row's byte offset rides in a scalar register, the lane's column offset (loop-invariant) in voff[c]. A chunk at or beyond
+// column n re-reads the row's first 16 bytes (voff = 0; the caller makes those lanes' values harmless).
+//   * a load inside a branch makes the compiler's wait-count pass give up counting: every later wait becomes s_waitcnt vmcnt(0) -- "wait for
+//     every load in flight", the rows prefetched for LATER iterations included -- and the prefetch hides nothing;
+//   * flat 64-bit addresses cost two registers per chunk and row in flight and a 64-bit add per load.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int NCH, bool NT = false>
+__device__ __forceinline__ void sw_load_slice_rsrc(__amdgpu_buffer_rsrc_t z, unsigned row_bytes, const int (&voff)[NCH], f32x4 (&dst)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(z, voff[c], (int)row_bytes, NT ? 2 : 0);  // aux bit 1: nontemporal
+        dst[c] = __builtin_bit_cast(f32x4, raw);
+    }
+}
+
 template <int NW, int NCH, bool NT>
 __global__ __launch_bounds__(64 * NW) void sinkhorn_rows_wide_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                                      const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
@@ -730,7 +746,7 @@ __global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __re
 }
 
 template <bool SG, int NW, int NCH, bool NT = false>
-__global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void extract_rows_wide_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                                     const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
                                                                     const float* __restrict__ rowvec, const float* __restrict__ colvec,
                                                                     const float* __restrict__ zlogit, float* __restrict__ max0,
@@ -740,6 +756,12 @@ __global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float*
     // profiles/r05_sq_counters.csv); the slices' candidates meet once, after the loop.
     __shared__ float xv[SW_ROWS][NW];
     __shared__ int xi[SW_ROWS][NW];
+    // The column TERMS of a wave's slice (b_j; LightGlue: logsigmoid(z1_j) too) live in LDS, not in registers: they are read-only, a wave reads
+    // back only what it wrote itself (no barrier), one ds_read_b128 per chunk and term and row (20 KiB per term at four waves x five chunks; 10 KB
+    // of LDS reads per wave and row against 5 KB of HBM reads: far below the LDS rate). That frees 8 registers per chunk, which pay for a THIRD row
+    // buffer (two rows in flight behind the one being processed) at three workgroups per CU instead of two: 120 KB in flight per CU against 40.
+    __shared__ __attribute__((aligned(16))) float col_b[NW][NCH][256];
+    __shared__ __attribute__((aligned(16))) float col_c[SG ? 1 : NW][SG ? 1 : NCH][256];
     const int p = blockIdx.y;
     const PairDesc pd = pairs[p];
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
@@ -754,72 +776,96 @@ __global__ __launch_bounds__(64 * NW) void extract_rows_wide_kernel(const float*
     const int vec0 = vec_off(s0, 2 * p), vec1 = vec_off(s1, 2 * p + 1);
     const float NEG = neg_inf();
     const float norm = SG ? -logf((float)m + (float)n) : 0.f;
-    f32x4 bj[NCH], cj[NCH], cbv[NCH], za[NCH], zb[NCH];
+    f32x4 cbv[NCH], za[NCH], zb[NCH];
     int cbi[NCH][4];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int col = 256 * (wave + NW * c) + 4 * lane;
-        cj[c] = za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         // columns beyond n (the row's padding to 4 floats, the chunks past the matrix) carry a column term that turns every value into
         // -inf or NaN -- SuperGlue adds b_j (-inf), LightGlue subtracts it (+inf) -- so that no comparison below can select them whatever the
         // padding holds: the row loop needs no per-element bounds test (compiled as a branch per element until round 5: 0.26 of the roof)
-        bj[c] = SG ? f32x4{NEG, NEG, NEG, NEG} : f32x4{-NEG, -NEG, -NEG, -NEG};
+        f32x4 bj = SG ? f32x4{NEG, NEG, NEG, NEG} : f32x4{-NEG, -NEG, -NEG, -NEG};
+        f32x4 cj = f32x4{0.f, 0.f, 0.f, 0.f};
         cbv[c] = f32x4{NEG, NEG, NEG, NEG};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             cbi[c][e] = SW_NO_INDEX;
             if (col + e < n) {
-                bj[c][e] = colvec[vec1 + col + e];
-                if (!SG) cj[c][e] = logsigmoid(zlogit[s1.row_off + col + e]);
+                bj[e] = colvec[vec1 + col + e];
+                if (!SG) cj[e] = logsigmoid(zlogit[s1.row_off + col + e]);
             }
         }
+        *reinterpret_cast<f32x4*>(&col_b[wave][c][4 * lane]) = bj;
+        if (!SG) *reinterpret_cast<f32x4*>(&col_c[wave][c][4 * lane]) = cj;
     }
     float ci_lane = 0.f;  // logsigmoid(z0_i) of the block's rows, one per lane (see extract_rows_kernel)
     if (!SG && r0 + (lane & 31) < m) ci_lane = logsigmoid(zlogit[s0.row_off + r0 + (lane & 31)]);
-    auto process = [&](int i, const f32x4(&zz)[NCH], int slot) {
+    auto process = [&](int i, const f32x4(&zz)[NCH]) {
         const float a_i = rowvec[vec0 + i];
         const float c_i = SG ? 0.f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ci_lane), __builtin_amdgcn_readfirstlane(i - r0)));
         float best = NEG;
-        int bidx = SW_NO_INDEX;
+        int bcode = -1;  // 4 * chunk + element of the lane's best value: wave-uniform constants (columns ascend with the code within a lane)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int col = 256 * (wave + NW * c) + 4 * lane;
+            const f32x4 bj = *reinterpret_cast<const f32x4*>(&col_b[wave][c][4 * lane]);
+            const f32x4 cj = SG ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(&col_c[SG ? 0 : wave][SG ? 0 : c][4 * lane]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float val = assign_value<SG>(zz[c][e], a_i, bj[c][e], norm, c_i, cj[c][e]);  // -inf / NaN beyond column n: never selected
+                const float val = assign_value<SG>(zz[c][e], a_i, bj[e], norm, c_i, cj[e]);  // -inf / NaN beyond column n: never selected
                 const bool row_better = val > best;  // columns ascend within a lane: the first maximum wins
                 best = row_better ? val : best;
-                bidx = row_better ? col + e : bidx;
+                bcode = row_better ? 4 * c + e : bcode;
                 const bool col_better = val > cbv[c][e];  // rows ascend
                 cbv[c][e] = col_better ? val : cbv[c][e];
                 cbi[c][e] = col_better ? i : cbi[c][e];
             }
+            // the chunk's column state is final HERE (unpinned, the compiler computes every chunk's values first and updates the column state
+            // after the wave reduction: 20 more live registers), and one chunk's column terms are in registers at a time (unfenced: all 40 are
+            // read up front)
+            asm volatile("" : "+v"(cbv[c]), "+v"(cbi[c][0]), "+v"(cbi[c][1]), "+v"(cbi[c][2]), "+v"(cbi[c][3]));
+            __builtin_amdgcn_sched_barrier(0);
         }
+        int bidx = bcode < 0 ? SW_NO_INDEX : 256 * (wave + NW * (bcode >> 2)) + 4 * lane + (bcode & 3);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const float ob = __shfl_xor(best, off, 64);
             const int oj = __shfl_xor(bidx, off, 64);
-            const bool take_ob = ob > best || (ob == best && oj < bidx);  // selects, not a branch
+            const bool take_ob = (ob > best) | ((ob == best) & (oj < bidx));  // bitwise: || and && compile to a branch per step
             best = take_ob ? ob : best;
             bidx = take_ob ? oj : bidx;
         }
         if (lane == 0) xv[i - r0][wave] = best, xi[i - r0][wave] = bidx;
-        (void)slot;
     };
-    const int rend = (r0 + SW_ROWS < m) ? r0 + SW_ROWS : m;
+    const int rend = (r0 + SW_ROWS < m) ? r0 + SW_ROWS : m, last = rend - 1;
+    // Two rows in flight behind the one being processed, every load unconditional (sw_load_slice_rsrc; past the block's last row the
+    // last row is read again: <= 2 of 32 rows, L2 hits) so that the waits are exact counts: s_waitcnt vmcnt(2 NCH) before row i leaves rows
+    // i + 1 and i + 2 in flight. Until this form every wait was vmcnt(0) -- each row paid the full memory latency (3 us per row at the cap, 70 %
+    // of the wave cycles waiting, VALU issue 18 %: profiles/r05_sq_counters.csv) and only the occupancy overlapped anything.
+    // every piece of the resource and of the row offset through readfirstlane: a descriptor the compiler cannot prove wave-uniform is read in a
+    // loop over the lanes' values around each load
+    const unsigned long long zaddr = reinterpret_cast<unsigned long long>(Z);
+    float* const zuni = reinterpret_cast<float*>((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(zaddr >> 32)) << 32 |
+                                                 (unsigned)__builtin_amdgcn_readfirstlane((int)zaddr));
+    const unsigned ldb = (unsigned)__builtin_amdgcn_readfirstlane(ld) * 4u, mrows = (unsigned)__builtin_amdgcn_readfirstlane(m);
+    const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc(zuni, 0, (int)(mrows * ldb), 0x00020000);
+    int voff[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 256 * (wave + NW * c) + 4 * lane;
+        voff[c] = col < n ? 4 * col : 0;
+    }
+    auto row_bytes = [&](int r) { return (unsigned)__builtin_amdgcn_readfirstlane(r < last ? r : last) * ldb; };
     int i = r0;
-    // One row in flight behind the one being processed. A third register buffer (two rows in flight) was built in round 5: 256 VGPRs + 20 .. 57
-    // spilled at five chunks (the column state -- value, index, two column terms -- is 16 registers per chunk already) and one workgroup per
-    // CU instead of two: not kept. What bounds the kernel is that row time = memory latency (3 us per row at the cap; 70 % of the wave cycles
-    // waiting, VALU issue 18 %: profiles/r05_sq_counters.csv); the way past it is the column state in LDS, not more registers.
-    sw_load_slice<NW, NCH, NT>(Z + (size_t)i * ld, n, wave, lane, za);
+    sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i), voff, za);
 #pragma unroll 1
-    for (; i < rend; i += 2) {
-        if (i + 1 < rend) sw_load_slice<NW, NCH, NT>(Z + (size_t)(i + 1) * ld, n, wave, lane, zb);
-        process(i, za, 0);
+    for (;; i += 2) {
+        sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i + 1), voff, zb);
+        process(i, za);
         if (i + 1 >= rend) break;
-        if (i + 2 < rend) sw_load_slice<NW, NCH, NT>(Z + (size_t)(i + 2) * ld, n, wave, lane, za);
-        process(i + 1, zb, 1);
+        sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i + 2), voff, za);
+        process(i + 1, zb);
+        if (i + 2 >= rend) break;
     }
     // block partial per column: plane 0 = best value, plane 1 = its row (as int bits), at part_off + block * 2 ld
     float* part = partials + pd.part_off + (size_t)blockIdx.x * 2 * ld;
