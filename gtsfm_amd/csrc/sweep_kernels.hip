@@ -62,6 +62,32 @@ __device__ __forceinline__ void sw_load_row(const float* __restrict__ zr, int n,
     }
 }
 
+// A row (or a wave's slice of it) through a buffer resource, with NO branch around any load and ONE 32-bit register of address per chunk: the pair's matrix is
+// the resource, the row's byte offset rides in a scalar register, the lane's column offset (loop-invariant) in voff[c]. A chunk at or beyond
+// column n re-reads the row's first 16 bytes (voff = 0; the caller makes those lanes' values harmless).
+//   * a load inside a branch makes the compiler's wait-count pass give up counting: every later wait becomes s_waitcnt vmcnt(0) -- "wait for
+//     every load in flight", the rows prefetched for LATER iterations included -- and the prefetch hides nothing;
+//   * flat 64-bit addresses cost two registers per chunk and row in flight and a 64-bit add per load.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int NCH, bool NT = false>
+__device__ __forceinline__ void sw_load_slice_rsrc(__amdgpu_buffer_rsrc_t z, unsigned row_bytes, const int (&voff)[NCH], f32x4 (&dst)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(z, voff[c], (int)row_bytes, NT ? 2 : 0);  // aux bit 1: nontemporal
+        dst[c] = __builtin_bit_cast(f32x4, raw);
+    }
+}
+
+// The pair's score matrix as a buffer resource + the row pitch in bytes. Every piece goes through readfirstlane: a descriptor the compiler
+// cannot prove wave-uniform is read in a loop over the lanes' values around each load.
+#define SW_MAKE_ROW_RESOURCE(res, pitch, Zptr, mrows_, ld_)                                                                                  \
+    const unsigned long long res##_addr = reinterpret_cast<unsigned long long>(Zptr);                                                        \
+    float* const res##_uni = reinterpret_cast<float*>((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(res##_addr >> 32)) << 32 | \
+                                                      (unsigned)__builtin_amdgcn_readfirstlane((int)res##_addr));                            \
+    const unsigned pitch = (unsigned)__builtin_amdgcn_readfirstlane(ld_) * 4u;                                                               \
+    const __amdgpu_buffer_rsrc_t res =                                                                                                       \
+        __builtin_amdgcn_make_buffer_rsrc(res##_uni, 0, (int)((unsigned)__builtin_amdgcn_readfirstlane(mrows_) * pitch), 0x00020000)
+
 // ---------------------------------------------------------------------------------------------------------------
 // SuperGlue: one Sinkhorn iteration = sinkhorn_rows_kernel + sinkhorn_cols_kernel
 // ---------------------------------------------------------------------------------------------------------------
@@ -100,15 +126,12 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 2 : 3) void sinkhorn_rows_kernel(co
     const float t_bin = alpha + colvec[vec1 + n];  // dustbin column: Z[i][n] = bin_score for every row
     float acc_bin = 0.f;
 
-    auto load = [&](int i, f32x4(&dst)[NCH]) {
-        if (i < m) {
-            sw_load_row<NCH, NT>(Z + (size_t)i * ld, n, lane, dst);
-        } else {  // dustbin row: Z[m][j] = bin_score
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) dst[c] = f32x4{alpha, alpha, alpha, alpha};
-        }
-    };
     auto process = [&](int i, f32x4(&zz)[NCH]) {
+        if (__builtin_amdgcn_readfirstlane(i) >= m) {  // dustbin row: Z[m][j] = bin_score. A real (scalar) branch, taken by one row per pair: as
+            asm volatile("");                          // selects it costs every row a v_cndmask per element AND is hoisted above the row's
+#pragma unroll                                         // first use, where it waits for the loads of the NEXT row as well
+            for (int c = 0; c < NCH; ++c) zz[c] = f32x4{alpha, alpha, alpha, alpha};
+        }
         float mx = t_bin;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -147,18 +170,38 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 2 : 3) void sinkhorn_rows_kernel(co
         acc_bin = fmaf(e_bin, w, acc_bin);
     };
 
-    int i = r0 + wave;
-    if (i < rows) load(i, za);
+    SW_MAKE_ROW_RESOURCE(zres, ldb, Z, m, ld);
+    int voff[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        voff[c] = col < n ? 4 * col : 0;
+    }
+    // this wave's rows: r0 + wave, + 4, ... One row in flight behind the one being processed; every load unconditional (past the wave's last row
+    // the last row is read again: an L2 hit) so that the waits are exact counts -- see sw_load_slice_rsrc
+    const int iend = (r0 + SW_ROWS < rows) ? r0 + SW_ROWS : rows;
+    int i = r0 + __builtin_amdgcn_readfirstlane(wave);
+    if (i < iend) {
+        const int lastw = i + ((iend - 1 - i) & ~3);
+        // the dustbin row (r = m) reads row m - 1 (m = 0: the resource is empty, zeros come back); process() puts bin_score in its place
+        auto load = [&](int r, f32x4(&dst)[NCH]) {
+            const int rc = r < lastw ? r : lastw;
+            sw_load_slice_rsrc<NCH, NT>(zres, (unsigned)__builtin_amdgcn_readfirstlane(rc < m ? rc : m - 1) * ldb, voff, dst);
+        };
+        load(i, za);
 #pragma unroll 1
-    for (int k = 0; k < SW_ROWS / 4; k += 2) {
-        if (i >= rows) break;
-        if (i + 4 < rows) load(i + 4, zb);  // k + 1 < 8 always holds here
-        process(i, za);
-        i += 4;
-        if (i >= rows) break;
-        if (i + 4 < rows && k + 2 < SW_ROWS / 4) load(i + 4, za);
-        process(i, zb);
-        i += 4;
+        for (;;) {
+            load(i + 4, zb);
+            __builtin_amdgcn_sched_barrier(0);  // the next row's loads are issued BEFORE the wait for this row's
+            process(i, za);
+            i += 4;
+            if (i >= iend) break;
+            load(i + 4, za);
+            __builtin_amdgcn_sched_barrier(0);
+            process(i, zb);
+            i += 4;
+            if (i >= iend) break;
+        }
     }
 
     // column partials of the block's 32 rows: sum of the 4 waves, in a fixed order
@@ -274,18 +317,33 @@ __global__ __launch_bounds__(256, 2) void lg_rows_kernel(const float* __restrict
         s = wave_sum(s);
         if (lane == 0) rowvec[vec0 + i] = logf(s) + mx;
     };
-    int i = r0 + wave;
-    if (i < m) sw_load_row<NCH>(Z + (size_t)i * ld, n, lane, za);
+    SW_MAKE_ROW_RESOURCE(zres, ldb, Z, m, ld);
+    int voff[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        voff[c] = col < n ? 4 * col : 0;
+    }
+    // this wave's rows: r0 + wave, + 4, ...; unconditional loads with exact wait counts (see sinkhorn_rows_kernel)
+    const int iend = (r0 + SW_ROWS < m) ? r0 + SW_ROWS : m;
+    int i = r0 + __builtin_amdgcn_readfirstlane(wave);
+    if (i < iend) {
+        const int lastw = i + ((iend - 1 - i) & ~3);
+        auto row_bytes = [&](int r) { return (unsigned)__builtin_amdgcn_readfirstlane(r < lastw ? r : lastw) * ldb; };
+        sw_load_slice_rsrc<NCH>(zres, row_bytes(i), voff, za);
 #pragma unroll 1
-    for (int k = 0; k < SW_ROWS / 4; k += 2) {
-        if (i >= m) break;
-        if (i + 4 < m) sw_load_row<NCH>(Z + (size_t)(i + 4) * ld, n, lane, zb);
-        process(i, za);
-        i += 4;
-        if (i >= m) break;
-        if (i + 4 < m && k + 2 < SW_ROWS / 4) sw_load_row<NCH>(Z + (size_t)(i + 4) * ld, n, lane, za);
-        process(i, zb);
-        i += 4;
+        for (;;) {
+            sw_load_slice_rsrc<NCH>(zres, row_bytes(i + 4), voff, zb);
+            __builtin_amdgcn_sched_barrier(0);
+            process(i, za);
+            i += 4;
+            if (i >= iend) break;
+            sw_load_slice_rsrc<NCH>(zres, row_bytes(i + 4), voff, za);
+            __builtin_amdgcn_sched_barrier(0);
+            process(i, zb);
+            i += 4;
+            if (i >= iend) break;
+        }
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -432,18 +490,33 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(con
             idx0[s0.row_off + i] = (bidx == SW_NO_INDEX) ? 0 : bidx;  // all-NaN row: stay in range
         }
     };
-    int i = r0 + wave;
-    if (i < m) sw_load_row<NCH>(Z + (size_t)i * ld, n, lane, za);
+    SW_MAKE_ROW_RESOURCE(zres, ldb, Z, m, ld);
+    int voff[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        voff[c] = col < n ? 4 * col : 0;
+    }
+    // this wave's rows: r0 + wave, + 4, ...; unconditional loads with exact wait counts (see sinkhorn_rows_kernel)
+    const int iend = (r0 + SW_ROWS < m) ? r0 + SW_ROWS : m;
+    int i = r0 + __builtin_amdgcn_readfirstlane(wave);
+    if (i < iend) {
+        const int lastw = i + ((iend - 1 - i) & ~3);
+        auto row_bytes = [&](int r) { return (unsigned)__builtin_amdgcn_readfirstlane(r < lastw ? r : lastw) * ldb; };
+        sw_load_slice_rsrc<NCH>(zres, row_bytes(i), voff, za);
 #pragma unroll 1
-    for (int k = 0; k < SW_ROWS / 4; k += 2) {
-        if (i >= m) break;
-        if (i + 4 < m) sw_load_row<NCH>(Z + (size_t)(i + 4) * ld, n, lane, zb);
-        process(i, za);
-        i += 4;
-        if (i >= m) break;
-        if (i + 4 < m && k + 2 < SW_ROWS / 4) sw_load_row<NCH>(Z + (size_t)(i + 4) * ld, n, lane, za);
-        process(i, zb);
-        i += 4;
+        for (;;) {
+            sw_load_slice_rsrc<NCH>(zres, row_bytes(i + 4), voff, zb);
+            __builtin_amdgcn_sched_barrier(0);
+            process(i, za);
+            i += 4;
+            if (i >= iend) break;
+            sw_load_slice_rsrc<NCH>(zres, row_bytes(i + 4), voff, za);
+            __builtin_amdgcn_sched_barrier(0);
+            process(i, zb);
+            i += 4;
+            if (i >= iend) break;
+        }
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -525,22 +598,6 @@ __device__ __forceinline__ void sw_load_slice(const float* __restrict__ zr, int 
     }
 }
 
-// The same slice through a buffer resource, with NO branch around any load and ONE 32-bit register of address per chunk: the pair's matrix is
-// the resource, the row's byte offset rides in a scalar register, the lane's column offset (loop-invariant) in voff[c]. A chunk at or beyond
-// column n re-reads the row's first 16 bytes (voff = 0; the caller makes those lanes' values harmless).
-//   * a load inside a branch makes the compiler's wait-count pass give up counting: every later wait becomes s_waitcnt vmcnt(0) -- "wait for
-//     every load in flight", the rows prefetched for LATER iterations included -- and the prefetch hides nothing;
-//   * flat 64-bit addresses cost two registers per chunk and row in flight and a 64-bit add per load.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <int NCH, bool NT = false>
-__device__ __forceinline__ void sw_load_slice_rsrc(__amdgpu_buffer_rsrc_t z, unsigned row_bytes, const int (&voff)[NCH], f32x4 (&dst)[NCH]) {
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(z, voff[c], (int)row_bytes, NT ? 2 : 0);  // aux bit 1: nontemporal
-        dst[c] = __builtin_bit_cast(f32x4, raw);
-    }
-}
-
 template <int NW, int NCH, bool NT>
 __global__ __launch_bounds__(64 * NW) void sinkhorn_rows_wide_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                                      const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
@@ -573,15 +630,12 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_rows_wide_kernel(const float
     const float t_bin = alpha + colvec[vec1 + n];  // dustbin column: Z[i][n] = bin_score for every row
     float acc_bin = 0.f;                           // kept by every wave (same value)
 
-    auto load = [&](int i, f32x4(&dst)[NCH]) {
-        if (i < m) {
-            sw_load_slice<NW, NCH, NT>(Z + (size_t)i * ld, n, wave, lane, dst);
-        } else {  // dustbin row: Z[m][j] = bin_score
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) dst[c] = f32x4{alpha, alpha, alpha, alpha};
-        }
-    };
     auto process = [&](int i, f32x4(&zz)[NCH], int slot) {
+        if (__builtin_amdgcn_readfirstlane(i) >= m) {  // dustbin row: Z[m][j] = bin_score. A real (scalar) branch, taken by one row per pair: as
+            asm volatile("");                          // selects it costs every row a v_cndmask per element AND is hoisted above the row's
+#pragma unroll                                         // first use, where it waits for the loads of the NEXT row as well
+            for (int c = 0; c < NCH; ++c) zz[c] = f32x4{alpha, alpha, alpha, alpha};
+        }
         float mw = NEG;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -631,16 +685,33 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_rows_wide_kernel(const float
         acc_bin = fmaf(e_bin, wrow, acc_bin);
     };
 
-    const int rend = (r0 + SW_ROWS < rows) ? r0 + SW_ROWS : rows;
+    const int rend = (r0 + SW_ROWS < rows) ? r0 + SW_ROWS : rows, last = rend - 1;
+    SW_MAKE_ROW_RESOURCE(zres, ldb, Z, m, ld);
+    int voff[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 256 * (wave + NW * c) + 4 * lane;
+        voff[c] = col < n ? 4 * col : 0;
+    }
+    // every load unconditional (past the block's last row the last row is read again: an L2 hit) so that the waits are exact counts -- see
+    // sw_load_slice_rsrc
+    // the dustbin row (r = m) reads row m - 1 (m = 0: the resource is empty, zeros come back); process() puts bin_score in its place
+    auto load = [&](int r, f32x4(&dst)[NCH]) {
+        const int rc = r < last ? r : last;
+        sw_load_slice_rsrc<NCH, NT>(zres, (unsigned)__builtin_amdgcn_readfirstlane(rc < m ? rc : m - 1) * ldb, voff, dst);
+    };
     int i = r0;
     load(i, za);
 #pragma unroll 1
-    for (; i < rend; i += 2) {  // uniform for the workgroup: every wave walks the same rows
-        if (i + 1 < rend) load(i + 1, zb);
+    for (;; i += 2) {  // uniform for the workgroup: every wave walks the same rows
+        load(i + 1, zb);
+        __builtin_amdgcn_sched_barrier(0);  // the next row's loads are issued BEFORE the wait for this row's
         process(i, za, 0);
         if (i + 1 >= rend) break;
-        if (i + 2 < rend) load(i + 2, za);
+        load(i + 2, za);
+        __builtin_amdgcn_sched_barrier(0);
         process(i + 1, zb, 1);
+        if (i + 2 >= rend) break;
     }
 
     // column partials of the block's 32 rows: a wave's columns are its own, no combination step
@@ -663,7 +734,9 @@ template <int NW, int NCH>
 __global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                                const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
                                                                float* __restrict__ rowvec, float* __restrict__ partials) {
-    __shared__ float xm[2][NW], xs[2][NW];
+    // per row of the block and wave: (max, sum of exp(. - max)) of the wave's slice. No barrier inside the row loop (a barrier per row makes
+    // every wave wait for the slowest wave's loads of every row): the slices' statistics meet once, after the loop -- see extract_rows_wide_kernel
+    __shared__ float xm[SW_ROWS][NW], xs[SW_ROWS][NW];
     const int p = blockIdx.y;
     const PairDesc pd = pairs[p];
     const SeqDesc s0 = seqs[2 * p], s1 = seqs[2 * p + 1];
@@ -681,14 +754,14 @@ __global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __re
         cm[c] = f32x4{NEG, NEG, NEG, NEG};
         cs[c] = za[c] = zb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    auto process = [&](int i, f32x4(&zz)[NCH], int slot) {
+    auto process = [&](int i, f32x4(&zz)[NCH]) {
         float mw = NEG;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int col = 256 * (wave + NW * c) + 4 * lane;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float t = (col + e < n) ? zz[c][e] : NEG;
+                const float t = (col + e < n) ? zz[c][e] : NEG;  // also what makes the clamped loads of sw_load_slice_rsrc harmless
                 zz[c][e] = t;
                 mw = fmaxf(mw, t);
             }
@@ -711,28 +784,31 @@ __global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __re
             }
         }
         sw = wave_sum(sw);
-        if (lane == 0) xm[slot][wave] = mw, xs[slot][wave] = sw;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float mx = xm[slot][0];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) mx = fmaxf(mx, xm[slot][w]);
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) s += xs[slot][w] * sw_exp2((xm[slot][w] - mx) * SW_LOG2E);
-            rowvec[vec0 + i] = logf(s) + mx;
-        }
+        if (lane == 0) xm[i - r0][wave] = mw, xs[i - r0][wave] = sw;
     };
-    const int rend = (r0 + SW_ROWS < m) ? r0 + SW_ROWS : m;
+    const int rend = (r0 + SW_ROWS < m) ? r0 + SW_ROWS : m, last = rend - 1;
+    // one row in flight behind the one being processed, every load unconditional and through the pair's buffer resource (sw_load_slice_rsrc:
+    // exact wait counts -- with a branch around the loads every wait was vmcnt(0) and the prefetched row was waited for as well)
+    SW_MAKE_ROW_RESOURCE(zres, ldb, Z, m, ld);
+    int voff[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 256 * (wave + NW * c) + 4 * lane;
+        voff[c] = col < n ? 4 * col : 0;
+    }
+    auto row_bytes = [&](int r) { return (unsigned)__builtin_amdgcn_readfirstlane(r < last ? r : last) * ldb; };
     int i = r0;
-    sw_load_slice<NW, NCH>(Z + (size_t)i * ld, n, wave, lane, za);
+    sw_load_slice_rsrc<NCH>(zres, row_bytes(i), voff, za);
 #pragma unroll 1
-    for (; i < rend; i += 2) {
-        if (i + 1 < rend) sw_load_slice<NW, NCH>(Z + (size_t)(i + 1) * ld, n, wave, lane, zb);
-        process(i, za, 0);
+    for (;; i += 2) {
+        sw_load_slice_rsrc<NCH>(zres, row_bytes(i + 1), voff, zb);
+        __builtin_amdgcn_sched_barrier(0);  // the next row's loads are issued BEFORE the wait for this row's (the scheduler puts them after)
+        process(i, za);
         if (i + 1 >= rend) break;
-        if (i + 2 < rend) sw_load_slice<NW, NCH>(Z + (size_t)(i + 2) * ld, n, wave, lane, za);
-        process(i + 1, zb, 1);
+        sw_load_slice_rsrc<NCH>(zres, row_bytes(i + 2), voff, za);
+        __builtin_amdgcn_sched_barrier(0);
+        process(i + 1, zb);
+        if (i + 2 >= rend) break;
     }
     // block partial per column: plane 0 = max, plane 1 = sum of exp(. - max), at part_off + block * 2 ld
     float* part = partials + pd.part_off + (size_t)blockIdx.x * 2 * ld;
@@ -742,6 +818,18 @@ __global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __re
         if (col >= n) continue;
         *reinterpret_cast<f32x4*>(part + col) = cm[c];  // col < n, col % 4 == 0 -> col + 3 < ld (columns >= n are never read)
         *reinterpret_cast<f32x4*>(part + ld + col) = cs[c];
+    }
+    // the one barrier of the kernel; thread r merges row r0 + r over the waves, wave 0 first (the order the per-row form summed in)
+    __syncthreads();
+    if ((int)threadIdx.x < rend - r0) {
+        const int r = threadIdx.x;
+        float mx = xm[r][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mx = fmaxf(mx, xm[r][w]);
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += xs[r][w] * sw_exp2((xm[r][w] - mx) * SW_LOG2E);
+        rowvec[vec0 + r0 + r] = logf(sum) + mx;
     }
 }
 
@@ -842,13 +930,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void extract_rows_wide_ke
     // last row is read again: <= 2 of 32 rows, L2 hits) so that the waits are exact counts: s_waitcnt vmcnt(2 NCH) before row i leaves rows
     // i + 1 and i + 2 in flight. Until this form every wait was vmcnt(0) -- each row paid the full memory latency (3 us per row at the cap, 70 %
     // of the wave cycles waiting, VALU issue 18 %: profiles/r05_sq_counters.csv) and only the occupancy overlapped anything.
-    // every piece of the resource and of the row offset through readfirstlane: a descriptor the compiler cannot prove wave-uniform is read in a
-    // loop over the lanes' values around each load
-    const unsigned long long zaddr = reinterpret_cast<unsigned long long>(Z);
-    float* const zuni = reinterpret_cast<float*>((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(zaddr >> 32)) << 32 |
-                                                 (unsigned)__builtin_amdgcn_readfirstlane((int)zaddr));
-    const unsigned ldb = (unsigned)__builtin_amdgcn_readfirstlane(ld) * 4u, mrows = (unsigned)__builtin_amdgcn_readfirstlane(m);
-    const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc(zuni, 0, (int)(mrows * ldb), 0x00020000);
+    SW_MAKE_ROW_RESOURCE(zres, ldb, Z, m, ld);
     int voff[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
