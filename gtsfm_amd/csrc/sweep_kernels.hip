@@ -43,6 +43,14 @@ constexpr float SW_LOG2E = 1.44269504088896340736f;
 constexpr float SW_FLT_MIN = 1.17549435e-38f;
 
 __device__ __forceinline__ float sw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// fmaxf as the one instruction it is: for operands that come from memory the compiler puts a canonicalising v_max_f32 x, x in front of every
+// fmaxf (IEEE mode: a signalling NaN has to be quieted first) -- 40 of 320 vector instructions per row in the double log-softmax sweep.
+// v_max_f32 itself returns the other operand for a NaN, which is all the sweeps rely on.
+__device__ __forceinline__ float sw_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // Score-matrix reads. NT = nontemporal: when the matrices of one launch together exceed the 256 MiB Infinity Cache, every sweep streams
 // them from HBM anyway and reads that do not allocate in the caches are 4-8 % faster (4.63 -> 4.92 TB/s, 21 pairs at 5000 columns;
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) void sinkhorn_cols_kernel(const PairDesc* __re
 // LightGlue: row log-sum-exp + online column (max, sum) statistics in one pass (sigmoid_log_double_softmax)
 // ---------------------------------------------------------------------------------------------------------------
 
-template <int NCH>
+template <int NCH, bool NT = false>
 __global__ __launch_bounds__(256, 2) void lg_rows_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                          const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
                                                          float* __restrict__ rowvec, float* __restrict__ partials) {
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void lg_rows_kernel(const float* __restrict
             for (int e = 0; e < 4; ++e) {
                 const float t = (col + e < n) ? zz[c][e] : NEG;
                 zz[c][e] = t;
-                mx = fmaxf(mx, t);
+                mx = sw_max(mx, t);
             }
         }
         mx = wave_max(mx);
@@ -306,12 +314,15 @@ __global__ __launch_bounds__(256, 2) void lg_rows_kernel(const float* __restrict
             for (int e = 0; e < 4; ++e) {
                 const float t = zz[c][e];
                 s += sw_exp2((t - mx) * SW_LOG2E);
-                // online column statistics: the masked columns (t = -inf) keep (max, sum) = (-inf, 0)
-                const float nm = fmaxf(cm[c][e], t);
-                const float keep = (nm == NEG) ? 0.f : sw_exp2((cm[c][e] - nm) * SW_LOG2E);
-                const float add = (nm == NEG) ? 0.f : sw_exp2((t - nm) * SW_LOG2E);
-                cs[c][e] = cs[c][e] * keep + add;
-                cm[c][e] = nm;
+                // online column statistics with ONE exponential: of (old maximum - new maximum) and (t - new maximum) one is 0 and the other
+                // -|t - old maximum| (exp2(0) = 1 exactly: the same bits as two exponentials). The kernel is bound by the vector ALU, not by
+                // HBM -- three quarter-rate v_exp_f32 per element were 12 of its 29 issue slots per element. A masked column (t = -inf, maximum
+                // -inf) gets NaN here; columns >= n are never read.
+                const float d = t - cm[c][e];
+                const float ex = sw_exp2(-fabsf(d) * SW_LOG2E);
+                const bool up = d > 0.f;  // the column maximum moves to this row
+                cs[c][e] = cs[c][e] * (up ? ex : 1.f) + (up ? 1.f : ex);
+                cm[c][e] = sw_max(cm[c][e], t);
             }
         }
         s = wave_sum(s);
@@ -330,15 +341,15 @@ __global__ __launch_bounds__(256, 2) void lg_rows_kernel(const float* __restrict
     if (i < iend) {
         const int lastw = i + ((iend - 1 - i) & ~3);
         auto row_bytes = [&](int r) { return (unsigned)__builtin_amdgcn_readfirstlane(r < lastw ? r : lastw) * ldb; };
-        sw_load_slice_rsrc<NCH>(zres, row_bytes(i), voff, za);
+        sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i), voff, za);
 #pragma unroll 1
         for (;;) {
-            sw_load_slice_rsrc<NCH>(zres, row_bytes(i + 4), voff, zb);
+            sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i + 4), voff, zb);
             __builtin_amdgcn_sched_barrier(0);
             process(i, za);
             i += 4;
             if (i >= iend) break;
-            sw_load_slice_rsrc<NCH>(zres, row_bytes(i + 4), voff, za);
+            sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i + 4), voff, za);
             __builtin_amdgcn_sched_barrier(0);
             process(i, zb);
             i += 4;
@@ -730,7 +741,7 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_rows_wide_kernel(const float
     if (threadIdx.x == 0 && (n & 3) == 0) part[n] = acc_bin;  // ... or opens a float4 of its own
 }
 
-template <int NW, int NCH>
+template <int NW, int NCH, bool NT = false>
 __global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                                const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
                                                                float* __restrict__ rowvec, float* __restrict__ partials) {
@@ -763,7 +774,7 @@ __global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __re
             for (int e = 0; e < 4; ++e) {
                 const float t = (col + e < n) ? zz[c][e] : NEG;  // also what makes the clamped loads of sw_load_slice_rsrc harmless
                 zz[c][e] = t;
-                mw = fmaxf(mw, t);
+                mw = sw_max(mw, t);
             }
         }
         mw = wave_max(mw);
@@ -775,12 +786,15 @@ __global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __re
             for (int e = 0; e < 4; ++e) {
                 const float t = zz[c][e];
                 sw += sw_exp2((t - mref) * SW_LOG2E);
-                // online column statistics: the masked columns (t = -inf) keep (max, sum) = (-inf, 0)
-                const float nm = fmaxf(cm[c][e], t);
-                const float keep = (nm == NEG) ? 0.f : sw_exp2((cm[c][e] - nm) * SW_LOG2E);
-                const float add = (nm == NEG) ? 0.f : sw_exp2((t - nm) * SW_LOG2E);
-                cs[c][e] = cs[c][e] * keep + add;
-                cm[c][e] = nm;
+                // online column statistics with ONE exponential: of (old maximum - new maximum) and (t - new maximum) one is 0 and the other
+                // -|t - old maximum| (exp2(0) = 1 exactly: the same bits as two exponentials). The kernel is bound by the vector ALU, not by
+                // HBM -- three quarter-rate v_exp_f32 per element were 12 of its 29 issue slots per element. A masked column (t = -inf, maximum
+                // -inf) gets NaN here; columns >= n are never read.
+                const float d = t - cm[c][e];
+                const float ex = sw_exp2(-fabsf(d) * SW_LOG2E);
+                const bool up = d > 0.f;  // the column maximum moves to this row
+                cs[c][e] = cs[c][e] * (up ? ex : 1.f) + (up ? 1.f : ex);
+                cm[c][e] = sw_max(cm[c][e], t);
             }
         }
         sw = wave_sum(sw);
@@ -798,14 +812,14 @@ __global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __re
     }
     auto row_bytes = [&](int r) { return (unsigned)__builtin_amdgcn_readfirstlane(r < last ? r : last) * ldb; };
     int i = r0;
-    sw_load_slice_rsrc<NCH>(zres, row_bytes(i), voff, za);
+    sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i), voff, za);
 #pragma unroll 1
     for (;; i += 2) {
-        sw_load_slice_rsrc<NCH>(zres, row_bytes(i + 1), voff, zb);
+        sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i + 1), voff, zb);
         __builtin_amdgcn_sched_barrier(0);  // the next row's loads are issued BEFORE the wait for this row's (the scheduler puts them after)
         process(i, za);
         if (i + 1 >= rend) break;
-        sw_load_slice_rsrc<NCH>(zres, row_bytes(i + 2), voff, za);
+        sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i + 2), voff, za);
         __builtin_amdgcn_sched_barrier(0);
         process(i + 1, zb);
         if (i + 2 >= rend) break;
@@ -1076,10 +1090,17 @@ int launch_double_softmax_lse(const SweepArgs& a, hipStream_t stream) {
     if (a.npairs <= 0 || a.max_m <= 0 || a.max_n <= 0) return GTSFM_OK;
     if (!use_register_rows(a.max_n)) return launch_double_softmax_lse_lds(a, stream);
     const dim3 grid_rows(ceil_div(a.max_m, SW_ROWS), a.npairs), grid_cols(ceil_div(a.max_n, 256), a.npairs);
-#define SW_LAUNCH_LG(N) \
-    hipLaunchKernelGGL((lg_rows_kernel<N>), grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.partials)
-#define SW_LAUNCH_LG_WIDE(NW, N) \
-    hipLaunchKernelGGL((lg_rows_wide_kernel<NW, N>), grid_rows, dim3(64 * NW), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.partials)
+    // nontemporal score-matrix reads once the launch's matrices exceed the Infinity Cache: nothing of them survives until the extraction sweep
+    // anyway (see sw_zload; GTSFM_SWEEP_NT_MB as for the other sweeps; the same values are loaded)
+    const char* nt_env = getenv("GTSFM_SWEEP_NT_MB");
+    const bool nt = (double)a.npairs * a.max_m * a.max_n * 4.0 / (1024.0 * 1024.0) > (nt_env ? atof(nt_env) : 256.0);
+#define SW_LG_ARGS stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.partials
+#define SW_LAUNCH_LG(N)                                                                       \
+    if (nt) hipLaunchKernelGGL((lg_rows_kernel<N, true>), grid_rows, dim3(256), 0, SW_LG_ARGS); \
+    else hipLaunchKernelGGL((lg_rows_kernel<N, false>), grid_rows, dim3(256), 0, SW_LG_ARGS)
+#define SW_LAUNCH_LG_WIDE(NW, N)                                                                           \
+    if (nt) hipLaunchKernelGGL((lg_rows_wide_kernel<NW, N, true>), grid_rows, dim3(64 * NW), 0, SW_LG_ARGS); \
+    else hipLaunchKernelGGL((lg_rows_wide_kernel<NW, N, false>), grid_rows, dim3(64 * NW), 0, SW_LG_ARGS)
     if (a.max_n > SW_WIDE4_COLS) SW_DISPATCH_WIDE(8, wide_chunks_for(a.max_n, 8), SW_LAUNCH_LG_WIDE)
     if (a.max_n > SW_MAX_COLS) SW_DISPATCH_WIDE(4, wide_chunks_for(a.max_n, 4), SW_LAUNCH_LG_WIDE)
     SW_DISPATCH(chunks_for(a.max_n), SW_LAUNCH_LG)
