@@ -23,12 +23,16 @@
 // Score matrices wider than 2048 columns (GTSfM's 5000-keypoint cap, deep_front_end.yaml:29) do not fit one wave's
 // registers (20 float4 per lane x 4 buffers). They take the *_wide_kernel forms below: the 4 (or 8) waves of a
 // workgroup SHARE a row -- wave w owns the 256-column chunks w, w + NW, w + 2 NW, ... of every one of the block's 32 rows,
-// so its column statistics are complete without any cross-wave step, and a row costs ONE barrier: every wave publishes
+// so its column statistics are complete without any cross-wave step, and a Sinkhorn row costs ONE barrier: every wave publishes
 // the (max, sum) of its slice relative to its OWN maximum, and all waves combine the NW pairs in a fixed order
-// (exp(t - max) = exp(t - max_w) exp(max_w - max)). 5120 columns with 4 waves (round 3), 10240 with 8; beyond that the
+// (exp(t - max) = exp(t - max_w) exp(max_w - max)); the double log-softmax and the extraction need no barrier per row at all (the slices'
+// row statistics / candidates meet once per block). 5120 columns with 4 waves (round 3), 10240 with 8; beyond that the
 // LDS-staged kernels of matcher_kernels.hip. Which kernel a pair takes depends only on ITS OWN column count -- a batch wider
 // than 2048 launches every tier and the blocks of the other tiers' pairs return at once -- so results do not depend on the
 // batch a pair travels in. Built with -ffp-contract=off.
+// Every row kernel reads the matrix through a buffer resource with NO branch around a load (sw_load_slice_rsrc, round 5): with
+// `if (col < n) load` the compiler's wait-count pass cannot count loads in flight and every wait becomes s_waitcnt vmcnt(0) -- the row
+// prefetched for the next iteration is waited for together with the current one and the double buffering overlaps nothing.
 
 #include <stdlib.h>
 
@@ -1117,10 +1121,11 @@ int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogi
     // One wave per row up to SW_EXTRACT_NARROW_COLS = 1024 columns (4 register chunks), the waves of a workgroup share a row above: four up to
     // 5120 columns, eight up to 10240. Until round 5 one wave held rows of up to 2048 columns (8 chunks: 256 VGPRs + 81 .. 150 spilled to AGPRs,
     // 1.7 TB/s at N = 2048) and LightGlue took eight waves for every wider row (with a bounds BRANCH per element its four-wave form needed 256
-    // VGPRs + 44 spilled at GTSfM's cap). The branch-free row loop (poisoned column terms, selects) and the barrier-free wide kernel need 129 ..
-    // 234 VGPRs, nothing spilled; LightGlue, 16 pairs at the cap: 0.767 -> 0.49 ms. Arg-maxima do not depend on how a row is cut into slices,
-    // so -- unlike the Sinkhorn / double-softmax sweeps, whose sums do -- this launcher is free to choose; GTSFM_EXTRACT_WAVES=8 sends every
-    // row above 1024 columns to the eight-wave tier, =4 is the default.
+    // VGPRs + 44 spilled at GTSfM's cap). Round 5, in this order: a branch-free row loop (poisoned column terms, selects) and no barrier per row
+    // (0.767 -> 0.49 ms for LightGlue, 16 pairs at the cap); then no branch around any LOAD (sw_load_slice_rsrc: exact wait counts where every
+    // wait had been vmcnt(0)) with the column terms in LDS and three workgroups per CU (153 VGPRs): 0.49 -> 0.33 ms. Arg-maxima do not depend on
+    // how a row is cut into slices, so -- unlike the Sinkhorn / double-softmax sweeps, whose sums do -- this launcher is free to choose;
+    // GTSFM_EXTRACT_WAVES=8 sends every row above 1024 columns to the eight-wave tier, =4 is the default.
     const int narrow_max = max_cols_narrow_extract();
 #define SW_LAUNCH_EXTRACT_SG(N)                                                                                                         \
     hipLaunchKernelGGL((extract_rows_kernel<true, N>), grid_rows, dim3(256), 0, stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.colvec, \
