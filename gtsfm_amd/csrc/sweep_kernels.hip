@@ -91,14 +91,17 @@ __device__ __forceinline__ void sw_load_slice_rsrc(__amdgpu_buffer_rsrc_t z, uns
 }
 
 // The pair's score matrix as a buffer resource + the row pitch in bytes. Every piece goes through readfirstlane: a descriptor the compiler
-// cannot prove wave-uniform is read in a loop over the lanes' values around each load.
+// cannot prove wave-uniform is read in a loop over the lanes' values around each load. res_empty is the same resource with ZERO records: a load
+// through it is out of range, returns zeros and moves no data -- what the unconditional prefetch past a wave's last row (and of Sinkhorn's
+// synthetic dustbin row) reads; a scalar select between the two descriptors is not a branch around the load.
 #define SW_MAKE_ROW_RESOURCE(res, pitch, Zptr, mrows_, ld_)                                                                                  \
     const unsigned long long res##_addr = reinterpret_cast<unsigned long long>(Zptr);                                                        \
     float* const res##_uni = reinterpret_cast<float*>((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(res##_addr >> 32)) << 32 | \
                                                       (unsigned)__builtin_amdgcn_readfirstlane((int)res##_addr));                            \
     const unsigned pitch = (unsigned)__builtin_amdgcn_readfirstlane(ld_) * 4u;                                                               \
     const __amdgpu_buffer_rsrc_t res =                                                                                                       \
-        __builtin_amdgcn_make_buffer_rsrc(res##_uni, 0, (int)((unsigned)__builtin_amdgcn_readfirstlane(mrows_) * pitch), 0x00020000)
+        __builtin_amdgcn_make_buffer_rsrc(res##_uni, 0, (int)((unsigned)__builtin_amdgcn_readfirstlane(mrows_) * pitch), 0x00020000);        \
+    const __amdgpu_buffer_rsrc_t res##_empty = __builtin_amdgcn_make_buffer_rsrc(res##_uni, 0, 0, 0x00020000)
 
 // ---------------------------------------------------------------------------------------------------------------
 // SuperGlue: one Sinkhorn iteration = sinkhorn_rows_kernel + sinkhorn_cols_kernel
@@ -195,10 +198,10 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 2 : 3) void sinkhorn_rows_kernel(co
     int i = r0 + __builtin_amdgcn_readfirstlane(wave);
     if (i < iend) {
         const int lastw = i + ((iend - 1 - i) & ~3);
-        // the dustbin row (r = m) reads row m - 1 (m = 0: the resource is empty, zeros come back); process() puts bin_score in its place
+        // the dustbin row (r = m) and the prefetch past the wave's last row read nothing (zres_empty); process() puts bin_score in the former
         auto load = [&](int r, f32x4(&dst)[NCH]) {
-            const int rc = r < lastw ? r : lastw;
-            sw_load_slice_rsrc<NCH, NT>(zres, (unsigned)__builtin_amdgcn_readfirstlane(rc < m ? rc : m - 1) * ldb, voff, dst);
+            const bool real = __builtin_amdgcn_readfirstlane(r <= lastw && r < m);
+            sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)__builtin_amdgcn_readfirstlane(r) * ldb : 0u, voff, dst);
         };
         load(i, za);
 #pragma unroll 1
@@ -344,16 +347,20 @@ __global__ __launch_bounds__(256, 2) void lg_rows_kernel(const float* __restrict
     int i = r0 + __builtin_amdgcn_readfirstlane(wave);
     if (i < iend) {
         const int lastw = i + ((iend - 1 - i) & ~3);
-        auto row_bytes = [&](int r) { return (unsigned)__builtin_amdgcn_readfirstlane(r < lastw ? r : lastw) * ldb; };
-        sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i), voff, za);
+        // past the last row: nothing is read (zres_empty)
+        auto load = [&](int r, f32x4(&dst)[NCH]) {
+            const bool real = __builtin_amdgcn_readfirstlane(r <= lastw);
+            sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)__builtin_amdgcn_readfirstlane(r) * ldb : 0u, voff, dst);
+        };
+        load(i, za);
 #pragma unroll 1
         for (;;) {
-            sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i + 4), voff, zb);
+            load(i + 4, zb);
             __builtin_amdgcn_sched_barrier(0);
             process(i, za);
             i += 4;
             if (i >= iend) break;
-            sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i + 4), voff, za);
+            load(i + 4, za);
             __builtin_amdgcn_sched_barrier(0);
             process(i, zb);
             i += 4;
@@ -517,16 +524,20 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(con
     int i = r0 + __builtin_amdgcn_readfirstlane(wave);
     if (i < iend) {
         const int lastw = i + ((iend - 1 - i) & ~3);
-        auto row_bytes = [&](int r) { return (unsigned)__builtin_amdgcn_readfirstlane(r < lastw ? r : lastw) * ldb; };
-        sw_load_slice_rsrc<NCH>(zres, row_bytes(i), voff, za);
+        // past the last row: nothing is read (zres_empty)
+        auto load = [&](int r, f32x4(&dst)[NCH]) {
+            const bool real = __builtin_amdgcn_readfirstlane(r <= lastw);
+            sw_load_slice_rsrc<NCH>(real ? zres : zres_empty, real ? (unsigned)__builtin_amdgcn_readfirstlane(r) * ldb : 0u, voff, dst);
+        };
+        load(i, za);
 #pragma unroll 1
         for (;;) {
-            sw_load_slice_rsrc<NCH>(zres, row_bytes(i + 4), voff, zb);
+            load(i + 4, zb);
             __builtin_amdgcn_sched_barrier(0);
             process(i, za);
             i += 4;
             if (i >= iend) break;
-            sw_load_slice_rsrc<NCH>(zres, row_bytes(i + 4), voff, za);
+            load(i + 4, za);
             __builtin_amdgcn_sched_barrier(0);
             process(i, zb);
             i += 4;
@@ -710,10 +721,10 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_rows_wide_kernel(const float
     }
     // every load unconditional (past the block's last row the last row is read again: an L2 hit) so that the waits are exact counts -- see
     // sw_load_slice_rsrc
-    // the dustbin row (r = m) reads row m - 1 (m = 0: the resource is empty, zeros come back); process() puts bin_score in its place
+    // the dustbin row (r = m) and the prefetch past the block's last row read nothing (zres_empty); process() puts bin_score in the former
     auto load = [&](int r, f32x4(&dst)[NCH]) {
-        const int rc = r < last ? r : last;
-        sw_load_slice_rsrc<NCH, NT>(zres, (unsigned)__builtin_amdgcn_readfirstlane(rc < m ? rc : m - 1) * ldb, voff, dst);
+        const bool real = __builtin_amdgcn_readfirstlane(r <= last && r < m);
+        sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)__builtin_amdgcn_readfirstlane(r) * ldb : 0u, voff, dst);
     };
     int i = r0;
     load(i, za);
@@ -814,16 +825,20 @@ __global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __re
         const int col = 256 * (wave + NW * c) + 4 * lane;
         voff[c] = col < n ? 4 * col : 0;
     }
-    auto row_bytes = [&](int r) { return (unsigned)__builtin_amdgcn_readfirstlane(r < last ? r : last) * ldb; };
+    // past the last row: nothing is read (zres_empty)
+    auto load = [&](int r, f32x4(&dst)[NCH]) {
+        const bool real = __builtin_amdgcn_readfirstlane(r <= last);
+        sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)__builtin_amdgcn_readfirstlane(r) * ldb : 0u, voff, dst);
+    };
     int i = r0;
-    sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i), voff, za);
+    load(i, za);
 #pragma unroll 1
     for (;; i += 2) {
-        sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i + 1), voff, zb);
+        load(i + 1, zb);
         __builtin_amdgcn_sched_barrier(0);  // the next row's loads are issued BEFORE the wait for this row's (the scheduler puts them after)
         process(i, za);
         if (i + 1 >= rend) break;
-        sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i + 2), voff, za);
+        load(i + 2, za);
         __builtin_amdgcn_sched_barrier(0);
         process(i + 1, zb);
         if (i + 2 >= rend) break;
@@ -955,15 +970,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void extract_rows_wide_ke
         const int col = 256 * (wave + NW * c) + 4 * lane;
         voff[c] = col < n ? 4 * col : 0;
     }
-    auto row_bytes = [&](int r) { return (unsigned)__builtin_amdgcn_readfirstlane(r < last ? r : last) * ldb; };
+    // past the last row: nothing is read (zres_empty)
+    auto load = [&](int r, f32x4(&dst)[NCH]) {
+        const bool real = __builtin_amdgcn_readfirstlane(r <= last);
+        sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)__builtin_amdgcn_readfirstlane(r) * ldb : 0u, voff, dst);
+    };
     int i = r0;
-    sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i), voff, za);
+    load(i, za);
 #pragma unroll 1
     for (;; i += 2) {
-        sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i + 1), voff, zb);
+        load(i + 1, zb);
         process(i, za);
         if (i + 1 >= rend) break;
-        sw_load_slice_rsrc<NCH, NT>(zres, row_bytes(i + 2), voff, za);
+        load(i + 2, za);
         process(i + 1, zb);
         if (i + 2 >= rend) break;
     }

@@ -16,5 +16,8 @@ GTSFM_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 python bench.py
 for f in gpu_tests.txt smoke.txt; do echo "== $f"; tail -3 $OUT/$f; done
 for f in bench_default bench_scene_config4_cap5000 bench_scene_config4_cap5000_rccl_one_rank; do echo "== $f"; grep "^{" $OUT/$f.log | cut -c1-420; done
 grep real $OUT/bench_default.log
+python tools/bench_assign.py > $OUT/bench_assign.txt 2>&1
+python tools/bench_sweeps.py 1024 2048 5000:16 5000 5000:1 > $OUT/bench_sweeps.txt 2>&1
+grep -v "waves=8" $OUT/bench_assign.txt | cut -c1-200; cut -c1-260 $OUT/bench_sweeps.txt
 bash tools/prof_r05.sh > $OUT/prof.log 2>&1
 grep "^TRAFFIC\|^SQ" $OUT/prof.log | cut -c1-260

@@ -7,5 +7,5 @@ mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 timeout 1200 python -m pytest tests/test_matchers_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | tail -8 > $OUT/tests.txt
 timeout 600 python tools/bench_assign.py > $OUT/bench_assign.txt 2>&1
-timeout 600 python tools/bench_sweeps.py 1024 2048 5000 5000:1 > $OUT/bench_sweeps.txt 2>&1
-cat $OUT/tests.txt; cat $OUT/bench_assign.txt; cat $OUT/bench_sweeps.txt
+timeout 600 python tools/bench_sweeps.py 1024 2048 5000:16 5000 5000:1 > $OUT/bench_sweeps.txt 2>&1
+cat $OUT/tests.txt; grep -v "waves=8" $OUT/bench_assign.txt; cut -c1-250 $OUT/bench_sweeps.txt
