@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 2 : 3) void sinkhorn_rows_kernel(co
         const int lastw = i + ((iend - 1 - i) & ~3);
         // the dustbin row (r = m) and the prefetch past the wave's last row read nothing (zres_empty); process() puts bin_score in the former
         auto load = [&](int r, f32x4(&dst)[NCH]) {
-            const bool real = __builtin_amdgcn_readfirstlane(r <= lastw && r < m);
-            sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)__builtin_amdgcn_readfirstlane(r) * ldb : 0u, voff, dst);
+            const bool real = r <= lastw && r < m;  // wave-uniform by construction: a scalar compare
+            sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)r * ldb : 0u, voff, dst);
         };
         load(i, za);
 #pragma unroll 1
@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256, 2) void lg_rows_kernel(const float* __restrict
         const int lastw = i + ((iend - 1 - i) & ~3);
         // past the last row: nothing is read (zres_empty)
         auto load = [&](int r, f32x4(&dst)[NCH]) {
-            const bool real = __builtin_amdgcn_readfirstlane(r <= lastw);
-            sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)__builtin_amdgcn_readfirstlane(r) * ldb : 0u, voff, dst);
+            const bool real = r <= lastw;  // wave-uniform by construction: a scalar compare
+            sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)r * ldb : 0u, voff, dst);
         };
         load(i, za);
 #pragma unroll 1
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void lg_cols_kernel(const PairDesc* __restrict
 #define SW_NO_INDEX 0x7fffffff
 
 template <bool SG, int NCH>
-__global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
+__global__ __launch_bounds__(256, NCH >= 8 ? 1 : 3) void extract_rows_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                               const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
                                                               const float* __restrict__ rowvec, const float* __restrict__ colvec,
                                                               const float* __restrict__ zlogit, float* __restrict__ max0,
@@ -484,26 +484,26 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(con
         const float a_i = rowvec[vec0 + i];
         const float c_i = SG ? 0.f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ci_lane), __builtin_amdgcn_readfirstlane(i - r0)));
         float best = NEG;
-        int bidx = SW_NO_INDEX;
+        int bcode = -1;  // 4 * chunk + element of the lane's best value: inline constants instead of a register per column index
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int col = 4 * (lane + 64 * c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float val = assign_value<SG>(zz[c][e], a_i, bj[c][e], norm, c_i, cj[c][e]);  // -inf / NaN beyond column n: never selected
-                const bool row_better = val > best;  // columns ascend within a lane: the first maximum wins
+                const bool row_better = val > best;  // columns ascend with the code within a lane: the first maximum wins
                 best = row_better ? val : best;
-                bidx = row_better ? col + e : bidx;
+                bcode = row_better ? 4 * c + e : bcode;
                 const bool col_better = val > cbv[c][e];  // rows ascend within a wave
                 cbv[c][e] = col_better ? val : cbv[c][e];
                 cbi[c][e] = col_better ? i : cbi[c][e];
             }
         }
+        int bidx = bcode < 0 ? SW_NO_INDEX : 4 * (lane + 64 * (bcode >> 2)) + (bcode & 3);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const float ob = __shfl_xor(best, off, 64);
             const int oj = __shfl_xor(bidx, off, 64);
-            const bool take_ob = ob > best || (ob == best && oj < bidx);  // selects, not a branch
+            const bool take_ob = (ob > best) | ((ob == best) & (oj < bidx));  // bitwise: || and && compile to a branch per step
             best = take_ob ? ob : best;
             bidx = take_ob ? oj : bidx;
         }
@@ -526,8 +526,8 @@ __global__ __launch_bounds__(256, NCH >= 8 ? 1 : 2) void extract_rows_kernel(con
         const int lastw = i + ((iend - 1 - i) & ~3);
         // past the last row: nothing is read (zres_empty)
         auto load = [&](int r, f32x4(&dst)[NCH]) {
-            const bool real = __builtin_amdgcn_readfirstlane(r <= lastw);
-            sw_load_slice_rsrc<NCH>(real ? zres : zres_empty, real ? (unsigned)__builtin_amdgcn_readfirstlane(r) * ldb : 0u, voff, dst);
+            const bool real = r <= lastw;  // wave-uniform by construction: a scalar compare
+            sw_load_slice_rsrc<NCH>(real ? zres : zres_empty, real ? (unsigned)r * ldb : 0u, voff, dst);
         };
         load(i, za);
 #pragma unroll 1
@@ -723,8 +723,8 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_rows_wide_kernel(const float
     // sw_load_slice_rsrc
     // the dustbin row (r = m) and the prefetch past the block's last row read nothing (zres_empty); process() puts bin_score in the former
     auto load = [&](int r, f32x4(&dst)[NCH]) {
-        const bool real = __builtin_amdgcn_readfirstlane(r <= last && r < m);
-        sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)__builtin_amdgcn_readfirstlane(r) * ldb : 0u, voff, dst);
+        const bool real = r <= last && r < m;  // wave-uniform by construction: a scalar compare
+        sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)r * ldb : 0u, voff, dst);
     };
     int i = r0;
     load(i, za);
@@ -827,8 +827,8 @@ __global__ __launch_bounds__(64 * NW) void lg_rows_wide_kernel(const float* __re
     }
     // past the last row: nothing is read (zres_empty)
     auto load = [&](int r, f32x4(&dst)[NCH]) {
-        const bool real = __builtin_amdgcn_readfirstlane(r <= last);
-        sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)__builtin_amdgcn_readfirstlane(r) * ldb : 0u, voff, dst);
+        const bool real = r <= last;  // wave-uniform by construction: a scalar compare
+        sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)r * ldb : 0u, voff, dst);
     };
     int i = r0;
     load(i, za);
@@ -972,8 +972,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void extract_rows_wide_ke
     }
     // past the last row: nothing is read (zres_empty)
     auto load = [&](int r, f32x4(&dst)[NCH]) {
-        const bool real = __builtin_amdgcn_readfirstlane(r <= last);
-        sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)__builtin_amdgcn_readfirstlane(r) * ldb : 0u, voff, dst);
+        const bool real = r <= last;  // wave-uniform by construction: a scalar compare
+        sw_load_slice_rsrc<NCH, NT>(real ? zres : zres_empty, real ? (unsigned)r * ldb : 0u, voff, dst);
     };
     int i = r0;
     load(i, za);
