@@ -41,7 +41,7 @@ def _loop_statistics(assembly: str) -> dict:
         m = re.match(r"^(_Z\w+):", line)
         if m:
             name, in_loop = m.group(1), False
-            stats[name] = {"buffer_loads": 0, "other_loads": 0, "vmcnt0": 0, "vmcnt_exact": 0, "scratch": 0}
+            stats[name] = {"buffer_loads": 0, "other_loads": 0, "vmcnt0": 0, "vmcnt_exact": 0, "scratch": 0, "barriers": 0}
             continue
         if name is None:
             continue
@@ -60,6 +60,8 @@ def _loop_statistics(assembly: str) -> dict:
             stats[name]["other_loads"] += 1
         elif text.startswith("scratch_"):
             stats[name]["scratch"] += 1
+        elif text.startswith("s_barrier"):
+            stats[name]["barriers"] += 1
         wait = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", text)
         if wait:
             stats[name]["vmcnt0" if wait.group(1) == "0" else "vmcnt_exact"] += 1
@@ -77,6 +79,20 @@ def test_row_kernels_wait_with_exact_counts(assembly):
         assert s["vmcnt0"] == 0, f"{name}: s_waitcnt vmcnt(0) inside the row loop -- the prefetched row is waited for: {s}"
         assert s["vmcnt_exact"] >= 2, (name, s)
         assert s["scratch"] == 0, (name, s)
+
+
+def test_only_sinkhorn_meets_at_a_barrier_per_row(assembly):
+    """The waves of a wide-tier workgroup share a row. Sinkhorn needs the row's log-sum-exp over all slices before its column accumulation: one
+    barrier per row (two in the loop body, which handles two rows). The double log-softmax and the extraction do not: their slices' per-row
+    results meet once per 32-row block, after the loop (a barrier per row made every wave wait for the slowest wave's loads of every row)."""
+    stats = _loop_statistics(assembly)
+    for name, s in stats.items():
+        if re.search(r"(lg|extract)_rows_wide_kernel", name):
+            assert s["barriers"] == 0, (name, s)
+        elif re.search(r"sinkhorn_rows_wide_kernel", name):
+            assert s["barriers"] == 2, (name, s)
+        elif re.search(r"(sinkhorn|lg|extract)_rows_kernel", name):  # one wave per row: nothing to meet for
+            assert s["barriers"] == 0, (name, s)
 
 
 def test_cap_kernels_fit_three_workgroups_per_cu(assembly):
