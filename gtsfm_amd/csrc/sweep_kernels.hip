@@ -56,23 +56,10 @@ __device__ __forceinline__ float sw_max(float a, float b) {
     return r;
 }
 
-// Score-matrix reads. NT = nontemporal: when the matrices of one launch together exceed the 256 MiB Infinity Cache, every sweep streams
-// them from HBM anyway and reads that do not allocate in the caches are 4-8 % faster (4.63 -> 4.92 TB/s, 21 pairs at 5000 columns;
-// 4.87 -> 5.18 at 2048, 32 pairs); when they fit (1-2 pairs at the cap, <= 15 at 2048) the plain reads hit the cache on the next
+// Score-matrix reads are nontemporal (NT: aux bit 1 of the buffer load) when the matrices of one launch together exceed the 256 MiB Infinity
+// Cache: every sweep streams them from HBM anyway and reads that do not allocate in the caches are 4-8 % faster (4.63 -> 4.92 TB/s, 21 pairs at
+// 5000 columns; 4.87 -> 5.18 at 2048, 32 pairs); when they fit (1-2 pairs at the cap, <= 15 at 2048) the plain reads hit the cache on the next
 // sweep and NT costs 11 %. The launcher chooses (speed only: the same values are loaded).
-template <bool NT>
-__device__ __forceinline__ f32x4 sw_zload(const float* ptr) {
-    return NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr)) : *reinterpret_cast<const f32x4*>(ptr);
-}
-
-template <int NCH, bool NT = false>
-__device__ __forceinline__ void sw_load_row(const float* __restrict__ zr, int n, int lane, f32x4 (&dst)[NCH]) {
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int col = 4 * (lane + 64 * c);
-        if (col < n) dst[c] = sw_zload<NT>(zr + col);  // col < n implies col + 3 < ld (ld = n rounded up to 4)
-    }
-}
 
 // A row (or a wave's slice of it) through a buffer resource, with NO branch around any load and ONE 32-bit register of address per chunk: the pair's matrix is
 // the resource, the row's byte offset rides in a scalar register, the lane's column offset (loop-invariant) in voff[c]. A chunk at or beyond
@@ -615,15 +602,6 @@ __device__ __forceinline__ bool sw_wide_tier(int n) {
     return NW == 4 ? (n > SW_MAX_COLS && n <= SW_WIDE4_COLS) : (n > SW_WIDE4_COLS && n <= SW_WIDE8_COLS);
 }
 
-template <int NW, int NCH, bool NT = false>
-__device__ __forceinline__ void sw_load_slice(const float* __restrict__ zr, int n, int wave, int lane, f32x4 (&dst)[NCH]) {
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int col = 256 * (wave + NW * c) + 4 * lane;
-        if (col < n) dst[c] = sw_zload<NT>(zr + col);
-    }
-}
-
 template <int NW, int NCH, bool NT>
 __global__ __launch_bounds__(64 * NW) void sinkhorn_rows_wide_kernel(const float* __restrict__ zbuf, const PairDesc* __restrict__ pairs,
                                                                      const SeqDesc* __restrict__ seqs, const int* __restrict__ counts,
@@ -1083,7 +1061,7 @@ int launch_sinkhorn(const SweepArgs& a, float bin_score, int iters, hipStream_t 
         group = group < 1 ? 1 : (group > a.npairs ? a.npairs : group);
     }
     const int nch = chunks_for(a.max_n);
-    // nontemporal score-matrix reads once the launch's matrices cannot stay in the Infinity Cache between sweeps (see sw_zload)
+    // nontemporal score-matrix reads once the launch's matrices cannot stay in the Infinity Cache between sweeps (see sw_load_slice_rsrc)
     const char* nt_env = getenv("GTSFM_SWEEP_NT_MB");  // read per call (tests switch it)
     const double nt_mb = nt_env ? atof(nt_env) : 256.0;
     for (int pair0 = 0; pair0 < a.npairs; pair0 += group) {
@@ -1114,7 +1092,7 @@ int launch_double_softmax_lse(const SweepArgs& a, hipStream_t stream) {
     if (!use_register_rows(a.max_n)) return launch_double_softmax_lse_lds(a, stream);
     const dim3 grid_rows(ceil_div(a.max_m, SW_ROWS), a.npairs), grid_cols(ceil_div(a.max_n, 256), a.npairs);
     // nontemporal score-matrix reads once the launch's matrices exceed the Infinity Cache: nothing of them survives until the extraction sweep
-    // anyway (see sw_zload; GTSFM_SWEEP_NT_MB as for the other sweeps; the same values are loaded)
+    // anyway (see sw_load_slice_rsrc; GTSFM_SWEEP_NT_MB as for the other sweeps; the same values are loaded)
     const char* nt_env = getenv("GTSFM_SWEEP_NT_MB");
     const bool nt = (double)a.npairs * a.max_m * a.max_n * 4.0 / (1024.0 * 1024.0) > (nt_env ? atof(nt_env) : 256.0);
 #define SW_LG_ARGS stream, a.zbuf, a.pairs, a.seqs, a.counts, a.rowvec, a.partials
@@ -1160,7 +1138,7 @@ int launch_extract_matches(const SweepArgs& a, int superglue, const float* zlogi
     if (nt) hipLaunchKernelGGL((extract_rows_wide_kernel<false, NW, N, true>), SW_EXTRACT_WIDE_ARGS(NW)); \
     else hipLaunchKernelGGL((extract_rows_wide_kernel<false, NW, N, false>), SW_EXTRACT_WIDE_ARGS(NW))
     // the extraction is the LAST reader of the matrices: once the launch's matrices exceed the Infinity Cache, nontemporal reads (same values)
-    // leave it to data somebody will read again (see sw_zload; GTSFM_SWEEP_NT_MB as for the Sinkhorn sweeps)
+    // leave it to data somebody will read again (see sw_load_slice_rsrc; GTSFM_SWEEP_NT_MB as for the Sinkhorn sweeps)
     const char* nt_env = getenv("GTSFM_SWEEP_NT_MB");
     const bool nt = (double)a.npairs * a.max_m * a.max_n * 4.0 / (1024.0 * 1024.0) > (nt_env ? atof(nt_env) : 256.0);
     const char* ew_env = getenv("GTSFM_EXTRACT_WAVES");
