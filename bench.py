@@ -512,6 +512,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the per-kernel roofline micro-launches (for rocprofv3 --kernel-trace runs whose stats should hold the workload's launches only)")
+    ap.add_argument("--details-file", default=DETAILS_FILE,
+                    help="where the full record goes (secondary legs, every kernel's roofline, notes); stdout carries only the < 4 KB headline line. '' = nowhere")
     ap.add_argument("--dump-matches", type=int, default=0, help="1: add match_digest (SHA-1 over the last step's (K,2) match arrays in pair order) to the line")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help='"nccl" = RCCL; "gloo" only with --plumbing-only')
     ap.add_argument("--plumbing-only", action="store_true",
@@ -570,6 +572,99 @@ def matches_to_numpy(results):
 
     return FrontEndPipeline.matches_to_numpy(results)
 
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The printed line: a headline a driver can read (< 4 KB, the LAST and only stdout line); everything else goes to a side file
+# ------------------------------------------------------------------------------------------------------------------
+
+HEADLINE_BYTES = 4000  # the driver keeps an 8 KB tail of stdout + stderr: a 21 KB line (round 5) left it nothing to parse
+DETAILS_FILE = "gpurun_out/bench_details.json"
+_HEADLINE_ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "avg_iteration_ms", "launch_shape")
+
+
+def _brief_roofline(r: dict) -> dict:
+    out = {k: r[k] for k in _HEADLINE_ROOFLINE_KEYS if k in r}
+    note = (r.get("traffic_note") or "").lower()
+    if r.get("traffic") is not None:  # what the PMC byte count is per (the full note with its counter file is in the details file)
+        out["traffic_per"] = next((unit for unit in ("image", "iteration", "pass") if f"per {unit}" in note), "launch")
+    return out
+
+
+def _brief_secondary(sec: dict) -> dict:
+    """name -> rate of every secondary leg (the legs themselves, with their workloads, parity checks and CPU baselines, are in the details file)."""
+    out = {}
+    for name, leg in sec.items():
+        if not isinstance(leg, dict):
+            continue
+        if "error" in leg:
+            out[name] = "error"
+        elif "value" in leg:
+            out[name] = leg["value"]
+        else:  # a group of rates (secondary_rates returns {name: {value, ...}})
+            for sub, subleg in leg.items():
+                if isinstance(subleg, dict) and "value" in subleg:
+                    out[sub] = subleg["value"]
+    return out
+
+
+def headline_of(result: dict, details_path) -> dict:
+    """The object the driver parses: metric / value / unit / n_gpus / steps / warmup / ms_per_step / dtype / config / roofline / cpu_baseline /
+    parity_check, at most three of the other kernels' rooflines (the conv stack, the largest projection GEMM and whichever kernel sits furthest
+    below its roof), and the secondary legs as bare rates. Fields are dropped from the end of that list until the line fits HEADLINE_BYTES."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "algorithmic_tflops", "executed_tflops", "step_frac_of_fp32_mfma_peak", "plumbing_only", "match_digest", "scene_check", "exchange", "distributed")
+    head = {k: result[k] for k in keep if k in result}
+    if "roofline" in result:
+        head["roofline"] = _brief_roofline(result["roofline"])
+        if result["roofline"].get("flops_per_launch") is not None:
+            head["roofline"]["flops_per_launch"] = result["roofline"]["flops_per_launch"]
+    if "cpu_baseline" in result:
+        head["cpu_baseline"] = {k: v for k, v in result["cpu_baseline"].items() if k != "reference_run"}
+    if "parity_check" in result:
+        head["parity_check"] = result["parity_check"]
+    optional = []
+    other = [r for r in result.get("roofline_other", []) if isinstance(r, dict) and "frac" in r]
+    if other:
+        picked = []
+        for want in ("conv3x3_mfma_kernel", "gemm_dma_walk_kernel"):
+            hit = next((r for r in other if r.get("kernel") == want), None)
+            if hit is not None:
+                picked.append(hit)
+        rest = [r for r in other if not any(r is q for q in picked)]
+        if rest:
+            picked.append(min(rest, key=lambda r: r["frac"]))
+        optional.append(("roofline_other", [_brief_roofline(r) for r in picked[:3]]))
+    if isinstance(result.get("secondary"), dict):
+        optional.append(("secondary_rates", _brief_secondary(result["secondary"])))
+    if details_path is not None:
+        head["details"] = str(details_path)
+    for key, val in optional:
+        head[key] = val
+    droppable = [k for k, _ in reversed(optional)] + ["exchange", "distributed", "scene_check", "parity_check"]
+    while len(json.dumps(head)) > HEADLINE_BYTES and droppable:
+        head.pop(droppable.pop(0), None)
+    if len(json.dumps(head)) > HEADLINE_BYTES:  # the config strings are the only thing left that can grow
+        head["config"] = {k: (v if not isinstance(v, str) or len(v) <= 120 else v[:117] + "...") for k, v in head["config"].items()}
+    return head
+
+
+def emit(result: dict, details_file: str) -> str:
+    """Write the full record (every leg, every roofline, the notes) to `details_file` and return the headline line for stdout."""
+    path = None
+    if details_file:
+        path = Path(details_file)
+        path = path if path.is_absolute() else REPO / path
+        try:
+            path.parent.mkdir(parents=True, exist_ok=True)
+            path.write_text(json.dumps(result, indent=1) + "\n")
+            path = path.relative_to(REPO) if path.is_relative_to(REPO) else path
+        except OSError as exc:  # a read-only tree must not cost the run its headline
+            print(f"bench.py: could not write {path}: {exc}", file=sys.stderr)
+            path = None
+    line = json.dumps(headline_of(result, path))
+    assert len(line) <= HEADLINE_BYTES, len(line)
+    return line
 
 # ------------------------------------------------------------------------------------------------------------------
 
@@ -784,10 +879,6 @@ def main() -> None:
         }
         if not detect_only and not plumbing:
             result["step_frac_of_fp32_mfma_peak"] = round(flops_step / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
-            result["step_note"] = ("algorithmic FLOP/s of the WHOLE step over the fp32 MFMA peak (the `roofline` object is the dominant kernel alone). At the 5000-keypoint cap the "
-                                   "step is ~77 % attention (0.84 of peak), ~19 % projection / FFN / score GEMMs (0.77 - 0.82; a build without any GEMM epilogue bounds what "
-                                   "is left there at 5 % of the GEMM time = 0.9 % of the step), ~4 % everything else; under load the clock sits at 2.1 - 2.2 of the nominal "
-                                   "2.4 GHz the peak is quoted at (DESIGN.md sections 6 and 8)")
         if args.dump_matches:
             import hashlib
 
@@ -883,7 +974,7 @@ def main() -> None:
                     result["secondary"]["config4_scene_share_cap5000"] = leg("config4", config4_scene_share_rate, args, detector, device, h, w, not args.no_cpu_baseline)
                     result["secondary"]["config4_scene_share_cap5000_bf16x3"] = leg("config4_bf16x3", config4_scene_share_rate, args, detector, device, h, w,
                                                                                             not args.no_cpu_baseline, "bf16x3")
-        print(json.dumps(result), flush=True)
+        print(emit(result, args.details_file), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

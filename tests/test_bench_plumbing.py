@@ -21,6 +21,8 @@ def _run_bench(*flags, env=None):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         e.pop(k, None)
     e.update(env or {})
+    if "--details-file" not in flags:  # the tests' stand-in runs must not overwrite a measured run's record under gpurun_out/
+        flags = (*flags, "--details-file", "")
     p = subprocess.run([sys.executable, str(REPO / "bench.py"), *flags], capture_output=True, text=True, timeout=600, env=e, cwd=str(REPO))
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     return p, lines
@@ -118,6 +120,36 @@ def test_default_workload_helpers():
     assert (args.pairs, args.images, args.pair_chunk) == (1000, 46, 32)
     args = bench.parse_args(["--mode", "scene"])
     assert (args.pairs, args.images, args.matcher) == (5000, 101, "superglue")
+
+
+def test_the_printed_line_is_one_the_driver_can_read(tmp_path):
+    """Round 5's line was 21.6 KB and the driver's 8 KB tail held no parseable object. The contract now: stdout's LAST
+    and only JSON line is under 4 KB; the full record goes to --details-file. Checked on a stand-in run and on round 5's own full record."""
+    import bench
+
+    side = tmp_path / "details.json"
+    p, lines = _run_bench("--plumbing-only", "--images", "5", "--pairs", "8", "--steps", "1", "--warmup", "0", "--details-file", str(side))
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = p.stdout.strip().splitlines()
+    assert len(lines) == 1 and out[-1] == lines[0] and len(out[-1]) < 4096
+    head = json.loads(out[-1])
+    full = json.loads(side.read_text())
+    assert head["details"] == str(side) and full["value"] == head["value"] and full["config"] == head["config"]
+    # a full run's record (round 5's, 21.6 KB): the headline keeps what the driver parses and drops the bulk
+    recorded = json.loads((REPO / "profiles" / "r05_final_bench_default.json").read_text())
+    line = json.dumps(bench.headline_of(recorded, bench.DETAILS_FILE))
+    assert len(line) < 4096 < len(json.dumps(recorded))
+    head = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline", "parity_check"):
+        assert key in head, key
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(head["roofline"]) and head["roofline"]["frac"] == recorded["roofline"]["frac"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(head["cpu_baseline"])
+    assert len(head["roofline_other"]) <= 3 and "secondary" not in head and "step_note" not in head
+    assert head["secondary_rates"]["config2_superpoint_480x640"] == recorded["secondary"]["config2_superpoint_480x640"]["value"]
+    # a record that still would not fit sheds its optional fields rather than its headline
+    bloated = dict(recorded, secondary={f"leg{i}": {"value": float(i), "note": "x" * 50} for i in range(400)})
+    shrunk = json.loads(json.dumps(bench.headline_of(bloated, bench.DETAILS_FILE)))
+    assert len(json.dumps(shrunk)) <= bench.HEADLINE_BYTES and "roofline" in shrunk and "cpu_baseline" in shrunk and "secondary_rates" not in shrunk
 
 
 def test_recorded_bench_line_is_hygienic():
