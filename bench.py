@@ -693,10 +693,15 @@ def main() -> None:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        import datetime
+
+        # a rank that never arrives fails its peers after this long instead of blocking them for good (rank 0's roofline / CPU legs run after
+        # the timed region and take minutes at N = 1 only; at N > 1 the other ranks wait for it in the closing barrier for well under this)
+        timeout = datetime.timedelta(minutes=30)
         if plumbing:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timeout)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=device)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=device, timeout=timeout)
 
     from gtsfm_amd import parallel
 

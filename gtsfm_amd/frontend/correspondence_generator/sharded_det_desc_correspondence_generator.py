@@ -87,6 +87,7 @@ class ShardedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         pipeline_factory: Optional[Callable[..., Any]] = None,
         pipeline_options: Optional[Dict[str, Any]] = None,
         always_launch: bool = False,
+        collective_timeout_s: float = 600.0,
     ) -> None:
         """``num_gpus``: ranks to start in launcher mode (None = every visible GPU); ignored when the caller is already part of a process
         group. ``pair_batch``: pairs per matcher launch sequence (0 = by keypoint count: 32 up to 2560 keypoints, 16 at the 5000 cap).
@@ -94,7 +95,9 @@ class ShardedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         ``pipeline_factory(generator, device) -> pipeline``: replaces the HIP pipeline (CPU plumbing tests with stand-in kernels; must be
         a picklable top-level callable in launcher mode); the plugins' models are then never built and no weights are broadcast.
         ``always_launch``: start rank processes even for one GPU (keeps the calling process free of device state; also how the launcher path
-        is exercised on a one-GPU box)."""
+        is exercised on a one-GPU box). ``collective_timeout_s``: process-group timeout of launcher mode -- a rank that never arrives at a
+        collective fails its peers after this long instead of blocking them for good (the reference's counterpart is the connect-retry
+        loop of ``gtsfm/runner.py:313-357``)."""
         if pipeline_factory is None:
             if not isinstance(detector_descriptor, SuperPointDetectorDescriptor):
                 raise TypeError("ShardedDetDescCorrespondenceGenerator needs gtsfm_amd's SuperPointDetectorDescriptor")
@@ -109,6 +112,7 @@ class ShardedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         self._pipeline_factory = pipeline_factory
         self._pipeline_options = dict(pipeline_options or {})
         self._always_launch = bool(always_launch)
+        self._collective_timeout_s = float(collective_timeout_s)
         self._pipe = None  # per process: FrontEndPipeline over this rank's engines
         self._pool = None  # launcher mode: the rank processes
         self.last_scene: Optional[SceneResult] = None
@@ -195,8 +199,13 @@ class ShardedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         counts = table["count"].cpu().numpy().astype(np.int64)
         table_shapes = [tuple(shapes[i]) for i in plan.table_images]
         todo = [(p, q) for p, q in zip(plan.my_pairs, plan.local_pairs) if counts[q[0]] > 0 and counts[q[1]] > 0]
-        results = pipe.match(table, [q for _, q in todo], table_shapes, counts=counts, **matcher_kwargs) if todo else []
-        local = pipe.matches_to_numpy(results) if results else {}
+        results, local, failure = [], {}, None
+        try:
+            results = pipe.match(table, [q for _, q in todo], table_shapes, counts=counts, **matcher_kwargs) if todo else []
+            local = pipe.matches_to_numpy(results) if results else {}
+        except Exception as exc:  # noqa: BLE001 - every rank must learn of it BEFORE the gather below, or the healthy ones block in it
+            failure = exc
+        parallel.agree_or_raise(failure, "matching")
         mine = {p: local[q] for p, q in todo}
         for p in plan.my_pairs:
             mine.setdefault(p, np.zeros((0, 2), dtype=np.int64))
@@ -223,7 +232,18 @@ class ShardedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         """Steps 2 - 5 for this rank's views already in HBM: ``local_images`` [s,H,W] uint8 / float32 on the device, row s = image
         ``partition_images(num_images, rank, world)[s]``. The timed step of ``bench.py --mode scene``."""
         pipe = self.attach()
-        return self.run_scene(pipe.detect(local_images), num_images, shapes, pairs, **matcher_kwargs)
+        return self.run_scene(self._agreed("detection", pipe.detect, local_images), num_images, shapes, pairs, **matcher_kwargs)
+
+    @staticmethod
+    def _agreed(phase: str, fn, *args):
+        """``fn(*args)`` as one phase of a sharded scene: the ranks agree that nobody failed before anyone enters the next collective."""
+        out = failure = None
+        try:
+            out = fn(*args)
+        except Exception as exc:  # noqa: BLE001
+            failure = exc
+        parallel.agree_or_raise(failure, phase)
+        return out
 
     # -- the generator contract ------------------------------------------------------------------------------------------------------
 
@@ -234,7 +254,11 @@ class ShardedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         rank, world = parallel.world_info()
         if parallel._dist() is None and (self._world_to_launch() > 1 or self._always_launch):
             imgs = BatchedDetDescCorrespondenceGenerator._resolve(client, images)
-            return self._launcher().run(imgs, pairs)
+            try:
+                return self._launcher().run(imgs, pairs)
+            except RuntimeError:  # the pool has been torn down (every rank terminated); the next call starts a new one
+                self._pool = None
+                raise
         imgs = BatchedDetDescCorrespondenceGenerator._resolve(client, images)
         shapes = [(int(im.height), int(im.width)) for im in imgs]
         mine = {i: imgs[i] for i in parallel.partition_images(len(imgs), rank, world)}
@@ -253,7 +277,7 @@ class ShardedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
         rank, world = parallel.world_info()
         n = len(shapes)
         order = parallel.partition_images(n, rank, world)
-        local = pipe.detect_image_objects([my_images[i] for i in order], self._image_batch)
+        local = self._agreed("detection", pipe.detect_image_objects, [my_images[i] for i in order], self._image_batch)
         dtype, kwargs = match_output_convention(self._matcher) if self._pipeline_factory is None else (np.int64, {})
         scene = self.run_scene(local, n, shapes, pairs, **kwargs)
         # every image's keypoints for the caller: count / xy / scores all-gathered (60 KB per image; the descriptors stay where they are)
@@ -270,7 +294,7 @@ class ShardedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
 
     def _launcher(self) -> "_RankPool":
         if self._pool is None:
-            self._pool = _RankPool(self, self._world_to_launch(), self._backend)
+            self._pool = _RankPool(self, self._world_to_launch(), self._backend, self._collective_timeout_s)
         return self._pool
 
     def close(self) -> None:
@@ -280,69 +304,104 @@ class ShardedDetDescCorrespondenceGenerator(CorrespondenceGeneratorBase):
             self._pool = None
 
 
-def _rank_main(rank: int, world: int, port: int, backend: str, generator: ShardedDetDescCorrespondenceGenerator, tasks, results) -> None:
-    """One rank process of launcher mode: joins the process group (RCCL: one GPU per rank), then serves scenes until told to stop."""
+def _rank_main(rank: int, world: int, port: int, backend: str, timeout_s: float, generator: ShardedDetDescCorrespondenceGenerator, tasks, results) -> None:
+    """One rank process of launcher mode: joins the process group (RCCL: one GPU per rank), then serves scenes until told to stop.
+
+    Failure handling: a scene that raises is reported to the parent at once and the process leaves WITHOUT ``destroy_process_group`` (which
+    can itself wait for peers that sit in a collective); the parent then terminates every rank (``_RankPool._kill_now``). Between the
+    phases of a scene the ranks agree that nobody failed (``parallel.agree_or_raise``), so a peer's failure normally surfaces as an
+    exception on every rank; what that cannot catch -- a rank killed from outside, a fault inside a collective -- ends at the
+    process-group timeout (``timeout_s``) or at the parent's liveness check, whichever comes first."""
+    import datetime
+
     import torch
     import torch.distributed as dist
+
+    def report_and_leave(kind: str, payload) -> None:
+        results.put((kind, rank, payload))
+        results.close()
+        results.join_thread()  # the message is on the pipe before the process goes
+        os._exit(1)
 
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes of one node
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")  # a collective that times out tears the process down instead of hanging it
+        timeout = datetime.timedelta(seconds=timeout_s)
         if backend == "nccl":
             torch.cuda.set_device(rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank), timeout=timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-        results.put(("ready", rank, None))
-        while True:
-            task = tasks.get()
-            if task is None:
-                break
-            my_images, shapes, pairs = task
-            try:
-                out = generator._generate_on_this_rank(my_images, shapes, pairs)
-                if rank == 0:
-                    results.put(("done", rank, out))
-            except Exception:  # noqa: BLE001 - reported to the parent, which tears the pool down
-                results.put(("error", rank, traceback.format_exc()))
-                break
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
     except Exception:  # noqa: BLE001
-        results.put(("error", rank, traceback.format_exc()))
-    finally:
+        report_and_leave("start_error", traceback.format_exc())
+    results.put(("ready", rank, None))
+    while True:
+        task = tasks.get()
+        if task is None:
+            break
+        my_images, shapes, pairs = task
         try:
-            if dist.is_initialized():
-                dist.destroy_process_group()
-        except Exception:  # noqa: BLE001
-            pass
+            out = generator._generate_on_this_rank(my_images, shapes, pairs)
+        except parallel.PeerRankFailed as exc:  # the rank that failed sends its own traceback; this one only confirms it left the scene
+            report_and_leave("peer_error", str(exc))
+        except Exception:  # noqa: BLE001 - reported to the parent, which tears the pool down
+            report_and_leave("error", traceback.format_exc())
+        if rank == 0:
+            results.put(("done", rank, out))
+    try:
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
 
 
 class _RankPool:
     """The rank processes of launcher mode: started once ("spawn": a fresh interpreter per GPU, no inherited device state), fed one scene
-    at a time. Each rank receives only its own share of the images (cyclic ownership); rank 0 returns the result."""
+    at a time. Each rank receives only its own share of the images (cyclic ownership); rank 0 returns the result. Any failure -- a rank
+    reports an exception, a rank process dies, nobody answers in time -- terminates ALL rank processes at once (peers of a failed rank may
+    sit in a collective that will never complete) and raises ``RuntimeError`` in the caller; the generator starts a new pool on its next call."""
 
     START_TIMEOUT_S = 600.0
+    START_ATTEMPTS = 3  # the rendezvous port is picked by binding port 0 and closing the socket: somebody else may take it before rank 0 binds
 
-    def __init__(self, generator: ShardedDetDescCorrespondenceGenerator, world: int, backend: str):
+    def __init__(self, generator: ShardedDetDescCorrespondenceGenerator, world: int, backend: str, collective_timeout_s: float = 600.0):
         import multiprocessing as mp
 
-        ctx = mp.get_context("spawn")
+        self._ctx = mp.get_context("spawn")
         self.world = world
+        self._procs, self._tasks, self._results = [], [], None
+        self._finalizer = None
+        for attempt in range(self.START_ATTEMPTS):
+            failure = self._start(generator, backend, collective_timeout_s)
+            if failure is None:
+                return
+            self._kill_now(self._procs, self._results)
+            rank, payload = failure
+            in_use = "EADDRINUSE" in payload or "address already in use" in payload.lower()
+            if not in_use or attempt == self.START_ATTEMPTS - 1:
+                raise RuntimeError(f"sharded generator: rank {rank} failed to start\n{payload}")
+
+    def _start(self, generator, backend: str, collective_timeout_s: float):
+        """Start the rank processes on a fresh port; None when all of them joined the process group, else (rank, what it said)."""
+        ctx = self._ctx
         self._results = ctx.Queue()
-        self._tasks = [ctx.Queue() for _ in range(world)]
+        self._tasks = [ctx.Queue() for _ in range(self.world)]
         port = _free_port()
-        self._procs = [ctx.Process(target=_rank_main, args=(r, world, port, backend, generator, self._tasks[r], self._results), daemon=True)
-                       for r in range(world)]
+        self._procs = [ctx.Process(target=_rank_main, args=(r, self.world, port, backend, collective_timeout_s, generator, self._tasks[r], self._results),
+                                   daemon=True) for r in range(self.world)]
         for p in self._procs:
             p.start()
-        self._finalizer = weakref.finalize(self, _RankPool._shutdown, self._procs, self._tasks)
+        if self._finalizer is not None:
+            atexit.unregister(self._finalizer)
+        self._finalizer = weakref.finalize(self, _RankPool._shutdown, self._procs, self._tasks, self._results)
         atexit.register(self._finalizer)
         ready = 0
-        while ready < world:
+        while ready < self.world:
             kind, rank, payload = self._get(self.START_TIMEOUT_S)
-            if kind == "error":
-                self.close()
-                raise RuntimeError(f"sharded generator: rank {rank} failed to start\n{payload}")
-            ready += kind == "ready"
+            if kind != "ready":
+                return rank, str(payload)
+            ready += 1
+        return None
 
     def _get(self, timeout: float):
         import queue
@@ -355,7 +414,10 @@ class _RankPool:
                 waited += 1.0
                 dead = [r for r, p in enumerate(self._procs) if not p.is_alive() and p.exitcode not in (0, None)]
                 if dead:
-                    return ("error", dead[0], f"rank process exited with code {self._procs[dead[0]].exitcode}")
+                    try:  # its last words may still be on the pipe
+                        return self._results.get(timeout=0.5)
+                    except queue.Empty:
+                        return ("error", dead[0], f"rank process exited with code {self._procs[dead[0]].exitcode}")
                 if waited >= timeout:
                     return ("error", -1, f"no answer from the rank processes within {timeout:.0f} s")
 
@@ -364,13 +426,44 @@ class _RankPool:
         for r in range(self.world):
             self._tasks[r].put(({i: imgs[i] for i in parallel.partition_images(len(imgs), r, self.world)}, shapes, pairs))
         kind, rank, payload = self._get(timeout)
+        if kind == "peer_error":  # a healthy rank left because a peer failed: the peer's own traceback is on its way (or its process is gone)
+            import time
+
+            first, deadline = (kind, rank, payload), time.monotonic() + 10.0
+            while kind == "peer_error" and time.monotonic() < deadline:
+                kind, rank, payload = self._get(max(1.0, deadline - time.monotonic()))
+            if kind != "error" or rank == -1:
+                kind, rank, payload = first
         if kind != "done":
-            self.close()
-            raise RuntimeError(f"sharded generator: rank {rank} failed\n{payload}")
+            # a rank that was killed from outside says nothing; what its peers report is a broken collective. Name the processes that are gone.
+            gone = [f"rank {r} exit code {p.exitcode}" for r, p in enumerate(self._procs) if not p.is_alive() and p.exitcode not in (0, 1, None)]
+            self.close(graceful=False)
+            raise RuntimeError(f"sharded generator: rank {rank} failed" + (f" (rank processes already gone: {', '.join(gone)})" if gone else "") + f"\n{payload}")
         return payload
 
     @staticmethod
-    def _shutdown(procs, tasks) -> None:
+    def _kill_now(procs, results) -> None:
+        """Terminate every rank process without asking: after a failure the healthy ranks may sit in a collective that will never complete."""
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=5)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=5)
+        if results is not None:  # late messages of the dying ranks must not meet the next reader
+            import queue
+
+            try:
+                while True:
+                    results.get_nowait()
+            except (queue.Empty, OSError, ValueError, EOFError):
+                pass
+
+    @staticmethod
+    def _shutdown(procs, tasks, results=None) -> None:
         for q in tasks:
             try:
                 q.put(None)
@@ -378,9 +471,10 @@ class _RankPool:
                 pass
         for p in procs:
             p.join(timeout=20)
-        for p in procs:
-            if p.is_alive():
-                p.terminate()
+        _RankPool._kill_now(procs, results)
 
-    def close(self) -> None:
-        self._finalizer()
+    def close(self, graceful: bool = True) -> None:
+        if not graceful:
+            self._kill_now(self._procs, self._results)
+        if self._finalizer is not None:
+            self._finalizer()

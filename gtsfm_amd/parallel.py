@@ -39,6 +39,59 @@ def world_info() -> Tuple[int, int]:
     return (d.get_rank(), d.get_world_size()) if d else (0, 1)
 
 
+def _collective_device() -> torch.device:
+    """Where a small control tensor of a collective lives: the rank's GPU under RCCL ("nccl"), the host under gloo."""
+    d = _dist()
+    if d is not None and d.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+class PeerRankFailed(RuntimeError):
+    """Raised on the healthy ranks when another rank reported a failure at an agreement point (``agree_or_raise``)."""
+
+
+def agree_or_raise(error: Optional[BaseException], phase: str) -> None:
+    """Agreement point between the phases of a sharded scene: every rank says whether ITS part of ``phase`` failed (one all_gather of one
+    int32 each) before anyone enters the next collective. A rank that raised alone would leave its peers blocked in that collective until
+    the process-group timeout; here the failing rank re-raises its own exception and every other rank raises ``PeerRankFailed`` naming
+    the ranks that failed, so all of them leave the scene together. Without a process group: re-raises ``error`` if there is one."""
+    d = _dist()
+    if d is None:
+        if error is not None:
+            raise error
+        return
+    flag = torch.tensor([0 if error is None else 1], dtype=torch.int32, device=_collective_device())
+    flags = torch.empty((d.get_world_size(),), dtype=torch.int32, device=flag.device)
+    d.all_gather_into_tensor(flags, flag)
+    failed = [r for r, f in enumerate(flags.cpu().tolist()) if f]
+    if error is not None:
+        raise error
+    if failed:
+        raise PeerRankFailed(f"sharded scene: rank(s) {failed} failed during {phase}; rank {d.get_rank()} leaves the scene with them")
+
+
+_EXCHANGE_MODE: Dict[int, str] = {}  # id(default process group) -> the mode every rank of that group uses
+
+
+def agreed_exchange_mode() -> str:
+    """``GTSFM_SHARD_EXCHANGE`` ("all_to_all", default, or the "all_gather" escape hatch) as RANK 0 reads it, broadcast once per process group:
+    ranks whose environments differ (joined mode under several launchers) would otherwise enter different collectives and deadlock silently."""
+    d = _dist()
+    mine = os.environ.get("GTSFM_SHARD_EXCHANGE", "all_to_all")
+    if d is None:
+        return mine
+    key = id(d.group.WORLD)
+    if key not in _EXCHANGE_MODE:
+        box = [mine]
+        d.broadcast_object_list(box, src=0)
+        if box[0] not in ("all_to_all", "all_gather"):
+            raise ValueError(f"GTSFM_SHARD_EXCHANGE={box[0]!r} on rank 0: expected 'all_to_all' or 'all_gather'")
+        _EXCHANGE_MODE.clear()  # one live process group per process
+        _EXCHANGE_MODE[key] = box[0]
+    return _EXCHANGE_MODE[key]
+
+
 def broadcast_packed_weights(packed: Optional[torch.Tensor], numel: int, device: torch.device, src: int = 0) -> torch.Tensor:
     """Rank ``src`` passes its packed fp32 blob, the others pass None; returns the blob on ``device`` everywhere."""
     d = _dist()
@@ -162,9 +215,12 @@ def exchange_feature_rows(plan: ScenePlan, local: Dict[str, torch.Tensor], gathe
     ``gather_rows(tensor, index)``: how the send buffer is assembled from ``local`` (default ``torch.index_select``; the GPU pipeline passes
     its block-move kernel). Without a process group the table is assembled locally."""
     d = _dist()
-    if d is not None and os.environ.get("GTSFM_SHARD_EXCHANGE", "all_to_all") == "all_gather":
+    devices = {local[key].device for key in keys}
+    if len(devices) != 1:
+        raise ValueError(f"exchange_feature_rows: the feature arrays live on different devices ({sorted(map(str, devices))})")
+    if d is not None and agreed_exchange_mode() == "all_gather":
         # escape hatch (round 2-4's exchange): every rank receives every image, then keeps the rows of its table. Same result, ~R / 2 times the
-        # bytes; for a node whose RCCL build has trouble with ragged all_to_all.
+        # bytes; for a node whose RCCL build has trouble with ragged all_to_all. The mode is rank 0's, agreed once per process group.
         full = all_gather_feature_table(local, plan.num_images, keys=keys)
         rows = torch.tensor([table_index(i, plan.num_images, plan.world) for i in plan.table_images], dtype=torch.int64, device=local[keys[0]].device)
         return {key: torch.index_select(full[key], 0, rows) for key in keys}

@@ -73,3 +73,32 @@ class StandInPipeline:
 def stand_in_pipeline_factory(generator, device) -> StandInPipeline:
     """``pipeline_factory`` for ``ShardedDetDescCorrespondenceGenerator`` in plumbing tests (picklable: a module-level function)."""
     return StandInPipeline(min(int(getattr(generator._detector_descriptor, "max_keypoints", 32)), 32))
+
+
+class FailingStandInPipeline(StandInPipeline):
+    """Failure injection for the sharded generator's tests: on rank ``GTSFM_STANDIN_FAIL_RANK`` the ``GTSFM_STANDIN_FAIL_PHASE`` phase
+    ("detect" / "match") either raises (``GTSFM_STANDIN_FAIL_HOW=raise``, default) or kills the process the way an outside signal would
+    (``=exit``: no exception, no message, no agreement with the peers)."""
+
+    def _maybe_fail(self, phase: str) -> None:
+        import os
+
+        from gtsfm_amd import parallel
+
+        rank, _ = parallel.world_info()
+        if os.environ.get("GTSFM_STANDIN_FAIL_PHASE") == phase and int(os.environ.get("GTSFM_STANDIN_FAIL_RANK", "-1")) == rank:
+            if os.environ.get("GTSFM_STANDIN_FAIL_HOW", "raise") == "exit":
+                os._exit(3)
+            raise ValueError(f"injected failure in {phase} on rank {rank}")
+
+    def detect_image_objects(self, imgs, image_batch: int = 16):
+        self._maybe_fail("detect")
+        return super().detect_image_objects(imgs, image_batch)
+
+    def match(self, feats, pairs, shapes, counts=None, **kw):
+        self._maybe_fail("match")
+        return super().match(feats, pairs, shapes, counts=counts, **kw)
+
+
+def failing_stand_in_pipeline_factory(generator, device) -> FailingStandInPipeline:
+    return FailingStandInPipeline(min(int(getattr(generator._detector_descriptor, "max_keypoints", 32)), 32))

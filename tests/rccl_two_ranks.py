@@ -1,5 +1,6 @@
-"""Two ranks of the front-end's collectives on ONE device (tests/test_rccl_gpu.py launches this under torch.distributed.run).
-Exit code 77 = RCCL refuses two ranks on one GPU (it normally does: "Duplicate GPU detected"); 0 = the collectives ran and agree."""
+"""The front-end's collectives on RCCL, one rank per GPU when the box has as many GPUs as ranks (tools/scale_selfcheck.sh on a multi-GPU node),
+otherwise every rank on device 0 (tests/test_rccl_gpu.py on a one-GPU box, launched under torch.distributed.run).
+Exit code 77 = RCCL refuses several ranks on one GPU (it normally does: "Duplicate GPU detected"); 0 = the collectives ran and agree."""
 import os
 import sys
 from pathlib import Path
@@ -12,16 +13,20 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from gtsfm_amd import parallel  # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-torch.cuda.set_device(0)
-dev = torch.device("cuda:0")
+import datetime  # noqa: E402
+
+distinct = torch.cuda.device_count() >= world
+index = int(os.environ.get("LOCAL_RANK", rank)) if distinct else 0
+torch.cuda.set_device(index)
+dev = torch.device("cuda", index)
 try:
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=120))
     probe = torch.full((4,), float(rank), device=dev)
     dist.all_reduce(probe)
     torch.cuda.synchronize()
 except Exception as e:  # noqa: BLE001
-    print(f"rank {rank}: RCCL refused two ranks on one device: {str(e)[:200]}", flush=True)
-    os._exit(77)
+    print(f"rank {rank}: RCCL refused {world} ranks on {'distinct devices' if distinct else 'one device'}: {str(e)[:200]}", flush=True)
+    os._exit(1 if distinct else 77)  # on distinct devices a refusal is a failure, not a skip
 blob = torch.arange(1000, dtype=torch.float32, device=dev) if rank == 0 else None
 got = parallel.broadcast_packed_weights(blob, 1000, dev)
 assert torch.equal(got.cpu(), torch.arange(1000, dtype=torch.float32))
@@ -42,4 +47,4 @@ gathered = parallel.gather_matches({p: np.full((p[0] + p[1], 2), p[0], dtype=np.
 assert sorted(gathered) == parallel.exhaustive_pairs(n) and all(v.shape == (p[0] + p[1], 2) for p, v in gathered.items())
 dist.barrier()
 dist.destroy_process_group()
-print(f"rank {rank}: rccl_two_ranks OK", flush=True)
+print(f"rank {rank}: rccl_two_ranks OK on {dev} ({'one rank per GPU' if distinct else 'ranks share device 0'})", flush=True)

@@ -19,7 +19,7 @@ import torch.multiprocessing as mp
 from gtsfm_amd import parallel
 from gtsfm_amd.common.image import Image
 from gtsfm_amd.frontend.correspondence_generator.sharded_det_desc_correspondence_generator import ShardedDetDescCorrespondenceGenerator
-from gtsfm_amd.utils.standin import stand_in_pipeline_factory
+from gtsfm_amd.utils.standin import failing_stand_in_pipeline_factory, stand_in_pipeline_factory
 
 
 def _free_port() -> int:
@@ -158,3 +158,73 @@ def test_constructor_checks_and_pickling(tmp_path):
         ShardedDetDescCorrespondenceGenerator(object(), det)
     with pytest.raises(TypeError):
         ShardedDetDescCorrespondenceGenerator(mt, object())
+
+
+def _children_alive():
+    import multiprocessing
+
+    return [p for p in multiprocessing.active_children() if p.is_alive()]
+
+
+@pytest.mark.parametrize("phase,how", [("match", "raise"), ("detect", "raise"), ("match", "exit")])
+def test_a_rank_that_fails_mid_scene_fails_the_call_quickly_and_leaves_no_process_behind(monkeypatch, phase, how):
+    """one of three gloo ranks fails in the middle of a scene -- by raising (its peers learn of it at the
+    agreement point before the next collective and leave with it) or by dying without a word (its peers sit in a collective that will never
+    complete; the parent sees the dead process and terminates them). Either way the caller gets ``RuntimeError`` well inside a minute, no
+    rank process survives, and the generator serves the next scene with a fresh pool."""
+    import time
+
+    monkeypatch.setenv("GTSFM_STANDIN_FAIL_RANK", "1")
+    monkeypatch.setenv("GTSFM_STANDIN_FAIL_PHASE", phase)
+    monkeypatch.setenv("GTSFM_STANDIN_FAIL_HOW", how)
+    images, pairs = _scene(9), parallel.exhaustive_pairs(9)[:30]
+    gen = ShardedDetDescCorrespondenceGenerator(None, types.SimpleNamespace(max_keypoints=24), num_gpus=3, backend="gloo",
+                                                pipeline_factory=failing_stand_in_pipeline_factory, collective_timeout_s=120.0)
+    before = len(_children_alive())
+    t0 = time.monotonic()
+    try:
+        with pytest.raises(RuntimeError) as err:
+            gen.generate_correspondences(None, images, pairs)
+        took = time.monotonic() - t0
+        assert took < 60.0, f"the failure took {took:.0f} s to reach the caller"
+        if how == "raise":  # the failing rank's own traceback, not a peer's "somebody failed"
+            assert f"injected failure in {phase} on rank 1" in str(err.value) and "rank 1 failed" in str(err.value)
+        else:
+            assert "rank 1 exit code 3" in str(err.value) or "rank 1 failed\nrank process exited with code 3" in str(err.value)
+        assert gen._pool is None
+        deadline = time.monotonic() + 10.0
+        while len(_children_alive()) > before and time.monotonic() < deadline:
+            time.sleep(0.1)
+        assert len(_children_alive()) == before, "rank processes outlived the failed call"
+        # the next scene gets a fresh pool; with the injection switched off it equals the single-process result
+        monkeypatch.setenv("GTSFM_STANDIN_FAIL_RANK", "-1")
+        got = gen.generate_correspondences(None, images, pairs)
+        _assert_same(got, _generator(1).generate_correspondences(None, images, pairs), pairs)
+    finally:
+        gen.close()
+
+
+def _disagreeing_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ["GTSFM_SHARD_EXCHANGE"] = "all_gather" if rank == 1 else "all_to_all"  # rank 1's launcher exported something else
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert parallel.agreed_exchange_mode() == "all_to_all"  # rank 0's, everywhere
+        images, pairs = _scene(7), parallel.exhaustive_pairs(7)
+        _, matches = _generator(None).generate_correspondences(None, images, pairs)
+        np.save(os.path.join(tmp, f"d{rank}.npy"), np.concatenate([matches[p].reshape(-1) for p in pairs]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_with_different_exchange_settings_follow_rank_zero(tmp_path):
+    """GTSFM_SHARD_EXCHANGE was read per rank at call time; ranks that disagreed entered different collectives and hung.
+    The mode is now rank 0's, broadcast once per process group."""
+    mp.spawn(_disagreeing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    images, pairs = _scene(7), parallel.exhaustive_pairs(7)
+    _, matches = _generator(1).generate_correspondences(None, images, pairs)
+    want = np.concatenate([matches[p].reshape(-1) for p in pairs])
+    for r in range(2):
+        np.testing.assert_array_equal(np.load(tmp_path / f"d{r}.npy"), want)
