@@ -46,5 +46,5 @@ struct AttnParams {
 // Floats of workspace the launch (nproblems, heads, max_q, max_k) over `rows` token rows can use (0 when every problem is one segment).
 size_t attention_workspace_floats(int nproblems, int heads, int max_q, int max_k, size_t rows, int math);
 int attention_math_from_env();      // GTSFM_ATTENTION_MATH=bf16x3 -> ATTN_MATH_BF16X3, else ATTN_MATH_F32 (read per call)
-int attention_segments(int max_k);  // key segments (1024 keys each) a problem with max_k keys is cut into
+int attention_segments(int max_k);  // key segments a launch must provide for when no problem has more than max_k keys (an upper bound: 512-key segments)
 int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t stream);

@@ -14,7 +14,8 @@
 // one wave. Per 64-key tile and wave: 64 + 64 v_mfma_f32_32x32x2_f32. Derivation, LDS-bank argument and the round-1 /
 // round-2 measurements (register-staged predecessor, double-buffered K/V, ...): tools/experimental/attention_dma.hip, DESIGN.md.
 //
-// Key SEGMENTS (round 3). The keys of a problem are cut into segments of AT_SEG_TILES tiles (1024 keys). Every segment runs
+// Key SEGMENTS (round 3; their length a function of the problem's size since round 6: at_seg_tiles below). The keys of a problem are cut into
+// segments of 8 .. 16 tiles (512 .. 1024 keys). Every segment runs
 // the online softmax from a FRESH state (O = 0, l = 0, reference maximum from its first tile) and the segments' (O, m, l) are
 // merged in ascending order with one fixed formula (at_merge). Two schedules execute exactly this arithmetic:
 //   fused  (attention_dma_kernel<false>): a workgroup walks all segments of its 128 queries; the running merged O sits in a
@@ -38,7 +39,7 @@
 #define AT_QB 128      // queries per workgroup of 4 waves (the 8-wave form of the fused schedule owns 256)
 #define AT_REBASE 8.0f  // rebase the softmax reference when the running maximum moved by more than this (base-2 units)
 #ifndef AT_SEG_TILES
-#define AT_SEG_TILES 16  // key tiles per segment
+#define AT_SEG_TILES 16  // key tiles per segment, at most
 #endif
 
 // Developer timeline (tools/trace_attention.hip builds this file with -DGTSFM_TRACE; the product build has none of it): per wave,
@@ -97,6 +98,28 @@ __device__ unsigned long long* g_attn_trace;  // [workgroup][wave][10]: S issue,
 #ifndef ATD_WGS_PER_CU
 #define ATD_WGS_PER_CU 2
 #endif
+
+// Key tiles per segment of a problem with nq queries and nk keys (round 6): a PURE FUNCTION OF THE PROBLEM'S OWN SIZE -- never of the launch, the
+// batch or the device -- so the fused and the split schedule, a pair alone and a pair inside a batch all cut the same keys into the same segments
+// and merge them in the same order: bit-identical by construction, as with the fixed 16-tile segments of rounds 3 - 5.
+// Why not a constant: the split schedule's work units are (128-query tile, segment) pairs and ONE keypoint-set pair offers 8 (problem, head)
+// groups of them. At the 5000-keypoint cap that was 8 x 40 x 5 = 1600 units on the 512 workgroup slots of a 256-CU chip: 3.1 rounds, the fourth
+// nearly empty (0.62 of peak for the launch the per-call plugin API lives on). The function picks the even segment length in 8 .. 16 tiles that
+// minimises rounds x segment length for that single-pair geometry on 512 slots (ties: the longer segment): 10 tiles at the cap = 8 x 40 x 8 =
+// 2560 units = 5.0 rounds. The constants 8 and 512 are part of the DEFINITION (they are not queried from the device): results must not depend
+// on the chip the code runs on. Batches run the fused schedule, which only pays one more LDS round trip of its state per extra segment.
+#define AT_SEG_MIN_TILES 8
+__host__ __device__ inline int at_seg_tiles(int nq, int nk) {
+    const int qt = (nq + AT_QB - 1) / AT_QB, nt = (nk + AT_KT - 1) / AT_KT;
+    int best = AT_SEG_TILES, best_cost = 0x7fffffff;
+    for (int seg = AT_SEG_TILES; seg >= AT_SEG_MIN_TILES; seg -= 2) {
+        const int nseg = (nt + seg - 1) / seg;
+        const int rounds = (8 * qt * nseg + 511) / 512;
+        const int cost = rounds * (nt < seg ? nt : seg);
+        if (cost < best_cost) best = seg, best_cost = cost;
+    }
+    return best;
+}
 
 __device__ __forceinline__ void mfma8(f32x16& acc0, f32x16& acc1, const f32x4 a0, const f32x4 a1, const f32x4 b) {
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
@@ -180,10 +203,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? ATD_WGS_PER_CU : 1) void atten
     const int qrow = q0 + wave * 32 + j;
     const bool qvalid = qrow < nq;
     const int ntiles = (nk + AT_KT - 1) / AT_KT;
-    const int t_begin = SPLIT ? seg_of_wg * AT_SEG_TILES : 0;
-    const int t_end = SPLIT ? (ntiles < t_begin + AT_SEG_TILES ? ntiles : t_begin + AT_SEG_TILES) : ntiles;
-    if (SPLIT && t_begin >= ntiles) return;  // this problem has fewer segments than the widest of the launch (or no keys: combine writes zeros)
-    if (!SPLIT && !p.park && !p.lds_has_oc && ntiles > AT_SEG_TILES) __builtin_trap();  // the host promised one segment and reserved no parking space
+    const int seg_tiles = at_seg_tiles(nq, nk);  // wave-uniform: scalar arithmetic
+    const int t_begin = SPLIT ? seg_of_wg * seg_tiles : 0;
+    const int t_end = SPLIT ? (ntiles < t_begin + seg_tiles ? ntiles : t_begin + seg_tiles) : ntiles;
+    if (SPLIT && t_begin >= ntiles) return;  // this problem has fewer segments than the launch provides for (or no keys: combine writes zeros)
+    if (!SPLIT && !p.park && !p.lds_has_oc && ntiles > seg_tiles) __builtin_trap();  // the host promised one segment and reserved no parking space
 
     f32x4 qreg[8];  // Q fragment (B operand of S^T = K Q^T): lane (q = j, kh) holds Q[q][8t + 4kh .. +3], pre-scaled by scale * log2(e)
     {
@@ -271,13 +295,15 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? ATD_WGS_PER_CU : 1) void atten
     // raised wave priority over the softmax, round 3: the softmax phase shrinks from 2.9 k to 2.0 k cycles per tile and the
     // barrier waits grow by as much, tools/trace_attention.hip.)
     TRACE_DECL
+    int ts_run = 0;  // tile index inside its segment (both schedules start at a segment boundary)
     auto tile_step = [&](auto par_c, auto last_c, f32x16& sc0, f32x16& sc1, f32x16& sn0, f32x16& sn1, const int t) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool more = !decltype(last_c)::value;  // compile time: the last tile of the walk has its own body (no S phase to interleave with)
         constexpr int KB = ATD_DBUF ? PAR : 0, KB_NEXT = ATD_DBUF ? PAR ^ 1 : 0, VB = ATD_DBUF ? PAR : 0, VB_NEXT = ATD_DBUF ? PAR ^ 1 : 0;
         const int k0 = t * AT_KT;
-        const int ts = t % AT_SEG_TILES;  // tile index inside its segment (t_begin is a multiple of AT_SEG_TILES)
-        const bool next_fresh = !SPLIT && more && ts == AT_SEG_TILES - 1;  // fused: the next tile opens a new segment
+        const int ts = ts_run;  // tile index inside its segment
+        ts_run = (ts + 1 == seg_tiles) ? 0 : ts + 1;
+        const bool next_fresh = !SPLIT && more && ts == seg_tiles - 1;  // fused: the next tile opens a new segment
         if (ATD_DBUF) {
             __builtin_amdgcn_s_waitcnt(0x0f70);  // own pieces of K(t+1) and V(t) landed (issued one tile ago)
             __syncthreads();
@@ -457,8 +483,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? ATD_WGS_PER_CU : 1) void atten
         TRACE_SEG(4)
         // ---- fused schedule, end of a segment: fold (O, m, l) into the merged state, which waits in Oc (each thread reads and
         // writes only its own 34 slots, so no barrier is involved) while the registers serve the next segment.
-        if (!SPLIT && (next_fresh || (!more && t >= AT_SEG_TILES))) {
-            if (t >= AT_SEG_TILES) {  // not the first segment: merged <- merged (+) this segment
+        if (!SPLIT && (next_fresh || (!more && t >= seg_tiles))) {
+            if (t >= seg_tiles) {  // not the first segment: merged <- merged (+) this segment
                 const AtMergeWeights w = at_merge_weights(Oc[32 * NT + tid], m);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -486,7 +512,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? ATD_WGS_PER_CU : 1) void atten
     using Par1 = std::integral_constant<int, 1>;
     using NotLast = std::false_type;
     using Last = std::true_type;
-    // t_begin is even (a multiple of AT_SEG_TILES): parity of t = parity inside the segment. Two tiles per iteration, the two score
+    // t_begin is even (segment lengths are even): parity of t = parity inside the segment. Two tiles per iteration, the two score
     // tiles swapping roles (no copies); the last tile of the walk runs a body without an S phase.
     int t = t_begin;
 #if ATD_DBUF || ATD_UNROLL2
@@ -548,7 +574,8 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(AttnParams p) {
     const int lane = threadIdx.x & 63, h = lane >> 4, c = lane & 15;
     if (h >= p.heads) return;
     const int ntiles = (nk + AT_KT - 1) / AT_KT;
-    const int nseg = (ntiles + AT_SEG_TILES - 1) / AT_SEG_TILES;
+    const int seg_tiles = at_seg_tiles(nq, nk);
+    const int nseg = (ntiles + seg_tiles - 1) / seg_tiles;
     const size_t row = (size_t)pr.q_off + qrow;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     float m = 0.f, l = 0.f;
@@ -708,11 +735,12 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
     const int qrow = q0 + wave * 32 + j;
     const bool qvalid = qrow < nq;
     const int ntiles = (nk + AT_KT - 1) / AT_KT;
-    const int t_begin = SPLIT ? seg_of_wg * AT_SEG_TILES : 0;
-    const int t_end = SPLIT ? (ntiles < t_begin + AT_SEG_TILES ? ntiles : t_begin + AT_SEG_TILES) : ntiles;
+    const int seg_tiles = at_seg_tiles(nq, nk);
+    const int t_begin = SPLIT ? seg_of_wg * seg_tiles : 0;
+    const int t_end = SPLIT ? (ntiles < t_begin + seg_tiles ? ntiles : t_begin + seg_tiles) : ntiles;
     if (SPLIT && t_begin >= ntiles) return;
     float* Oc = p.park + (size_t)blockIdx.x * (34 * NT);  // fused schedule, more than one segment: this thread's merged (O, m, l)
-    if (!SPLIT && !p.park && ntiles > AT_SEG_TILES) __builtin_trap();
+    if (!SPLIT && !p.park && ntiles > seg_tiles) __builtin_trap();
 
     if (!SPLIT && nk <= 0) {  // no keys: the output rows are zero; uniform for the workgroup
         if (qvalid) {
@@ -776,9 +804,8 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     __syncthreads();
 
-    for (int t = t_begin; t < t_end; ++t) {
+    for (int t = t_begin, ts = 0; t < t_end; ++t, ts = (ts + 1 == seg_tiles) ? 0 : ts + 1) {  // ts: tile index inside its segment
         const int k0 = t * AT_KT;
-        const int ts = t % AT_SEG_TILES;
         const bool more = t + 1 < t_end;
         // ---- S^T = K Q^T - m
         f32x16 s0, s1;
@@ -860,9 +887,9 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
             tile_dma(1, t + 1, Vl);
         }
         // ---- fused schedule, end of a segment: fold (O, m, l) into the merged state parked in the workspace
-        const bool seg_end = more && ts == AT_SEG_TILES - 1;
-        if (!SPLIT && (seg_end || (!more && t >= AT_SEG_TILES))) {
-            if (t >= AT_SEG_TILES) {
+        const bool seg_end = more && ts == seg_tiles - 1;
+        if (!SPLIT && (seg_end || (!more && t >= seg_tiles))) {
+            if (t >= seg_tiles) {
                 const AtMergeWeights w = at_merge_weights(Oc[32 * NT + tid], m);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -906,7 +933,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
     }
 }
 
-static int at_segments(int max_k) { return ceil_div(ceil_div(max_k < 1 ? 1 : max_k, AT_KT), AT_SEG_TILES); }
+// Segments the launch must provide for: an upper bound over every problem with at most max_k keys (a segment has at least AT_SEG_MIN_TILES tiles;
+// which length a problem takes depends on its own query count too, which the host does not know for device-resident counts). Workgroups of
+// segments a problem does not have exit at once; 1 = no problem of the launch can have more than one segment.
+static int at_segments(int max_k) { return ceil_div(ceil_div(max_k < 1 ? 1 : max_k, AT_KT), AT_SEG_MIN_TILES); }
 int attention_segments(int max_k) { return at_segments(max_k); }
 
 // The split schedule pays one extra round trip of O through the workspace; it is chosen when the unsplit launch would not fill

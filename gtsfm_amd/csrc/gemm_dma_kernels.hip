@@ -70,7 +70,18 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
     const int ncb_total = (p.N + 127) / 128, mtiles = (p.M + 127) / 128;
     const int groups = (ncb_total + p.nb_per_wg - 1) / p.nb_per_wg;
     const int b = blockIdx.x, kx = b >> 3;
-    const int mt = (kx / groups) * 8 + (b & 7), cb0 = (kx % groups) * p.nb_per_wg;
+    int mt = (kx / groups) * 8 + (b & 7), cb0 = (kx % groups) * p.nb_per_wg;
+    if (p.super_rows > 0) {
+        // Wide products (the score matrix of a pair at the cap: 40 x 40 tiles, W = image 1's 5000 x 256 descriptors = 5 MB against 4 MiB of L2): with
+        // a whole row of column blocks side by side, every row tile streamed ALL of W through its XCD's L2 -- 286 MB moved for 110 MB algorithmic
+        // (profiles/r05_pmc_traffic.json). Here the ~64 workgroups an XCD runs at a time form a super-tile of super_rows row tiles x 8 column
+        // groups: 8 + 8 operand panels of 128 KB serve 64 tiles (41 panels in the row order). Speed only: a tile's arithmetic does not change.
+        const int per = p.super_rows * 8, nsc = (groups + 7) >> 3;
+        const int sb = kx / per, w = kx - sb * per;
+        const int cg = (sb % nsc) * 8 + (w & 7);
+        if (cg >= groups) return;
+        mt = ((sb / nsc) * p.super_rows + (w >> 3)) * 8 + (b & 7), cb0 = cg * p.nb_per_wg;
+    }
     if (mt >= mtiles) return;
     const int m0 = mt * 128;
     if (p.tile_cnt_idx) {  // ragged batch with 128-row-aligned sequences
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
     };
 
     f32x16 c00, c01, c10, c11;  // (row half, column half) of the wave's 64 x 64 tile; lane = row, registers = columns
-    f32x4 bia[8];               // bias of the lane's 32 columns
+    f32x4 bia[2];               // bias of the lane's columns in the epilogue's transposed mapping: 4 columns in either column half of the wave's tile
     f32x4 aux[16];              // residual values (HAS_RES) / rotary (cos, sin) pairs (ROT) of the block being finished
     const bool vec_ok = ((N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.c_coff & 3) == 0) && (!HAS_RES || (p.ldres & 3) == 0);
     const int nbias = (p.N + 63) / 64 * 64;
@@ -150,12 +161,6 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
         if (st == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) c00[r] = c01[r] = c10[r] = c11[r] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int cc = colb + 32 * (q >> 2) + 8 * (q & 3);
-                bia[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.bias && cc < nbias) bia[q] = *reinterpret_cast<const f32x4*>(p.bias + cc);
-            }
         }
         // source of the next stage (the stage after the last one re-fetches it: nobody reads that buffer)
         if (dcb >= nblk) dcb = nblk - 1, dst = nstages - 1;
@@ -165,6 +170,18 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
         const char* na = baseA + (size_t)dst * (DM_KC * 4);
         const char* nw = baseW + (size_t)dst * (DM_KC * 4);
         if (++dst == nstages) dst = 0, ++dcb;
+        if (last && vec_ok && !X3) {
+            // the block's bias in the epilogue's transposed lane mapping (a lane finishes 4 consecutive columns of a row there: 8 registers; in
+            // the MFMA layout, where a lane owns 32 + 32 columns of its row, the bias took 32 registers for the whole block and the residual /
+            // rotary variants spilled: round 5, 256 VGPRs + 20 / 28 bytes of scratch). Bias, alpha, ReLU, rotary, residual are elementwise
+            // and keep their order per element, so applying them after the transpose gives the same bits.
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int col = n0 + 64 * wn + 32 * h + 4 * tc;
+                bia[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && col < nbias) bia[h] = *reinterpret_cast<const f32x4*>(p.bias + col);
+            }
+        }
         if (last && vec_ok && !X3) {  // (X3: the operand pieces need the registers; the epilogue loads them where it uses them)
             // residual values / rotary (cos, sin) pairs of this block, in the epilogue's transposed lane mapping (see below):
             // requested now, in registers when the last MFMAs are done
@@ -255,20 +272,6 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
         if (last) {
 #endif
             // epilogue of column block cbi; its stores drain under the next block's MFMAs
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                c00[r] += bia[r >> 2][r & 3], c10[r] += bia[r >> 2][r & 3];
-                c01[r] += bia[4 + (r >> 2)][r & 3], c11[r] += bia[4 + (r >> 2)][r & 3];
-            }
-            if (p.alpha != 1.0f) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c00[r] *= p.alpha, c01[r] *= p.alpha, c10[r] *= p.alpha, c11[r] *= p.alpha;
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    c00[r] = fmaxf(c00[r], 0.f), c01[r] = fmaxf(c01[r], 0.f), c10[r] = fmaxf(c10[r], 0.f), c11[r] = fmaxf(c11[r], 0.f);
-            }
             if (vec_ok) {
                 // Transposed through LDS, one 32 x 32 accumulator tile at a time: in the MFMA layout a lane owns a ROW, so a
                 // 16-byte store instruction touches 32 rows x 32 B (64 cache lines per wave-instruction; the epilogue was
@@ -276,9 +279,24 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
                 // 8 full lines per instruction, and the residual / rotary operands arrive the same way. Scratch = this wave's
                 // OWN 4 KiB slice of the A stage all waves have just finished reading (only this wave's later DMA writes it).
                 float* scr = const_cast<float*>(sA) + 32 * wave * DM_KC;
+                // the lane's epilogue coordinates from a lane id read HERE (mbcnt behind an asm the compiler cannot hoist): derived from threadIdx
+                // at the top of the kernel they are loop invariants that occupy registers through every MFMA stage, and the rotary variant of the
+                // bf16x3 build spilled four of them
+                int elane;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
+                const int tr = elane >> 3, tc = elane & 7, j = elane & 31, kh = elane >> 5;
+                if (X3) {  // (the operand pieces needed the registers during the last stage)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int col = n0 + 64 * wn + 32 * h + 4 * tc;
+                        bia[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (p.bias && col < nbias) bia[h] = *reinterpret_cast<const f32x4*>(p.bias + col);
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const f32x16& ct = (t == 0) ? c00 : (t == 1) ? c01 : (t == 2) ? c10 : c11;
+                    if (X3) __builtin_amdgcn_sched_barrier(0);  // one tile's residual / rotary loads at a time: hoisted together they cost 64 registers
 #pragma unroll
                     for (int q = 0; q < 4; ++q)  // row j, 16-byte chunk 2 q + kh, XOR-swizzled by the row (conflict-free writes)
                         *reinterpret_cast<f32x4*>(scr + j * 32 + (((2 * q + kh) ^ (j & 7)) << 2)) = f32x4{ct[4 * q], ct[4 * q + 1], ct[4 * q + 2], ct[4 * q + 3]};
@@ -298,6 +316,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
                                 if (row < M) aux[4 * t + i] = *reinterpret_cast<const f32x4*>(p.rot_enc + (size_t)row * 64 + 32 * (t & 1) + 4 * tc);
                             }
                         }
+                        v += bia[t & 1];
+                        if (p.alpha != 1.0f) v *= p.alpha;
+                        if (p.relu) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
                         if (rot) {  // (x0, x1) -> (x0 c - x1 s, x1 c + x0 s) per feature pair, as apply_cached_rotary_emb
                             const f32x4 e = aux[4 * t + i];
                             v = f32x4{(v.x * e.x) + ((-v.y) * e.y), (v.y * e.x) + (v.x * e.y), (v.z * e.z) + ((-v.w) * e.w), (v.w * e.z) + (v.z * e.w)};
@@ -317,7 +338,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int col = col0 + 8 * (r >> 2) + (r & 3);
-                            if (col < N) crow[col] = HAS_RES ? p.res[(size_t)row * p.ldres + col] + ct[r] : ct[r];
+                            if (col >= N) continue;
+                            float v = ct[r] + (p.bias ? p.bias[col] : 0.f);  // same order per element as the vector path: bias, alpha, ReLU, residual
+                            if (p.alpha != 1.0f) v *= p.alpha;
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            crow[col] = HAS_RES ? p.res[(size_t)row * p.ldres + col] + v : v;
                         }
                     }
                 }
@@ -537,7 +562,14 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
         GTSFM_CHECK_LAUNCH("gemm_dma_small_kernel");
         return GTSFM_OK;
     }
-    const dim3 grid(ceil_div(mtiles, 8) * 8 * ceil_div(ncb, nbw), nprob);
+    dim3 grid(ceil_div(mtiles, 8) * 8 * ceil_div(ncb, nbw), nprob);
+    const int groups = ceil_div(ncb, nbw), local_rows = ceil_div(mtiles, 8);  // column groups; row tiles per XCD
+    static const char* super_env = getenv("GTSFM_GEMM_SUPERTILE");             // "0": row order everywhere (experiments)
+    q.super_rows = 0;
+    if (groups > 8 && !(super_env && super_env[0] == '0')) {
+        q.super_rows = local_rows < 8 ? local_rows : 8;
+        grid.x = 8 * ceil_div(local_rows, q.super_rows) * q.super_rows * ceil_div(groups, 8) * 8;
+    }
     const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
     if (x3) {  // opt-in arithmetic (GTSFM_GEMM_MATH=bf16x3): the same launch geometry, stages and epilogues
         if (q.rot_enc)

@@ -30,6 +30,8 @@ struct GemmParams {
     int math;       // 0 = exact fp32 (default; SuperPoint's 1x1 convolutions always), 1 = bf16x3 (opt-in: set by the matchers' forward and the
                     // stand-alone linear entry points from GTSFM_GEMM_MATH via gemm_math_from_env(); LDS-DMA kernel only)
     int nb_per_wg;  // filled by the launcher: 128-column blocks one workgroup walks
+    int super_rows; // filled by the launcher (LDS-DMA kernel): 0 = a row tile's column blocks run side by side on one XCD; r > 0 = wide products
+                    // (more than 8 column groups: the matchers' score matrices) walk super-tiles of r row tiles x 8 column groups per XCD
     int debug;      // developer ablation switches (GTSFM_GEMM_DEBUG): 1 = skip epilogue, 2 = skip A loads
 };
 

@@ -542,6 +542,38 @@ extern "C" int gtsfm_sinkhorn_f32(float* z_dev, int npairs, const int32_t* m, co
     return GTSFM_OK;
 }
 
+// Stand-alone score matrices: the ragged batched score GEMM exactly as sg_forward_phased launches it (parity against per-pair matmuls,
+// bench.py's roofline of the launch as the workload issues it -- one pair alone is 1600 tiles on 512 workgroup slots and says little
+// about a 16-pair chunk)
+extern "C" size_t gtsfm_score_matrices_workspace_bytes(int npairs) {
+    return npairs <= 0 ? 256 : align_up(desc_layout(npairs, 0).total * sizeof(int32_t), 256);
+}
+
+extern "C" int gtsfm_score_matrices_f32(const float* mdesc_dev, int npairs, const int32_t* m, const int32_t* n, float alpha, float* z_dev,
+                                        void* workspace_dev, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GTSFM_CHECK_ARG(mdesc_dev && m && n && z_dev && workspace_dev, "score_matrices: null pointer");
+    GTSFM_CHECK_ARG(npairs > 0, "score_matrices: bad arguments");
+    GTSFM_CHECK_ARG(gemm_uses_dma(256, 256), "score_matrices: the LDS-DMA GEMM is switched off");
+    const DescLayout DL = desc_layout(npairs, 0);
+    if (workspace_bytes < DL.total * sizeof(int32_t)) {
+        gtsfm_set_error("score_matrices: workspace too small (%zu < %zu bytes)", workspace_bytes, DL.total * sizeof(int32_t));
+        return GTSFM_ERR_WORKSPACE;
+    }
+    const BatchDims d = batch_dims(npairs, m, n, 1);
+    std::vector<int32_t> host(DL.total), hw((size_t)4 * npairs, 1);
+    TRY(gtsfm_match_build_desc(1, npairs, m, n, hw.data(), host.data()));
+    int32_t* desc_dev = (int32_t*)workspace_dev;
+    if (hipMemcpyAsync(desc_dev, host.data(), DL.total * sizeof(int32_t), hipMemcpyHostToDevice, stream) != hipSuccess) return GTSFM_ERR_HIP;
+    if (hipStreamSynchronize(stream) != hipSuccess) return GTSFM_ERR_HIP;  // `host` goes out of scope below
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.A = mdesc_dev, g.lda = 256, g.M = d.max_n0, g.K = 256, g.wraw = mdesc_dev, g.ldw = 256, g.N = d.max_n1, g.C = z_dev, g.alpha = alpha;
+    g.math = gemm_math_from_env();
+    GemmBatch bt = {(const GemmProblem*)(desc_dev + DL.score_p), desc_dev + DL.live, npairs};
+    return launch_gemm_dma_batched(g, bt, stream);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Stand-alone LightGlue assignment (sigmoid_log_double_softmax + filter_matches on given similarity matrices) and stand-alone
 // LayerNorm + GELU: parity tests against torch, bench.py's rooflines of the sweep / row kernels the forward launches

@@ -119,6 +119,11 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "gtsfm_score_matrices_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "gtsfm_score_matrices_f32": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
     "gtsfm_verify_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "gtsfm_verify_essential_f64": (
         C.c_int,

@@ -147,6 +147,25 @@ def synthetic_overlapping_views(num_views: int, height: int, width: int, seed: i
     return np.stack([canvas[dy : dy + height, dx : dx + width] for dy, dx in view_offsets(num_views)])
 
 
+def synthetic_mixed_scene(num_views: int, height: int, width: int, seed: int = 2000, canvases: int = 3) -> np.ndarray:
+    """``num_views`` views [n,H,W] uint8 that do NOT all look alike (bench.py's adaptive-depth leg): view v is cut from canvas
+    ``v % canvases`` -- canvases differ in seed and in low-pass radius (2, 3, 5, ...), i.e. in texture scale -- at an offset that grows with
+    ``v // canvases`` in steps of 1/8 of the image side (multiples of the 8-px cell). Pairs of one canvas overlap by 100 % ... ~30 %; pairs
+    across canvases share nothing, like the unrelated pairs of a real exhaustive visibility graph. A matcher's early exit and point pruning
+    then have something to tell apart."""
+    per = -(-num_views // canvases)
+    step = max(8, (min(height, width) // 8) // 8 * 8)
+    radii = [2, 3, 5, 4, 6]
+    pads = step * per
+    sheets = [synthetic_gray_image(height + pads, width + pads, seed + 17 * c, blur=radii[c % len(radii)]) for c in range(canvases)]
+    views = []
+    for v in range(num_views):
+        c, k = v % canvases, v // canvases
+        dy, dx = step * k, step * ((3 * k) % per)
+        views.append(sheets[c][dy : dy + height, dx : dx + width])
+    return np.stack(views)
+
+
 def topk_detection_order(scores: np.ndarray, k: int) -> np.ndarray:
     """Indices of the ``k`` largest responses, ties broken by detection order, returned in detection order -- the
     selection of ``kp_select_topk_kernel`` (``Keypoints.get_top_k``'s ``np.argpartition`` leaves ties and order

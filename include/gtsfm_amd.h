@@ -255,6 +255,17 @@ size_t gtsfm_sinkhorn_workspace_bytes(int npairs, const int32_t* m_host, const i
 int gtsfm_sinkhorn_f32(float* z_dev, int npairs, const int32_t* m_host, const int32_t* n_host, float bin_score, int iters,
                        void* workspace_dev, size_t workspace_bytes, float* u_dev, float* v_dev, void* stream);
 
+/* The score matrices of a batch of pairs in ONE ragged launch of the LDS-DMA GEMM, as gtsfm_sg_forward issues them (SG:257-258:
+ * scores = einsum('bdn,bdm->bnm', mdesc0, mdesc1) / 256^.5): pair p's image-0 descriptor rows times its image-1 rows, image 1's rows
+ * standing in for the weights as they lie (no packing pass). mdesc_dev: [sum(m) + sum(n)][256], pair p's m[p] image-0 rows followed by
+ * its n[p] image-1 rows, pairs back to back. z_dev: couplings matrices in gtsfm_sinkhorn_f32's layout (pair p: (m[p]+1) rows of stride
+ * ld = (n[p]+1 rounded up to 4)); only the inner m x n block is written: alpha * <mdesc0[i], mdesc1[j]>. Parity tests of the batched
+ * product against per-pair matmuls; bench.py's roofline of the launch. Builds and uploads its own batch descriptor: synchronises
+ * `stream` once. */
+size_t gtsfm_score_matrices_workspace_bytes(int npairs);
+int gtsfm_score_matrices_f32(const float* mdesc_dev, int npairs, const int32_t* m_host, const int32_t* n_host, float alpha, float* z_dev,
+                             void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* The same, split at the point where a pair's two images first see each other (for callers that match one image against
  * many: the per-image part runs once per image instead of once per pair; results are bit-identical to gtsfm_sg_forward).
  * phase 1: keypoint encoder + the first (self) GNN layer of every keypoint set of the batch (superglue.py:243-248, first

@@ -261,6 +261,42 @@ def test_sinkhorn_standalone_vs_oracle(lib, gpu_device, shapes, iters):
         np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4)
 
 
+@pytest.mark.parametrize("shapes", [[(300, 200), (1, 5), (129, 128), (64, 700)], [(5000, 4800), (2049, 5000)], [(1400, 1300)] * 3],
+                         ids=["ragged_small", "cap_super_tiles", "nine_to_eleven_column_groups"])
+def test_score_matrices_batched_launch_vs_matmul(lib, gpu_device, shapes):
+    """gtsfm_score_matrices_f32: the ragged one-launch score GEMM of a chunk (superglue.py:257-258) against per-pair float64 matmuls, and -- the
+    tile ORDER being a launch-geometry decision only -- bit-identical between the row order of rounds 2-5 and round 6's super-tile order for wide
+    products (more than 8 column groups) and the 64 x 64 tiling small single products take: every pair again through the stand-alone linear entry
+    point, which picks its own tiling and order from its own geometry."""
+    from gtsfm_amd.runtime import lib as L
+
+    rng = np.random.default_rng(11)
+    m = np.array([s[0] for s in shapes], dtype=np.int32)
+    n = np.array([s[1] for s in shapes], dtype=np.int32)
+    descs = [(rng.standard_normal((a + b, 256)) / 16.0).astype(np.float32) for a, b in shapes]
+    mdesc = T(np.concatenate(descs)).to(gpu_device)
+    sizes = [(a + 1) * ((b + 1 + 3) // 4 * 4) for a, b in shapes]
+    z = torch.full((sum(sizes),), float("nan"), device=gpu_device)
+    ws = torch.empty(int(lib.gtsfm_score_matrices_workspace_bytes(len(shapes))), dtype=torch.uint8, device=gpu_device)
+    L.check(lib.gtsfm_score_matrices_f32(mdesc.data_ptr(), len(shapes), m.ctypes.data, n.ctypes.data, 0.0625, z.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         _stream()), "score_matrices")
+    z = z.cpu().numpy()
+    off = 0
+    for (a, b), d, size in zip(shapes, descs, sizes):
+        ld = (b + 1 + 3) // 4 * 4
+        got = z[off : off + size].reshape(a + 1, ld)
+        ref = (d[:a].astype(np.float64) @ d[a:].astype(np.float64).T) * 0.0625
+        np.testing.assert_allclose(got[:a, :b], ref, rtol=0, atol=2e-6)
+        assert np.isnan(got[a]).all() and np.isnan(got[:a, b:]).all()  # the dustbin row / column and the padding are not this launch's to write
+        # the same product of ONE pair through the stand-alone linear entry point (same kernel, same tile order rule): bit-identical
+        c = torch.empty((a, b), device=gpu_device)
+        A, W = T(d[:a]).to(gpu_device), T(d[a:]).to(gpu_device)
+        L.check(lib.gtsfm_linear_rowmajor_f32(A.data_ptr(), 256, a, None, 256, W.data_ptr(), 256, None, b, None, c.data_ptr(), b, 0, None, 0, 0.0625, 0, _stream()),
+                "linear_rowmajor")
+        np.testing.assert_array_equal(c.cpu().numpy(), got[:a, :b])  # (widths that are no multiple of 4 take scalar stores there: same arithmetic)
+        off += size
+
+
 def test_sinkhorn_batch_composition_does_not_change_a_pair(lib, gpu_device):
     """Which sweep kernel a pair takes depends on its own width only: a pair alone, next to a wider pair (which adds the
     workgroup-per-row launches and more register chunks per wave) and next to a narrower one gives the same u, v bit for bit."""
