@@ -1002,6 +1002,8 @@ def main() -> None:
                     result["secondary"]["headline_per_pair_first_layer"] = leg("unshared", unshared_rate, args, detector, matcher, images, pairs, shapes, mk)
                 if args.matcher == "lightglue":
                     result["secondary"]["lightglue_adaptive_depth"] = leg("adaptive", adaptive_depth_rate, args, detector, device, images, pairs, shapes)
+                    if args.keypoints > 1024:
+                        result["secondary"]["lightglue_adaptive_realistic"] = leg("adaptive_realistic", adaptive_realistic_rate, args, detector, device, h, w, not args.no_cpu_baseline)
                 result["secondary"]["verifier_stage"] = leg("verifier", verifier_rate, pipe, feats, res, h, w, ms_per_step, device, not args.no_cpu_baseline)
                 result["secondary"]["plugin_api"] = leg("plugin_api", plugin_api_rate, args, pipe, views_np, device, h, w)
                 result["secondary"]["config2_superpoint_480x640"] = leg("config2", config2_superpoint_rate, lib, detector, device, not args.no_cpu_baseline)
@@ -1121,6 +1123,84 @@ def adaptive_depth_rate(args, detector, device, images, pairs, shapes):
             "pairs_per_step": len(pairs), "matcher_layers_run": {"mean": round(float(layers.mean()), 2), "min": int(layers.min()), "max": int(layers.max())},
             "keypoints_alive_at_assignment": round(float(kept.mean()), 1), "matches_per_pair": round(nm / max(1, len(pairs)), 1),
             "workload": f"the first {len(pairs)} pairs of the headline workload with synthetic token-confidence heads that fire (conf_bias 1, conf_gain 4): adaptive depth / width on the device"}
+
+
+ADAPTIVE_HEADS = dict(delta_gain=0.25, conf_bias=4.5, conf_gain=30.0, conf_ramp=0.6, conf_shared_direction=True, match_bias=-3.5, match_gain=40.0)
+
+
+def adaptive_realistic_rate(args, detector, device, h, w, with_oracle: bool):
+    """LightGlue as the reference configures it -- `LightGlue(features=...)` with upstream's adaptive depth (0.95) and width (0.99) defaults,
+    gtsfm/frontend/matcher/lightglue_matcher.py:41 -- on a workload where BOTH mechanisms fire and pairs differ: 250 exhaustive pairs of 23 views cut
+    from four canvases of different texture scale (synthetic.synthetic_mixed_scene: overlaps of 100 % .. ~30 % inside a canvas, unrelated pairs across
+    canvases, like a real exhaustive visibility graph) with token-confidence heads whose confidence grows with depth at an image-dependent level and
+    matchability heads that declare a share of the keypoints unmatchable (ADAPTIVE_HEADS; chosen with tools/tune_adaptive_leg.py). Pairs leave the
+    batch at different layers inside one launch sequence and both images of a pair are pruned to different widths: the ragged device-side control flow
+    production hits. Reported: the rate, the distribution of layers run and of keypoints alive at the assignment, and a parity check of five pairs
+    (one per distinct stop layer where there are that many) against the oracle on the GPU's own features: stop layer, match indices, scores.
+    Synthetic heads: the SHAPE of the distributions is a construction, not a prediction for real checkpoints."""
+    from gtsfm_amd import parallel
+    from gtsfm_amd.runtime import matcher_engine as ME
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+
+    sd = synthetic.synthetic_lightglue_state_dict(**ADAPTIVE_HEADS)
+    matcher = ME.LightGlueEngine(sd, device)
+    pipe = FrontEndPipeline(detector, matcher, max_keypoints=args.keypoints, pair_chunk=args.pair_chunk, num_streams=args.streams,
+                            use_graphs=bool(args.graphs), share_first_layer=bool(args.share_first_layer))
+    n = fewest_images_for(SIDE_LEG_PAIRS)
+    pairs = parallel.exhaustive_pairs(n)[:SIDE_LEG_PAIRS]
+    images = torch.from_numpy(synthetic.synthetic_mixed_scene(n, h, w, canvases=4)).to(device)
+    shapes = [(h, w)] * n
+    state = {}
+
+    def step():
+        state["feats"] = pipe.detect(images)
+        return pipe.match(state["feats"], pairs, shapes)
+
+    res, timing = _time_steps(step, SECONDARY_STEPS, 1, device)
+    ms = timing["ms_per_step"]
+    stop = torch.cat([r["stop"] for r in res]).cpu().numpy().astype(np.int64)
+    kept = torch.cat([r["kept"] for r in res]).cpu().numpy().reshape(-1).astype(np.float64)
+    nm = np.array([len(v) for v in FrontEndPipeline.matches_to_numpy(res).values()])
+    k = float(args.keypoints)
+    out = {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", **timing, "pairs_per_step": len(pairs), "images_per_step": n,
+           "matcher_layers_run": {"mean": round(float(stop.mean()), 2), "histogram_layers_1_to_9": np.bincount(stop, minlength=10)[1:10].tolist()},
+           "keypoints_alive_at_assignment_share": {q: round(float(np.quantile(kept, v)) / k, 3) for q, v in (("min", 0.0), ("p25", 0.25), ("median", 0.5), ("p75", 0.75), ("max", 1.0))},
+           "matches_per_pair": {"mean": round(float(nm.mean()), 1), "max": int(nm.max())},
+           "heads": ADAPTIVE_HEADS,
+           "workload": f"{len(pairs)} exhaustive pairs of {n} synthetic {h}x{w} views from 4 canvases of different texture scale (synthetic_mixed_scene), top-{args.keypoints} "
+                       "keypoints, LightGlue with upstream's adaptive depth / width defaults and synthetic heads that fire at pair-dependent depths"}
+    if with_oracle:
+        from oracle import lightglue_oracle
+
+        feats = state["feats"]
+        cnt = feats["count"].cpu().numpy()
+        flat = [(q, r) for r in res for q in range(len(r["pairs"]))]
+        picked, seen = [], set()
+        for idx, (q, r) in enumerate(flat):  # one pair per distinct stop layer, cheapest (earliest) layers first, five at most
+            layer = int(stop[idx])
+            if layer not in seen:
+                seen.add(layer)
+                picked.append((layer, idx, q, r))
+        picked = sorted(picked)[:5]
+        T = torch.from_numpy
+        checks, t0 = [], time.perf_counter()
+        for layer, idx, q, r in picked:
+            i, j = r["pairs"][q]
+            row = sum(a + b for a, b in zip(r["n0"][:q], r["n1"][:q]))
+            a = r["n0"][q]
+            got_m = r["matches"][row : row + a].cpu().numpy().astype(np.int64)
+            got_s = r["mscores"][row : row + a].cpu().numpy()
+            kp = [feats["xy"][v, : cnt[v]].cpu().numpy() for v in (i, j)]
+            de = [feats["descriptors"][v, : cnt[v]].cpu().numpy() for v in (i, j)]
+            with torch.no_grad():
+                ref = lightglue_oracle.lightglue_forward(sd, T(kp[0])[None], T(kp[1])[None], T(de[0])[None], T(de[1])[None], (h, w), (h, w))
+            ref_m = ref["matches0"][0].numpy().astype(np.int64)
+            equal = bool(np.array_equal(got_m, ref_m))
+            checks.append({"pair": [int(i), int(j)], "layers_run": layer, "oracle_layers_run": int(ref["stop"]), "matches": int((ref_m > -1).sum()), "matches_equal": equal,
+                           "max_dscore": float(np.abs(got_s - ref["matching_scores0"][0].numpy()).max()) if equal else None})
+        out["parity_check"] = {"pairs": checks, "oracle_s": round(time.perf_counter() - t0, 1),
+                               "within_tolerance": bool(all(c["matches_equal"] and c["layers_run"] == c["oracle_layers_run"] and c["max_dscore"] < 1e-4 for c in checks))}
+    return out
 
 
 SECONDARY_STEPS = 3  # timed steps of every secondary leg (each step bracketed by a device synchronisation; the MEDIAN is reported, min / max beside it)

@@ -47,4 +47,5 @@ struct AttnParams {
 size_t attention_workspace_floats(int nproblems, int heads, int max_q, int max_k, size_t rows, int math);
 int attention_math_from_env();      // GTSFM_ATTENTION_MATH=bf16x3 -> ATTN_MATH_BF16X3, else ATTN_MATH_F32 (read per call)
 int attention_segments(int max_k);  // key segments a launch must provide for when no problem has more than max_k keys (an upper bound: 512-key segments)
+bool attention_parks_in_workspace();  // the double-buffered build: fused launches on two streams must not share one workspace
 int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t stream);

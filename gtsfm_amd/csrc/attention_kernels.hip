@@ -938,6 +938,9 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
 // segments a problem does not have exit at once; 1 = no problem of the launch can have more than one segment.
 static int at_segments(int max_k) { return ceil_div(ceil_div(max_k < 1 ? 1 : max_k, AT_KT), AT_SEG_MIN_TILES); }
 int attention_segments(int max_k) { return at_segments(max_k); }
+// true in the double-buffered build (-DATD_DBUF=1): the fused schedule parks its merged state in ONE slab of the caller's workspace indexed by
+// blockIdx, so two fused launches must not share that workspace concurrently (the two-stream form of a pair checks this)
+bool attention_parks_in_workspace() { return ATD_PARK_GLOBAL != 0; }
 
 // The split schedule pays one extra round trip of O through the workspace; it is chosen when the unsplit launch would not fill
 // the chip's workgroup slots (256 CUs x ATD_WGS_PER_CU) twice and the keys span more than one segment. Measured (MI355X,

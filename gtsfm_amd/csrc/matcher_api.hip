@@ -827,7 +827,17 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
         int row0, rows, tile0, seq0, nseq;
         hipStream_t stream;
     };
-    const bool two = side_stream_ != nullptr && npairs == 1 && phase != 1 && attn_math == ATTN_MATH_F32;
+    // (the double-buffered attention build parks every fused launch's merged state in one workspace slab: no two launches side by side there)
+    const bool two = side_stream_ != nullptr && npairs == 1 && phase != 1 && attn_math == ATTN_MATH_F32 && !attention_parks_in_workspace();
+    // Any early return below (a failed launch, a failed event call) leaves kernels queued on side_stream that `stream` never waited for, while the
+    // caller owns workspace and outputs in `stream`'s order only: drain the side stream before the error leaves this function.
+    struct SideStreamGuard {
+        hipStream_t side;
+        bool armed;
+        ~SideStreamGuard() {
+            if (armed) (void)hipStreamSynchronize(side);
+        }
+    } side_guard = {(hipStream_t)side_stream_, two};
     View views[2];
     int nviews = 1;
     views[0] = {0, d.Tp, 0, 0, nseq, stream};
@@ -1001,6 +1011,7 @@ static int lg_forward_phased(const float* wts, int num_layers, const float* matc
     TRY(launch_double_softmax_lse(sa, stream));
     TRY(launch_extract_matches(sa, 0, z_logit, filter_threshold, max0, idx0, idx1, m_int, ms_int, stream));
     TRY(launch_lg_scatter_matches(seqs, final_cnt, ind_final, m_int, ms_int, nseq, d.max_n, d.T, matches_dev, mscores_dev, stream));
+    side_guard.armed = false;  // the last layer joined the side stream back into `stream`
     return GTSFM_OK;
 }
 

@@ -125,25 +125,39 @@ class _ImageEntry:
         self.kpts, self.scores, self.x, self.ready, self.stream, self.digest = kpts, scores, x, ready, stream, digest
 
 
+_WARNED_SLOW_DIGEST = False
+
+
 def _full_digest(arrays: Sequence[np.ndarray]) -> bytes:
-    """Checksum over EVERY byte of an image's host arrays (xxh3-128 where the xxhash package is importable: 0.4 ms per 5000 x 256 float32
-    descriptor matrix; zlib.crc32 + adler32 otherwise: 7 ms). The per-call path's image cache is validated against it on every hit, while the
-    GPU already works on the pair (``_MatcherBase._entries_still_valid``): a cached image can never be served for changed arrays."""
+    """Checksum over EVERY byte of an image's host arrays. The per-call path's image cache is validated against it on every hit, while the GPU already
+    works on the pair (``_MatcherBase._entries_still_valid``): a cached image can never be served for changed arrays.
+
+    With the ``xxhash`` package (an OPTIONAL dependency: INTEGRATION.md section 3): xxh3-128, 0.4 ms per 5000 x 256 float32 descriptor matrix -- far
+    inside the 9 - 11 ms the GPU spends on the pair, so the check costs a call nothing. Without it: ``hashlib.blake2b`` (16-byte digest, standard library,
+    ~5 ms per matrix): two images per hit then cost about what the GPU does, the per-call path becomes host-bound, and a warning says so once. Either way
+    the digest is 128 bits (the round-5 fallback was 64 bits of crc32 + adler32)."""
     try:
         import xxhash
-
+    except ImportError:
+        xxhash = None
+    if xxhash is not None:
         h = xxhash.xxh3_128()
         for a in arrays:
             h.update(np.ascontiguousarray(a))
         return h.digest()
-    except ImportError:
-        import zlib
+    import hashlib
+    import warnings
 
-        crc = adler = 0
-        for a in arrays:
-            buf = np.ascontiguousarray(a)
-            crc, adler = zlib.crc32(buf, crc), zlib.adler32(buf, adler)
-        return crc.to_bytes(4, "little") + adler.to_bytes(4, "little")
+    global _WARNED_SLOW_DIGEST
+    if not _WARNED_SLOW_DIGEST:
+        _WARNED_SLOW_DIGEST = True
+        warnings.warn("gtsfm_amd: the `xxhash` package is not installed; the per-call image cache validates its hits with hashlib.blake2b instead "
+                      "(~5 ms per 5000 x 256 descriptor matrix: about the GPU time of a pair). Install xxhash, or set GTSFM_PLUGIN_IMAGE_CACHE=0.",
+                      RuntimeWarning, stacklevel=2)
+    h = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        h.update(np.ascontiguousarray(a))
+    return h.digest()
 
 
 class _MatcherBase:

@@ -242,11 +242,16 @@ def synthetic_lightglue_state_dict(
     conf_gain: float = 1.0,
     match_bias: float = 2.0,
     match_gain: float = 4.0,
+    conf_ramp: float = 0.0,
+    conf_shared_direction: bool = False,
 ) -> StateDict:
     """Seeded LightGlue(features="superpoint") weights, upstream module names.
 
     ``conf_bias`` / ``conf_gain`` shape the token-confidence heads and ``match_bias`` / ``match_gain`` the matchability
-    heads so that early stopping and point pruning can be exercised (or suppressed) by tests.
+    heads so that early stopping and point pruning can be exercised (or suppressed) by tests; ``conf_ramp`` adds ``ramp * layer`` to the
+    token-confidence bias (confidence that grows with depth, so that pairs leave at DIFFERENT layers); ``conf_shared_direction`` gives every layer's
+    token-confidence head the direction of layer 0's (the residual stream is dominated by the input descriptors, so a keypoint's confidence then
+    depends on its image's descriptor statistics plus the ramp: images of different texture become confident at different depths).
     """
     gen = torch.Generator().manual_seed(seed)
     sd: StateDict = {}
@@ -278,8 +283,10 @@ def synthetic_lightglue_state_dict(
         sd[f"log_assignment.{l}.final_proj.bias"] = b
         if l < num_layers - 1:
             w, b = _linear_init(gen, 1, 256)
+            if conf_shared_direction and l > 0:  # (the generator is advanced all the same: every other tensor keeps its values)
+                w = sd["token_confidence.0.token.0.weight"] / conf_gain
             sd[f"token_confidence.{l}.token.0.weight"] = w * conf_gain
-            sd[f"token_confidence.{l}.token.0.bias"] = b + conf_bias
+            sd[f"token_confidence.{l}.token.0.bias"] = b + conf_bias + conf_ramp * l
     return {k: v.contiguous() for k, v in sd.items()}
 
 

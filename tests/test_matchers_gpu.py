@@ -506,6 +506,54 @@ def test_lightglue_batch_mixed_depths(gpu_device):
     assert stops == singles
 
 
+def test_lightglue_batch_mixed_depths_and_widths_beyond_2048_keypoints(gpu_device):
+    """the ragged / pruned path at the sizes production hits. 28 pairs of 8 views from four canvases of different texture
+    scale, top-2304 keypoints (past the one-wave sweeps' 2048 columns and LightGlue's 1536-keypoint pruning threshold), bench.py's ADAPTIVE_HEADS: pairs
+    leave ONE launch sequence at different layers and BOTH images of a pair are pruned, to different widths. Every checked pair must equal its stand-alone
+    result bit for bit (one pair per distinct stop layer), and two of them the oracle (stop layer, match indices, scores within 1e-4)."""
+    import bench
+    from gtsfm_amd import parallel
+    from gtsfm_amd.runtime.matcher_engine import LightGlueEngine
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+    from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+
+    k, n, hw = 2304, 8, (1024, 1024)
+    sd = synthetic.synthetic_lightglue_state_dict(**bench.ADAPTIVE_HEADS)
+    eng = LightGlueEngine(sd, gpu_device)
+    pipe = FrontEndPipeline(SuperPointEngine(synthetic.synthetic_superpoint_state_dict(), gpu_device), eng, max_keypoints=k, pair_chunk=32, use_graphs=False)
+    feats = pipe.detect(torch.from_numpy(synthetic.synthetic_mixed_scene(n, *hw, canvases=4)).to(gpu_device))
+    assert feats["count"].tolist() == [k] * n
+    pairs = parallel.exhaustive_pairs(n)
+    res = pipe.match(feats, pairs, [hw] * n)
+    stop = torch.cat([r["stop"] for r in res]).cpu().numpy()
+    kept = torch.cat([r["kept"] for r in res]).cpu().numpy().reshape(-1, 2)
+    print("MIXED stop layers", np.bincount(stop, minlength=10)[1:].tolist(), "kept share min / median / max", kept.min() / k, np.median(kept) / k, kept.max() / k)
+    assert len(set(stop.tolist())) >= 3, stop  # pairs leave at different depths ...
+    assert ((kept[:, 0] < k) & (kept[:, 1] < k)).sum() >= 5 and (kept[:, 0] != kept[:, 1]).any()  # ... and both images are pruned, to different widths
+    xy, de = feats["xy"].cpu().numpy(), feats["descriptors"].cpu().numpy()
+    flat = [(q, r) for r in res for q in range(len(r["pairs"]))]
+    first_of_layer = {}
+    for idx, (q, r) in enumerate(flat):
+        first_of_layer.setdefault(int(stop[idx]), (idx, q, r))
+    for checked, (layer, (idx, q, r)) in enumerate(sorted(first_of_layer.items())):
+        i, j = r["pairs"][q]
+        row = sum(a + b for a, b in zip(r["n0"][:q], r["n1"][:q]))
+        m = r["matches"][row : row + 2 * k].cpu().numpy()
+        ms = r["mscores"][row : row + 2 * k].cpu().numpy()
+        single = eng.match_pair(xy[i], de[i], xy[j], de[j], hw, hw)
+        assert single["stop"] == layer
+        np.testing.assert_array_equal(m[:k], single["matches0"])
+        np.testing.assert_array_equal(m[k:], single["matches1"])
+        np.testing.assert_array_equal(ms[:k], single["matching_scores0"])
+        np.testing.assert_array_equal(single["kept"].reshape(-1), kept[idx])
+        if checked < 2:
+            with torch.no_grad():
+                ora = lgo.lightglue_forward(sd, T(xy[i])[None], T(xy[j])[None], T(de[i])[None], T(de[j])[None], hw, hw)
+            assert int(ora["stop"]) == layer
+            np.testing.assert_array_equal(m[:k], ora["matches0"][0].numpy())
+            np.testing.assert_allclose(ms[:k], ora["matching_scores0"][0].numpy(), rtol=0, atol=SCORE_TOL)
+
+
 @pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
 def test_batch_mixing_sweep_tiers_equals_single_pairs(gpu_device, matcher):
     """Score matrices of one batch on both sides of the 2048-column limit of the wave-per-row sweeps: the wide pairs take the
@@ -555,12 +603,14 @@ def test_batch_mixing_sweep_tiers_equals_single_pairs(gpu_device, matcher):
 
 @pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
 def test_extraction_tiering_does_not_change_matches(gpu_device, monkeypatch, matcher):
-    """Arg-maxima do not depend on how a row is cut into slices: the match extraction runs eight waves per row for every width
-    beyond 2048 columns by default, four waves up to 5120 with GTSFM_EXTRACT_WAVES=4 -- same matches and scores bit for bit
-    (a 2600- and a 5000-column pair in one batch)."""
+    """Arg-maxima do not depend on how a row is cut into slices, so the match extraction's launcher is free to pick its tiers (launch_extract_matches):
+    by default one wave per row up to GTSFM_EXTRACT_NARROW_COLS = 1024 columns, four waves per row for 1025 .. 5120, eight beyond;
+    GTSFM_EXTRACT_WAVES=8 sends every row above the narrow bound to the eight-wave tier, and GTSFM_EXTRACT_NARROW_COLS=2048 restores round 4's
+    one-wave bound (the 8-chunk narrow instantiation). All three must give the same matches and scores bit for bit (a 1500-, a 2600- and a
+    5000-column pair in one batch: the 1500-column pair changes tier under the second switch, the wider two under the first)."""
     from gtsfm_amd.runtime import matcher_engine as ME
 
-    specs = [(300, 2600, 41), (200, 5000, 42)]
+    specs = [(300, 2600, 41), (200, 5000, 42), (250, 1500, 43)]
     feats = [synthetic.synthetic_pair_features(a, b, (480, 640), (480, 640), seed=sd) for a, b, sd in specs]
     kp = T(np.concatenate([np.concatenate([f[0], f[3]]) for f in feats])).to(gpu_device)
     sc = T(np.concatenate([np.concatenate([f[1], f[4]]) for f in feats])).to(gpu_device)
@@ -573,13 +623,17 @@ def test_extraction_tiering_does_not_change_matches(gpu_device, monkeypatch, mat
         eng = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(num_layers=2, match_bias=-2.0, match_gain=30.0), gpu_device)
         call = lambda: eng.match_batch(kp, de, n0, n1, hw, pruning_threshold=None)  # noqa: E731
     got = {}
-    for waves in ("8", "4"):
-        monkeypatch.setenv("GTSFM_EXTRACT_WAVES", waves)
+    for name, env in (("default", {}), ("eight_waves", {"GTSFM_EXTRACT_WAVES": "8"}), ("narrow_2048", {"GTSFM_EXTRACT_NARROW_COLS": "2048"})):
+        monkeypatch.delenv("GTSFM_EXTRACT_WAVES", raising=False)
+        monkeypatch.delenv("GTSFM_EXTRACT_NARROW_COLS", raising=False)
+        for key, value in env.items():
+            monkeypatch.setenv(key, value)
         out = call()
-        got[waves] = (out["matches"].cpu().numpy(), out["mscores"].cpu().numpy())
-    assert (got["8"][0] >= 0).sum() > 20
-    np.testing.assert_array_equal(got["8"][0], got["4"][0])
-    np.testing.assert_array_equal(got["8"][1], got["4"][1])
+        got[name] = (out["matches"].cpu().numpy(), out["mscores"].cpu().numpy())
+    assert (got["default"][0] >= 0).sum() > 20
+    for name in ("eight_waves", "narrow_2048"):
+        np.testing.assert_array_equal(got["default"][0], got[name][0])
+        np.testing.assert_array_equal(got["default"][1], got[name][1])
 
 
 @pytest.mark.parametrize("matcher", ["superglue", "lightglue"])

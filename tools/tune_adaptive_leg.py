@@ -6,6 +6,7 @@ For a small grid of (delta_gain, conf_bias, conf_gain, match_bias, match_gain) r
 (synthetic.synthetic_mixed_scene: three canvases of different texture scale, overlaps 100 % .. 30 % and unrelated pairs) and prints the
 histogram of stop layers and the share of keypoints alive at the assignment."""
 import itertools
+import os
 import sys
 from pathlib import Path
 
@@ -24,17 +25,20 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 66
 dev = torch.device("cuda:0")
 det = SuperPointEngine(synthetic.synthetic_superpoint_state_dict(), dev)
-n = 12
-views = torch.from_numpy(synthetic.synthetic_mixed_scene(n, 1024, 1024)).to(dev)
+n = int(os.environ.get("VIEWS", "12"))
+import os
+CANVASES = int(os.environ.get("CANVASES", "6"))
+views = torch.from_numpy(synthetic.synthetic_mixed_scene(n, 1024, 1024, canvases=CANVASES)).to(dev)
 pairs = parallel.exhaustive_pairs(n)[:npairs]
 shapes = [(1024, 1024)] * n
 feats = None
-grid = [dict(delta_gain=dg, conf_bias=cb, conf_gain=cg, match_bias=mb, match_gain=mg)
-        for dg, cb, cg, mb, mg in itertools.product((0.25, 1.0), (0.5, 1.0, 1.5), (4.0, 8.0), (-3.0,), (8.0,))]
+KEYS = ("delta_gain", "conf_bias", "conf_gain", "conf_ramp", "match_bias", "match_gain")
+grid = [dict(zip(KEYS, v)) for v in itertools.product((0.25,), (-2.0, -1.0, 0.0, 1.0), (5.0, 10.0, 20.0, 40.0), (0.4, 0.8), (-4.6,), (40.0,))]
 if len(sys.argv) > 3:
-    grid = [dict(zip(("delta_gain", "conf_bias", "conf_gain", "match_bias", "match_gain"), map(float, a.split(",")))) for a in sys.argv[3:]]
+    grid = [dict(zip(KEYS, map(float, a.split(",")))) for a in sys.argv[3:]]
+same = np.array([(i % CANVASES) == (j % CANVASES) for i, j in pairs])  # pairs of one canvas (they overlap) against pairs across canvases (nothing shared)
 for g in grid:
-    eng = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(**g), dev)
+    eng = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(conf_shared_direction=True, **g), dev)
     pipe = FrontEndPipeline(det, eng, max_keypoints=k, pair_chunk=16 if k > 2560 else 32)
     if feats is None:
         feats = pipe.detect(views)
@@ -44,4 +48,6 @@ for g in grid:
     kept = torch.cat([r["kept"] for r in res]).cpu().numpy().reshape(-1)
     nm = np.array([int((r["matches"] > -1).sum()) // 2 for r in res]).sum() / len(pairs)
     hist = np.bincount(stop, minlength=10)[1:].tolist()
-    print(g, "stop layers 1..9:", hist, "kept share min/median/max: %.2f %.2f %.2f" % (kept.min() / k, np.median(kept) / k, kept.max() / k), "matches/pair %.0f" % nm, flush=True)
+    hs = np.bincount(stop[same], minlength=10)[1:].tolist()
+    print(",".join(str(g[key]) for key in KEYS), "| stop 1..9:", hist, "same-canvas:", hs, "| kept min/med/max %.2f %.2f %.2f" % (kept.min() / k, np.median(kept) / k, kept.max() / k),
+          "| matches/pair %.0f" % nm, flush=True)
