@@ -701,8 +701,9 @@ __global__ __launch_bounds__(256) void attention_x3_split_kernel(AttnParams p) {
 
 // The attention kernel on the split tiles: same problem / segment / schedule structure as attention_dma_kernel (128 queries of one
 // head per workgroup of 4 waves, a wave owns 32 queries, 64-key tiles, 1024-key segments merged by at_merge, fused or split
-// schedule), ONE transposed score tile per wave. Per tile and wave: 48 + 48 v_mfma_f32_32x32x16_bf16. The fused schedule parks its
-// merged state in the caller's workspace (48 KiB of LDS tiles + a 34 KiB LDS slab would leave one workgroup per CU).
+// schedule), ONE transposed score tile per wave. Per tile and wave: 48 + 48 v_mfma_f32_32x32x16_bf16. The fused schedule keeps its
+// merged state in registers (round 6; rounds 4 - 5 parked it in the caller's workspace: 48 KiB of LDS tiles + a 34 KiB LDS slab would
+// leave one workgroup per CU).
 // Measured on MI355X, round 4 (tools/bench_attention.py, 32 sequences x 4 heads at N = 5000; exact fp32: 6.17 - 6.22 ms): 3.99 - 4.02 ms
 // including the 0.17 ms split pass = 1.55 x (N = 2048, 64 sequences: 2.03 -> 1.39 ms). Four more elaborate loops were built and measured
 // within +-3 % of this one (operand reads and the P split software-pipelined under the MFMAs with sched_group_barrier; three workgroups
@@ -712,7 +713,6 @@ __global__ __launch_bounds__(256) void attention_x3_split_kernel(AttnParams p) {
 // 2.2 - 2.3 GHz. At this duty cycle the bf16 pipe is power-limited: 3 / 8 of the matrix-pipe cycles buy 1.55 x, not 2.67 x.
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
-    constexpr int NT = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_x3[];
     unsigned char* Kl = lds_x3;
     unsigned char* Vl = lds_x3 + X3_TILE_BYTES;
@@ -739,8 +739,6 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
     const int t_begin = SPLIT ? seg_of_wg * seg_tiles : 0;
     const int t_end = SPLIT ? (ntiles < t_begin + seg_tiles ? ntiles : t_begin + seg_tiles) : ntiles;
     if (SPLIT && t_begin >= ntiles) return;
-    float* Oc = p.park + (size_t)blockIdx.x * (34 * NT);  // fused schedule, more than one segment: this thread's merged (O, m, l)
-    if (!SPLIT && !p.park && ntiles > seg_tiles) __builtin_trap();
 
     if (!SPLIT && nk <= 0) {  // no keys: the output rows are zero; uniform for the workgroup
         if (qvalid) {
@@ -798,6 +796,15 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
     float m = 0.f, l = 0.f;
+    // fused schedule: the merged (O, m, l) of the segments done so far stays in REGISTERS between segments (round 6; 34 more VGPRs in a kernel that
+    // had 45 to spare). Rounds 4 - 5 parked it in a workgroup-private slab of the workspace -- 34 floats per thread written and read back at every
+    // segment boundary: 1.35 GB written + ~1.2 GB re-fetched per 32-sequence launch at N = 5000 with round 6's 8 segments (0.86 GB with five),
+    // half of the launch's HBM-side traffic (profiles/r06_pmc_traffic.json, collected before this change) -- because this kernel's 48 KiB of LDS
+    // tiles leave no room for the 34 KiB slab the exact-fp32 kernel parks in. Same values, same merge: bit-identical.
+    f32x16 pk0, pk1;
+    float pkm = 0.f, pkl = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pk0[r] = pk1[r] = 0.f;
 
     tile_dma(0, t_begin, Kl);
     tile_dma(1, t_begin, Vl);
@@ -886,28 +893,27 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
             __syncthreads();
             tile_dma(1, t + 1, Vl);
         }
-        // ---- fused schedule, end of a segment: fold (O, m, l) into the merged state parked in the workspace
+        // ---- fused schedule, end of a segment: fold (O, m, l) into the merged state (registers pk0 / pk1 / pkm / pkl)
         const bool seg_end = more && ts == seg_tiles - 1;
         if (!SPLIT && (seg_end || (!more && t >= seg_tiles))) {
             if (t >= seg_tiles) {
-                const AtMergeWeights w = at_merge_weights(Oc[32 * NT + tid], m);
+                const AtMergeWeights w = at_merge_weights(pkm, m);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    o0[r] = at_merge(Oc[r * NT + tid], o0[r], w);
-                    o1[r] = at_merge(Oc[(16 + r) * NT + tid], o1[r], w);
+                    o0[r] = at_merge(pk0[r], o0[r], w);
+                    o1[r] = at_merge(pk1[r], o1[r], w);
                 }
-                l = at_merge(Oc[33 * NT + tid], l, w);
+                l = at_merge(pkl, l, w);
                 m = w.m;
             }
             if (more) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    Oc[r * NT + tid] = o0[r];
-                    Oc[(16 + r) * NT + tid] = o1[r];
+                    pk0[r] = o0[r];
+                    pk1[r] = o1[r];
                     o0[r] = o1[r] = 0.f;
                 }
-                Oc[32 * NT + tid] = m;
-                Oc[33 * NT + tid] = l;
+                pkm = m, pkl = l;
                 m = 0.f, l = 0.f;
             }
         }
@@ -978,15 +984,14 @@ static size_t x3_split_floats(int nproblems, int heads, int max_k) {  // K and V
 // Sized from the launch GEOMETRY, never from GTSFM_ATTENTION_SPLIT: a workspace is held across calls (the pipeline's per-stream
 // workspaces, captured graphs, callers' own) while the switch is read per launch. A launch that wants the split schedule and finds
 // the workspace too small (the switch was turned on after sizing) runs the fused schedule instead -- the two are bit-identical.
-// The arithmetic mode is the caller's statement (it changes results): bf16x3 adds the split K / V^T tiles and always parks the fused
-// schedule's merged state in the workspace.
+// The arithmetic mode is the caller's statement (it changes results): bf16x3 adds the split K / V^T tiles.
 size_t attention_workspace_floats(int nproblems, int heads, int max_q, int max_k, size_t rows, int math) {
     if (nproblems <= 0) return 0;
     const bool x3 = math == ATTN_MATH_BF16X3;
     const size_t base = x3 ? x3_split_floats(nproblems, heads, max_k) : 0;
     if (at_segments(max_k) < 2) return base;  // one segment: neither schedule needs memory
     const size_t split = (size_t)at_segments(max_k) * rows * ((size_t)heads * 64 + (size_t)heads * 2);
-    const size_t park = x3 ? (size_t)ceil_div(heads * nproblems, 8) * 8 * ceil_div(max_q, AT_QB) * ATD_OC_FLOATS  // bf16x3: 4 waves, always in the workspace
+    const size_t park = x3 ? 0  // bf16x3: the fused schedule keeps its merged state in registers (round 6)
                            : (ATD_PARK_GLOBAL ? (size_t)at_fused_grid(nproblems, heads, max_q) * (ATD_OC_FLOATS / 4 * at_fused_waves()) : 0);  // exact fp32, single buffers: parked in LDS
     return base + (at_geometry_wants_split(nproblems, heads, max_q, max_k) ? (split > park ? split : park) : park);
 }
@@ -1021,13 +1026,8 @@ static int launch_attention_x3(const AttnParams& p, int nproblems, int max_q, hi
         hipLaunchKernelGGL((attention_x3_kernel<true>), grid, dim3(256), X3_LDS_BYTES, stream, q);
         hipLaunchKernelGGL(attention_combine_kernel, dim3(ceil_div(max_q, 4), nproblems), dim3(256), 0, stream, q);
     } else {
-        q.nseg = 1;
+        q.nseg = 1;  // (the merged state between segments lives in registers: no parking space)
         dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles);
-        if (nseg > 1) {
-            const size_t need_park = (size_t)grid.x * (ATD_OC_FLOATS);
-            GTSFM_CHECK_ARG(rest_floats >= need_park, "attention (bf16x3): workspace too small for the merged states of the fused schedule (%zu < %zu floats)", rest_floats, need_park);
-            q.park = rest;
-        }
         hipLaunchKernelGGL((attention_x3_kernel<false>), grid, dim3(256), X3_LDS_BYTES, stream, q);
     }
     GTSFM_CHECK_LAUNCH("attention kernel (bf16x3)");

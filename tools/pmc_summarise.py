@@ -15,6 +15,7 @@ import os
 import sys
 
 out = sys.argv[1]
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "r06"  # prefix of the traffic file bench.py reads (bench.PMC_TRAFFIC_FILE)
 
 
 def collect(tag_dir):
@@ -56,9 +57,9 @@ def by_grid(tag, needle):
     return res
 
 
-traffic = {"_comment": ("HBM-side traffic from rocprofv3 PMC passes of ROUND 5, on the round's final tree (tools/prof_r05.sh -> tools/pmc_summarise.py; FETCH_SIZE and WRITE_SIZE in "
+traffic = {"_comment": (f"HBM-side traffic from rocprofv3 PMC passes of round {ROUND[1:].lstrip('0')}, on the round's final tree (tools/prof_{ROUND}.sh -> tools/pmc_summarise.py; FETCH_SIZE and WRITE_SIZE in "
                         "separate passes, KiB units, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as reported). Counters sit at the L2's fabric side: "
-                        "Infinity-Cache hits are counted. Raw per-dispatch averages: profiles/r05_pmc_raw_summary.json. Launch shapes = the headline's (16-pair chunks at the "
+                        f"Infinity-Cache hits are counted. Raw per-dispatch averages: profiles/{ROUND}_pmc_raw_summary.json. Launch shapes = the headline's (16-pair chunks at the "
                         "5000-keypoint cap).")}
 n, pairs, nseq, cap = 5000, 16, 32, 5120
 rows = 2 * pairs * cap
@@ -90,6 +91,12 @@ sg = [(g, v) for g, v in gem.items() if g.isdigit() and int(g) == (-(-(-(-n // 1
 if sg:
     traffic[f"gemm_dma_walk_kernel@{n}x256x{n}"] = {"launch_shape": f"score matrix of one pair: {n} x 256 -> {n}", "fetch_bytes": sg[0][1][0], "write_bytes": sg[0][1][1],
                                                   "algorithmic_bytes": 4 * (2 * n * 256 + n * n)}
+# the chunk's score matrices as ONE ragged launch (gtsfm_score_matrices_f32 = what the forward issues): grid = the one-pair grid x `pairs` problems
+one_pair_grid = (-(-(-(-n // 128)) // 8) * 8) * -(-n // 128) * 256
+sb = [(g, v) for g, v in gem.items() if g.isdigit() and int(g) == one_pair_grid * pairs]
+if sb:
+    traffic[f"score_matrices@{pairs}x{n}"] = {"launch_shape": f"score matrices of {pairs} pairs in one ragged launch: {n} x 256 -> {n} each", "fetch_bytes": sb[0][1][0],
+                                             "write_bytes": sb[0][1][1], "algorithmic_bytes": 4 * pairs * (2 * n * 256 + n * n)}
 sr, sc = per_launch("all", "sinkhorn_rows"), per_launch("all", "sinkhorn_cols_kernel")
 if sr and sc:
     traffic[f"sinkhorn_iteration@{pairs}x{n}"] = {"launch_shape": f"{pairs} pairs, ({n}+1) x ({n}+1) couplings, one iteration = rows + cols kernel", "fetch_bytes": sr[0] + sc[0],
@@ -120,7 +127,7 @@ if x3:
     traffic[f"attention_x3_kernel@{nseq}x4x{n}"] = {"launch_shape": f"{nseq} sequences x 4 heads, N = {n} (attention_x3_kernel, fused schedule)", "fetch_bytes": x3[0], "write_bytes": x3[1]}
 if x3s:
     traffic[f"attention_x3_split_kernel@{nseq}x4x{n}"] = {"launch_shape": f"K and V of {nseq} sequences x 4 heads, N = {n} -> three bf16 pieces each", "fetch_bytes": x3s[0], "write_bytes": x3s[1]}
-json.dump(traffic, open(out + "/r05_pmc_traffic.json", "w"), indent=1)
+json.dump(traffic, open(out + f"/{ROUND}_pmc_traffic.json", "w"), indent=1)
 for k, v in traffic.items():
     if isinstance(v, dict):
         fb, wb = v.get("fetch_bytes", v.get("fetch_bytes_per_image")), v.get("write_bytes", v.get("write_bytes_per_image"))
