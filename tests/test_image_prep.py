@@ -44,6 +44,51 @@ def test_oracle_resize_properties():
     assert ipo.downsampled_size(480, 640, 760) == (480, 640)
 
 
+def test_sizing_rule_reproduces_the_references_known_answers():
+    """The one part of the input step the reference's own tests pin with numbers: ``get_downsampling_factor_per_axis``
+    (tests/utils/test_image_utils.py:36-48 leave-intact, :64-81 landscape, :100-117 portrait). Oracle and product rule give the same sizes."""
+    from gtsfm_amd.runtime.image_prep import downsampled_size
+
+    for fn in (ipo.downsampled_size, downsampled_size):
+        assert fn(700, 1500, 800) == (700, 1500)   # shorter side already fits: untouched
+        assert fn(700, 1500, 600) == (600, 1286)   # 1500 * 600 / 700 = 1285.7 -> 1286
+        assert fn(1500, 700, 600) == (1286, 600)   # portrait
+
+
+REFERENCE = __import__("pathlib").Path(__import__("os").environ.get("GTSFM_REFERENCE", "/root/reference"))
+
+
+@pytest.mark.skipif(not (REFERENCE / "gtsfm" / "utils" / "images.py").exists(), reason="the reference tree is only mounted in the build container")
+def test_sizing_rule_equals_the_reference_function_run_live():
+    """``gtsfm/utils/images.py:189-220`` itself (imported from /root/reference in a subprocess, the absent third-party packages replaced by inert
+    stand-ins as in oracle/validate_wrappers_against_reference.py; the function is pure arithmetic) over 400 seeded (height, width, max_resolution)
+    triples: the same target size as the oracle's and the product's rule, every time."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import REPO
+    from gtsfm_amd.runtime.image_prep import downsampled_size
+
+    rng = np.random.default_rng(17)
+    cases = [(int(h), int(w), int(r)) for h, w, r in zip(rng.integers(40, 4000, 400), rng.integers(40, 4000, 400), rng.integers(32, 2000, 400))]
+    code = (
+        "import json, sys\n"
+        f"sys.path.insert(0, {str(REPO / 'oracle')!r}); sys.path.insert(0, {str(REPO)!r})\n"
+        "from validate_cache_against_reference import _AbsentPackages\n"
+        "sys.meta_path.insert(0, _AbsentPackages())\n"
+        f"sys.path.insert(0, {str(REFERENCE)!r})\n"
+        "import gtsfm.utils.images as I\n"
+        "cases = json.loads(sys.stdin.read())\n"
+        "print(json.dumps([[int(v) for v in I.get_downsampling_factor_per_axis(h, w, r)[2:]] for h, w, r in cases]))\n"
+    )
+    run = subprocess.run([sys.executable, "-c", code], input=json.dumps(cases), capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    ref = [tuple(v) for v in json.loads(run.stdout.strip().splitlines()[-1])]
+    assert ref == [ipo.downsampled_size(*c) for c in cases] == [downsampled_size(*c) for c in cases]
+    assert sum(1 for c, r in zip(cases, ref) if r != c[:2]) > 100  # the sweep does exercise the downsizing branch
+
+
 @pytest.mark.parametrize("h,w,nh,nw", [(300, 200, 120, 80), (484, 324, 283, 190), (97, 131, 64, 64), (64, 64, 200, 150)])
 def test_oracle_resize_agrees_with_an_independent_float_bicubic(h, w, nh, nw):
     """Independent anchor for the unpinned restatement: ATen's float64 bicubic (same half-pixel mapping, same A = -0.75
