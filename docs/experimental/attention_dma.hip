@@ -31,8 +31,8 @@
 // per CU, the default here) and spills 65 when held to 168 (-DAT_WGS_PER_CU=3). Both are to be measured; if two fat
 // waves per SIMD with intra-wave overlap lose to three thin ones, the next step is pipelining at 32-key granularity.
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-honor-nans tools/experimental/attention_dma.hip -o tools/experimental/attention_dma
-//   tools/experimental/attention_dma            self-check against an fp64 CPU reference (ragged, small), then timing
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-honor-nans docs/experimental/attention_dma.hip -o docs/experimental/attention_dma
+//   docs/experimental/attention_dma            self-check against an fp64 CPU reference (ragged, small), then timing
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

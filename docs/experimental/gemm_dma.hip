@@ -15,8 +15,8 @@
 // (+0.4) and raised wave priority outside the MFMA steps (+1). -DTM256 (256 x 128 tile, 8 waves, one workgroup per CU)
 // measured 72.6 / 78.9 %: worse than two 128 x 128 workgroups per CU.
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/experimental/gemm_dma.hip -o tools/experimental/gemm_dma
-//   tools/experimental/gemm_dma [M K N]        self-check against a CPU fp64 reference on sampled entries, then timing
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off docs/experimental/gemm_dma.hip -o docs/experimental/gemm_dma
+//   docs/experimental/gemm_dma [M K N]        self-check against a CPU fp64 reference on sampled entries, then timing
 //
 // LDS image of one operand stage: [128 rows][32 floats] = 128 B per row = eight 16-byte chunks; chunk c of row r is
 // stored at chunk position c ^ ((r >> 1) & 7). A ds_read_b128 of fragment chunk (2 s + kh) by the 16 lanes of one LDS

@@ -12,7 +12,7 @@
 // of the second product O^T[d][q] += V^T[d][key] P^T[key][q] -- no LDS round trip for P, no layout shuffles. A second
 // score tile lives in registers so that the softmax of tile t runs in the shadow of the S MFMAs of tile t + 1 inside
 // one wave. Per 64-key tile and wave: 64 + 64 v_mfma_f32_32x32x2_f32. Derivation, LDS-bank argument and the round-1 /
-// round-2 measurements (register-staged predecessor, double-buffered K/V, ...): tools/experimental/attention_dma.hip, DESIGN.md.
+// round-2 measurements (register-staged predecessor, double-buffered K/V, ...): docs/experimental/attention_dma.hip, docs/HISTORY.md.
 //
 // Key SEGMENTS (round 3; their length a function of the problem's size since round 6: at_seg_tiles below). The keys of a problem are cut into
 // segments of 8 .. 16 tiles (512 .. 1024 keys). Every segment runs

@@ -11,7 +11,7 @@
 
 // ---------------------------------------------------------------------------------------------------------------
 // GEMM with both operands staged by LDS-DMA (K % 32 == 0 and row-major weights available). See
-// tools/experimental/gemm_dma.hip for the derivation of the swizzle and the round-1 measurements; same contract as
+// docs/experimental/gemm_dma.hip for the derivation of the swizzle and the round-1 measurements; same contract as
 // gemm_mfma_kernel.
 // LDS image of one operand stage: [128 rows][32 floats]; 16-byte chunk c of row r sits at chunk position
 // c ^ ((r >> 1) & 7), which puts the 16 lanes of every ds_read_b128 service group on distinct banks; the DMA writes

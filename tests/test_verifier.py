@@ -98,6 +98,13 @@ def test_sampson_error_reproduces_the_references_known_answers():
     np.testing.assert_allclose(got, [6.744895e-01, 2.397196e03], rtol=1e-3)  # the reference's own tolerance
 
 
+def test_coordinate_normalisation_reproduces_the_references_known_answer():
+    """``feature_utils.normalize_coordinates`` on a distortion-free ``Cal3Bundler(fx=100, u0=20, v0=30)``, the numbers of the reference's
+    tests/utils/test_feature_utils.py:14-23 -- the first thing ``OpencvVerifierBase.verify`` does with the keypoints (opencv_verifier_base.py:74-75)."""
+    got = vo.normalize_pinhole(np.array([[10.0, 20.0], [25.0, 12.0], [30.0, 33.0]]), 100.0, 100.0, 20.0, 30.0)
+    np.testing.assert_allclose(got, [[-0.1, -0.1], [0.05, -0.18], [0.1, 0.03]], rtol=1e-12, atol=1e-15)
+
+
 def test_sampson_error_equals_the_reference_function_run_live():
     """``gtsfm/utils/verification.py:172-220`` itself, imported from /root/reference in a subprocess (gtsam / cv2 replaced by inert stand-ins: the
     function is numpy only), on 300 seeded correspondences under 20 seeded matrices: the oracle's explicit IEEE sequence agrees to 1e-9 relative."""
