@@ -49,6 +49,8 @@ def test_bf16x3_differs_from_exact_fp32_only_within_tolerance(gpu_device, monkey
     eng = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(), gpu_device)  # the weights of test_bench_shapes_gpu's N = 2048 case: > 1000 matches
     monkeypatch.setenv("GTSFM_PLUGIN_IMAGE_CACHE", "0")
     eng.image_cache_capacity = 0  # the per-image cache would hand the second run the first run's first block
+    monkeypatch.delenv("GTSFM_ATTENTION_MATH", raising=False)  # (the file also runs with both switches exported: the first run must still be exact)
+    monkeypatch.delenv("GTSFM_GEMM_MATH", raising=False)
     exact = eng.match_pair(k0, d0, k1, d1, (1024, 1024), (1024, 1024))
     monkeypatch.setenv("GTSFM_ATTENTION_MATH", "bf16x3")
     split = eng.match_pair(k0, d0, k1, d1, (1024, 1024), (1024, 1024))
