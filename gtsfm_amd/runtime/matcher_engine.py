@@ -160,63 +160,6 @@ def _full_digest(arrays: Sequence[np.ndarray]) -> bytes:
     return h.digest()
 
 
-class _PairGraph:
-    """The launch sequence of ONE pair on the per-call path (``LightGlueEngine.match_pair`` with both images resident in the engine's image
-    cache), captured once per (n0, n1, image shapes, options) on the lane that serves the call and replayed afterwards (round 6). The sequence
-    is static (adaptive depth / width run on the device) and its ~170 launches take the host ~0.5 ms to enqueue one by one; the GPU executes the
-    small ones (heads, stop check, pruning: 5 - 8 us each) faster than a busy or slow host core issues them, and four separate device-to-host
-    fetches followed each call -- on the box of the round's final run that cost 0.45 - 0.7 ms of an 11 ms call. Replay = four device-to-device
-    copies of the cached images' rows into the graph's input buffers, one graph launch, four asynchronous copies into one pinned host block, ONE
-    synchronisation. Same kernels on the same values: bit-identical to the eager path (tests/test_matchers_gpu.py). Holds its own workspace
-    (~0.5 GB at the 5000-keypoint cap), so a lane keeps at most ``GTSFM_PLUGIN_GRAPHS`` (default 2) of them, least recently used first."""
-
-    def __init__(self, eng: "LightGlueEngine", n0: int, n1: int, hw, kwargs: dict):
-        dev = eng.device
-        self.n0, self.n1, self.hw, self.kwargs = int(n0), int(n1), hw, dict(kwargs)
-        t = self.n0 + self.n1
-        self.kp = torch.empty((t, 2), dtype=torch.float32, device=dev)
-        self.x = torch.empty((t, 256), dtype=torch.float32, device=dev)
-        self.ws = torch.empty(eng.workspace_bytes([self.n0], [self.n1]) + 256, dtype=torch.uint8, device=dev)
-        self.host_m = torch.empty(t, dtype=torch.int32).pin_memory()
-        self.host_s = torch.empty(t, dtype=torch.float32).pin_memory()
-        self.host_meta = torch.empty(3, dtype=torch.int32).pin_memory()  # kept (2), stop (1)
-        self.graph = None
-        self.out = None
-
-    def _run(self, eng):
-        return eng.match_batch(self.kp, self.x, [self.n0], [self.n1], self.hw, workspace=self.ws, first_layer_done=True, **self.kwargs)
-
-    def load(self, e0, e1) -> None:
-        self.kp[: self.n0].copy_(e0.kpts, non_blocking=True)
-        self.kp[self.n0 :].copy_(e1.kpts, non_blocking=True)
-        self.x[: self.n0].copy_(e0.x, non_blocking=True)
-        self.x[self.n0 :].copy_(e1.x, non_blocking=True)
-
-    def capture(self, eng) -> None:
-        stream = torch.cuda.current_stream(eng.device)
-        with eng.pin_descriptors():  # the captured copy node reads the pristine descriptor block at its address
-            self._run(eng)           # eager warm-up on the real inputs: descriptor cache, allocator
-            stream.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: other worker threads keep launching on their own lanes while this one captures
-            with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
-                self.out = self._run(eng)
-        self.graph = graph
-
-    def replay(self) -> None:
-        self.graph.replay()
-
-    def fetch(self, eng):
-        """(matches int64 [n0 + n1], scores f32, stop, kept [2]) after ONE synchronisation."""
-        self.host_m.copy_(self.out["matches"], non_blocking=True)
-        self.host_s.copy_(self.out["mscores"], non_blocking=True)
-        self.host_meta[:2].copy_(self.out["kept"], non_blocking=True)
-        self.host_meta[2:].copy_(self.out["stop"], non_blocking=True)
-        torch.cuda.current_stream(eng.device).synchronize()
-        meta = self.host_meta.numpy()
-        return self.host_m.numpy().astype(np.int64), self.host_s.numpy().copy(), int(meta[2]), meta[:2].copy()
-
-
 class _MatcherBase:
     # what a lane shares with the engine it was made from: read-only after construction (the weight blob lives on the device)
     _SHARED_ATTRS: Tuple[str, ...] = ("device", "_lib", "weights", "num_layers", "desc_cache_capacity", "max_lanes", "pair_streams")
@@ -268,9 +211,6 @@ class _MatcherBase:
         self._lane_stream: Optional[torch.cuda.Stream] = None
         self._last_lookup: tuple = ((), [])  # what the last _image_entries call of this lane found (read by _entries_still_valid)
         self._side_stream: Optional[torch.cuda.Stream] = None  # second launch sequence of a single pair (LightGlueEngine.match_batch)
-        # captured launch sequences of the per-call path (_PairGraph), per pair shape; a shape is captured the second time it is seen
-        self._pair_graphs: "OrderedDict[tuple, _PairGraph]" = OrderedDict()
-        self._pair_shapes_seen: "OrderedDict[tuple, int]" = OrderedDict()
 
     def _sibling(self) -> "_MatcherBase":
         """An engine sharing this one's weights (read-only on the device) and nothing a call writes: built from the explicit list
@@ -320,7 +260,6 @@ class _MatcherBase:
                     self._lanes.remove(eng)
             if self in idle:
                 self._workspace = self._staging = None
-                self._pair_graphs.clear()
                 for key in [k for k in self._desc_cache if k not in self._desc_pinned]:
                     del self._desc_cache[key]
                 self._free_lanes.put(self)
@@ -797,32 +736,6 @@ class LightGlueEngine(_MatcherBase):
             out["sim"] = sim
         return out
 
-    def _pair_graph_for(self, n0: int, n1: int, hw, kwargs: dict) -> Optional[_PairGraph]:
-        """The captured launch sequence for this pair shape on THIS lane, or None when the call should run eagerly: graphs off
-        (``GTSFM_PLUGIN_GRAPHS=0``), an option a graph cannot hold (``return_sim`` allocates per call, two launch sequences per pair), or a
-        shape seen for the first time (scenes whose images are below the keypoint cap have a new shape per pair: those never pay a capture)."""
-        limit = int(os.environ.get("GTSFM_PLUGIN_GRAPHS", "2"))
-        if limit <= 0 or kwargs.get("return_sim") or kwargs.get("workspace") is not None or self.pair_streams > 1:
-            return None
-        # the library reads its schedule / arithmetic switches per launch: a captured sequence has them baked in, so they are part of the key
-        switches = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("GTSFM_")))
-        key = (int(n0), int(n1), tuple(int(v) for v in hw[0]), tuple(sorted((k, v) for k, v in kwargs.items())), switches)
-        graph = self._pair_graphs.get(key)
-        if graph is not None:
-            self._pair_graphs.move_to_end(key)
-            return graph
-        seen = self._pair_shapes_seen.get(key, 0) + 1
-        self._pair_shapes_seen[key] = seen
-        self._pair_shapes_seen.move_to_end(key)
-        while len(self._pair_shapes_seen) > 64:
-            self._pair_shapes_seen.popitem(last=False)
-        if seen < 2:
-            return None
-        while len(self._pair_graphs) >= limit:
-            self._pair_graphs.popitem(last=False)  # its workspace goes back to the allocator once the queued replays ran
-        graph = self._pair_graphs[key] = _PairGraph(self, n0, n1, hw, kwargs)
-        return graph
-
     def prepare_images(self, kpts: torch.Tensor, desc: torch.Tensor, counts: Sequence[int], shapes: Sequence[Sequence[int]],
                        workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The part of LightGlue that sees ONE image: the first layer's self block (rotary self-attention + FFN) on the keypoint
@@ -867,36 +780,23 @@ class LightGlueEngine(_MatcherBase):
             hw = [[shape0[0], shape0[1], shape1[0], shape1[1]]]
             if self.image_cache_capacity > 0 and not kwargs.get("first_layer_done", False):
                 images = [((k0, d0), shape0), ((k1, d1), shape1)]
-                graph = None
                 for attempt in range(2):  # a second round only when a cached image turned out to be stale (its entry is gone by then)
                     e0, e1 = eng._image_entries(images)
-                    graph = eng._pair_graph_for(n0, n1, hw, kwargs)
-                    if graph is not None:  # this shape's launch sequence is (or is now being) captured: copy the rows in, replay
-                        graph.load(e0, e1)
-                        if graph.graph is None:
-                            graph.capture(eng)
-                        graph.replay()
-                        out = None
-                    else:
-                        out = eng.match_batch(torch.cat([e0.kpts, e1.kpts]), torch.cat([e0.x, e1.x]), [n0], [n1], hw, **dict(kwargs, first_layer_done=True))
+                    out = eng.match_batch(torch.cat([e0.kpts, e1.kpts]), torch.cat([e0.x, e1.x]), [n0], [n1], hw, **dict(kwargs, first_layer_done=True))
                     if eng._entries_still_valid(images, (e0, e1)):
                         break
-                if out is None:
-                    m, ms, stop, kept = graph.fetch(eng)
-                    out = {"stop": [stop], "kept": kept}
             else:
                 kp, de = eng._stage_pair((k0, d0), (k1, d1))
                 out = eng.match_batch(kp, de, [n0], [n1], hw, **kwargs)
-            if "matches" in out:
-                m = out["matches"].cpu().numpy().astype(np.int64)
-                ms = out["mscores"].cpu().numpy()
-                out = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in out.items() if k in ("stop", "kept", "sim")}
+            m = out["matches"].cpu().numpy().astype(np.int64)
+            ms = out["mscores"].cpu().numpy()
+            out = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in out.items() if k in ("stop", "kept", "sim")}
         m0 = m[:n0]
         valid = m0 > -1
         res = {
             "matches": np.stack([np.flatnonzero(valid), m0[valid]], -1).astype(np.int64), "scores": ms[:n0][valid],
             "matches0": m0, "matches1": m[n0:], "matching_scores0": ms[:n0], "matching_scores1": ms[n0:],
-            "stop": int(out["stop"][0]), "kept": out["kept"].cpu().numpy() if isinstance(out["kept"], torch.Tensor) else np.asarray(out["kept"]),
+            "stop": int(out["stop"][0]), "kept": out["kept"].cpu().numpy(),
         }
         if "sim" in out:
             res["sim"] = out["sim"].cpu().numpy().reshape(n0, (n1 + 3) // 4 * 4)[:, :n1]

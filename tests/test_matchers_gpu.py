@@ -764,52 +764,6 @@ def test_image_cache_cannot_serve_an_array_overwritten_in_place(gpu_device, sg_s
 
 
 @pytest.mark.parametrize("which", ["superglue", "lightglue"])
-def test_per_call_path_replays_a_captured_launch_sequence_bit_identically(gpu_device, monkeypatch):
-    """Round 6: ``LightGlueEngine.match_pair`` with resident images captures a pair shape's launch sequence the second time it sees the shape and
-    replays it afterwards (``_PairGraph``). Replayed results == eager results (``GTSFM_PLUGIN_GRAPHS=0``) bit for bit, for pairs of the same
-    shape but different images, with early stopping and pruning active; a new shape runs eagerly; an array overwritten in place is still caught."""
-    from gtsfm_amd.runtime.matcher_engine import LightGlueEngine
-
-    sd = synthetic.synthetic_lightglue_state_dict(num_layers=4, conf_bias=1.2, conf_gain=5.0, match_bias=-1.0, match_gain=8.0)
-    sets = [synthetic.synthetic_pair_features(1700, 1700, (480, 640), (480, 640), overlap=ov, seed=sdd) for ov, sdd in ((0.6, 1), (0.2, 2), (0.9, 3))]
-    images = [(f[0], f[2]) for f in sets] + [(f[3], f[5]) for f in sets]  # six images of 1700 keypoints
-    pairs = [(0, 3), (1, 4), (2, 5), (0, 4), (1, 3)]
-    kw = dict(pruning_threshold=100)
-
-    def run(eng):
-        out = []
-        for i, j in pairs:
-            r = eng.match_pair(images[i][0], images[i][1], images[j][0], images[j][1], (480, 640), (480, 640), **kw)
-            out.append((r["matches0"].copy(), r["matches1"].copy(), r["matching_scores0"].copy(), r["stop"], r["kept"].copy()))
-        return out
-
-    monkeypatch.setenv("GTSFM_PLUGIN_GRAPHS", "0")
-    eager_eng = LightGlueEngine(sd, gpu_device)
-    eager = run(eager_eng)
-    assert not eager_eng._pair_graphs
-    monkeypatch.setenv("GTSFM_PLUGIN_GRAPHS", "2")
-    eng = LightGlueEngine(sd, gpu_device)
-    got = run(eng)
-    assert len(eng._pair_graphs) == 1 and next(iter(eng._pair_graphs.values())).graph is not None  # captured at the second pair, replayed for the rest
-    assert len({g[3] for g in eager}) >= 1 and sum(int((g[0] > -1).sum()) for g in eager) > 50
-    for a, b in zip(eager, got):
-        for x, y in zip(a, b):
-            np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
-    # another shape: eager, no second graph yet
-    other = synthetic.synthetic_pair_features(900, 800, (480, 640), (480, 640), seed=9)
-    eng.match_pair(other[0], other[2], other[3], other[5], (480, 640), (480, 640), **kw)
-    assert len(eng._pair_graphs) == 1
-    # an array overwritten in place between two replayed calls is caught by the full-buffer digest and the pair redone from the arrays
-    k0, d0 = images[0][0], images[0][1].copy()
-    first = eng.match_pair(k0, d0, images[3][0], images[3][1], (480, 640), (480, 640), **kw)
-    d0[5:900] = d0[5:900][::-1].copy()
-    second = eng.match_pair(k0, d0, images[3][0], images[3][1], (480, 640), (480, 640), **kw)
-    want = eager_eng.match_pair(k0, d0, images[3][0], images[3][1], (480, 640), (480, 640), **kw)
-    np.testing.assert_array_equal(second["matches0"], want["matches0"])
-    np.testing.assert_array_equal(second["matching_scores0"], want["matching_scores0"])
-    assert not np.array_equal(first["matches0"], second["matches0"])
-
-
 def test_threads_matching_pairs_that_share_an_image_are_bit_identical(gpu_device, sg_sd, which):
     """an image entry made on one lane's stream is consumed on another lane's as soon as it is in the cache; the event
     consumers wait for must cover the entry's keypoint / score clones as well as the per-image block's output. Six pairs over four images
