@@ -33,6 +33,7 @@
 
 #include "attention_kernels.h"
 #include "bf16x3.h"
+#include "f16x2.h"
 #include "mfma_tiles.h"
 
 #define AT_KT 64       // keys per tile
@@ -623,19 +624,30 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(AttnParams p) {
 // (row >> 1) & 7: the 16 lanes of a ds_read_b128 group read 16 consecutive rows at one logical chunk -> 16 distinct (bank group,
 // chunk) positions, conflict-free; the DMA applies the swizzle on the global side (lane-linear LDS image).
 // Keys beyond a problem's count are written as zeros by the split kernel (their scores are masked to -inf, P = 0 meets V = 0).
+//
+// Second opt-in arithmetic (round 6, GTSFM_ATTENTION_MATH=f16x2, AttnParams::math = 2; f16x2.h): the same kernels with NP = 2 fp16 pieces per
+// operand and THREE v_mfma_f32_32x32x16_f16 per block (lo hi, hi lo, hi hi) -- half the matrix-pipe work of bf16x3 and a third less LDS
+// traffic (two 8 KiB pieces per tile and tensor), at the same per-term error class (<= 2^-22 |x y| + an absolute floor of 2^-25 (|x| + |y|)).
+// fp16 has no headroom above 65504, so the softmax weights are kept in range by the kernel itself: in this mode the reference exponent sits
+// P_SHIFT = 7 BELOW the running maximum after a rebase (weights <= 2^7 then, and <= 2^15 before the next rebase at AT_REBASE + 7), which also
+// lifts the small weights of a row out of fp16's subnormal range: a weight 2^-21 of the row's largest is still a normal fp16. O / l does not
+// depend on the reference. K, V and the pre-scaled Q are split as they are; a value beyond +-65504 gives inf -> NaN outputs (never a clamp).
 // ---------------------------------------------------------------------------------------------------------------------
 
-#define X3_PIECE_BYTES 8192               // one bf16 piece of a 64 x 64 tile
-#define X3_TILE_BYTES (3 * X3_PIECE_BYTES)  // hi | mid | lo
-#define X3_LDS_BYTES (2 * X3_TILE_BYTES)    // K tile + V^T tile, single-buffered
+#define X3_PIECE_BYTES 8192               // one 16-bit piece of a 64 x 64 tile
+#define X3_TILE_BYTES(NP) ((NP) * X3_PIECE_BYTES)  // hi | mid | lo (bf16x3), hi | lo (f16x2)
+#define X3_LDS_BYTES(NP) (2 * X3_TILE_BYTES(NP))   // K tile + V^T tile, single-buffered
+#define X3_P_SHIFT 7.0f                   // f16x2: the softmax reference sits this far (base-2 units) below the running maximum after a rebase
 
-// Byte offset of tile (tensor ten = 0: K, 1: V^T; piece; head h; problem g; key tile t) in the split buffer.
-__device__ __forceinline__ size_t x3_tile_offset(const AttnParams& p, int ten, int piece, int h, int g, int t) {
-    return ((((size_t)(ten * 3 + piece) * p.heads + h) * p.nproblems + g) * p.x3_tiles + t) * X3_PIECE_BYTES;
+// Byte offset of tile (tensor ten = 0: K, 1: V^T; piece of np; head h; problem g; key tile t) in the split buffer.
+__device__ __forceinline__ size_t x3_tile_offset(const AttnParams& p, int np, int ten, int piece, int h, int g, int t) {
+    return ((((size_t)(ten * np + piece) * p.heads + h) * p.nproblems + g) * p.x3_tiles + t) * X3_PIECE_BYTES;
 }
 
-// grid (key tiles, problems, heads), 256 threads: one 64-key tile of K and of V of one head -> three bf16 pieces each.
+// grid (key tiles, problems, heads), 256 threads: one 64-key tile of K and of V of one head -> NP 16-bit pieces each (3: bf16, 2: fp16).
+template <int NP>
 __global__ __launch_bounds__(256) void attention_x3_split_kernel(AttnParams p) {
+    using SM = SplitMath<NP>;
     __shared__ float vt[64 * 65];
     const int t = blockIdx.x, g = blockIdx.y, h = blockIdx.z;
     const AttnProblem pr = p.problems[g];
@@ -647,23 +659,19 @@ __global__ __launch_bounds__(256) void attention_x3_split_kernel(AttnParams p) {
     {   // K: thread = (key row, 16 channels)
         const int r = tid >> 2, c0 = (tid & 3) * 16;
         const float* src = p.k + (size_t)(pr.k_off + t * AT_KT + (r < valid ? r : 0)) * p.ldk + h * 64 + c0;
-        unsigned hi[16], mid[16], lo[16];
+        u32x4 pc[2][NP];
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q4);
-            if (r >= valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const X3Split sp = x3_split(v[e]);
-                hi[4 * q4 + e] = sp.hi, mid[4 * q4 + e] = sp.mid, lo[4 * q4 + e] = sp.lo;
-            }
+        for (int o = 0; o < 2; ++o) {
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 8 * o), v1 = *reinterpret_cast<const f32x4*>(src + 8 * o + 4);
+            if (r >= valid) v0 = v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            SM::split8(v, pc[o]);
         }
 #pragma unroll
-        for (int piece = 0; piece < 3; ++piece) {
-            const unsigned* w = piece == 0 ? hi : piece == 1 ? mid : lo;
-            unsigned char* dst = xb + x3_tile_offset(p, 0, piece, h, g, t) + r * 128 + c0 * 2;
-            *reinterpret_cast<u32x4*>(dst) = u32x4{x3_pack(w[0], w[1]), x3_pack(w[2], w[3]), x3_pack(w[4], w[5]), x3_pack(w[6], w[7])};
-            *reinterpret_cast<u32x4*>(dst + 16) = u32x4{x3_pack(w[8], w[9]), x3_pack(w[10], w[11]), x3_pack(w[12], w[13]), x3_pack(w[14], w[15])};
+        for (int piece = 0; piece < NP; ++piece) {
+            unsigned char* dst = xb + x3_tile_offset(p, NP, 0, piece, h, g, t) + r * 128 + c0 * 2;
+            *reinterpret_cast<u32x4*>(dst) = pc[0][piece];
+            *reinterpret_cast<u32x4*>(dst + 16) = pc[1][piece];
         }
     }
     {   // V: through LDS (rows = keys, padded), then thread = (channel d, two slot octets): the transposed, slot-permuted tile
@@ -682,19 +690,14 @@ __global__ __launch_bounds__(256) void attention_x3_split_kernel(AttnParams p) {
         for (int oo = 0; oo < 2; ++oo) {
             const int oct = (tid >> 6) * 2 + oo;  // slots 8 oct .. 8 oct + 7 = k-step s = oct >> 1, lane half kh = oct & 1
             const int s = oct >> 1, kh = oct & 1;
-            unsigned hi[8], mid[8], lo[8];
+            float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int key = 32 * (s >> 1) + 16 * (s & 1) + 4 * kh + (i & 3) + 8 * (i >> 2);
-                const X3Split sp = x3_split(vt[key * 65 + d]);
-                hi[i] = sp.hi, mid[i] = sp.mid, lo[i] = sp.lo;
-            }
+            for (int i = 0; i < 8; ++i) v[i] = vt[(32 * (s >> 1) + 16 * (s & 1) + 4 * kh + (i & 3) + 8 * (i >> 2)) * 65 + d];
+            u32x4 pc[NP];
+            SM::split8(v, pc);
 #pragma unroll
-            for (int piece = 0; piece < 3; ++piece) {
-                const unsigned* w = piece == 0 ? hi : piece == 1 ? mid : lo;
-                unsigned char* dst = xb + x3_tile_offset(p, 1, piece, h, g, t) + d * 128 + oct * 16;
-                *reinterpret_cast<u32x4*>(dst) = u32x4{x3_pack(w[0], w[1]), x3_pack(w[2], w[3]), x3_pack(w[4], w[5]), x3_pack(w[6], w[7])};
-            }
+            for (int piece = 0; piece < NP; ++piece)
+                *reinterpret_cast<u32x4*>(xb + x3_tile_offset(p, NP, 1, piece, h, g, t) + d * 128 + oct * 16) = pc[piece];
         }
     }
 }
@@ -711,11 +714,14 @@ __global__ __launch_bounds__(256) void attention_x3_split_kernel(AttnParams p) {
 // run in the sixth digit when two streams shared the chip, cause not found, and was dropped): the SQ counters show the matrix pipe busy
 // 67 - 71 % of the cycles but the clock at 1.6 GHz under the counters (1.8 GHz free-running) where the exact-fp32 kernel holds
 // 2.2 - 2.3 GHz. At this duty cycle the bf16 pipe is power-limited: 3 / 8 of the matrix-pipe cycles buy 1.55 x, not 2.67 x.
-template <bool SPLIT>
+// NP = 2 (f16x2, round 6): 24 + 24 v_mfma_f32_32x32x16_f16 per tile and wave, 32 KiB of LDS tiles, the softmax reference X3_P_SHIFT below the maximum.
+template <bool SPLIT, int NP>
 __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
+    using SM = SplitMath<NP>;
+    constexpr float P_SHIFT = NP == 2 ? X3_P_SHIFT : 0.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_x3[];
     unsigned char* Kl = lds_x3;
-    unsigned char* Vl = lds_x3 + X3_TILE_BYTES;
+    unsigned char* Vl = lds_x3 + X3_TILE_BYTES(NP);
     const int b = blockIdx.x;
     const int groups = p.heads * p.nproblems;
     const int k_in_xcd = b >> 3;
@@ -749,38 +755,28 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
     }
 
     // Q^T fragment (B operand of S^T = K Q^T): lane (q = j, kh), k-step u: channels 16 u + 8 kh .. + 7, pre-scaled by scale * log2(e)
-    u32x4 qf[4][3];
+    u32x4 qf[4][NP];
     {
         const float* qp = p.q + (size_t)(pr.q_off + (qvalid ? qrow : 0)) * p.ldq + h * 64 + kh * 8;
         const float scale2 = p.scale * 1.44269504088896340736f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            unsigned hi[8], mid[8], lo[8];
-#pragma unroll
-            for (int q4 = 0; q4 < 2; ++q4) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(qp + 16 * u + 4 * q4);
-                if (!qvalid) v = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const X3Split sp = x3_split(v[e] * scale2);
-                    hi[4 * q4 + e] = sp.hi, mid[4 * q4 + e] = sp.mid, lo[4 * q4 + e] = sp.lo;
-                }
-            }
-            qf[u][0] = u32x4{x3_pack(hi[0], hi[1]), x3_pack(hi[2], hi[3]), x3_pack(hi[4], hi[5]), x3_pack(hi[6], hi[7])};
-            qf[u][1] = u32x4{x3_pack(mid[0], mid[1]), x3_pack(mid[2], mid[3]), x3_pack(mid[4], mid[5]), x3_pack(mid[6], mid[7])};
-            qf[u][2] = u32x4{x3_pack(lo[0], lo[1]), x3_pack(lo[2], lo[3]), x3_pack(lo[4], lo[5]), x3_pack(lo[6], lo[7])};
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(qp + 16 * u), v1 = *reinterpret_cast<const f32x4*>(qp + 16 * u + 4);
+            if (!qvalid) v0 = v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float v[8] = {v0[0] * scale2, v0[1] * scale2, v0[2] * scale2, v0[3] * scale2, v1[0] * scale2, v1[1] * scale2, v1[2] * scale2, v1[3] * scale2};
+            SM::split8(v, qf[u]);
         }
     }
 
-    // DMA of one tile of one tensor: 24 pieces of 1 KiB (3 bf16 pieces x 8 x [8 rows x 128 B]); wave w moves pieces w, w + 4, ..:
-    // their first row is 8 (w + 4 i) -> ((row >> 1) & 7) = ((lane >> 4) + 4 w) & 7 for all six: one swizzled source offset per lane.
+    // DMA of one tile of one tensor: 8 NP pieces of 1 KiB (NP 16-bit pieces x 8 x [8 rows x 128 B]); wave w moves pieces w, w + 4, ..:
+    // their first row is 8 (w + 4 i) -> ((row >> 1) & 7) = ((lane >> 4) + 4 w) & 7 for all of them: one swizzled source offset per lane.
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x3);
     const int dma_src = ((lane >> 3) * 128) + ((((lane & 7) ^ (((lane >> 4) + 4 * wave) & 7))) << 4);
     auto tile_dma = [&](int ten, int t, unsigned char* dst) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 2 * NP; ++i) {
             const int pc = wave + 4 * i, piece = pc >> 3, pp = pc & 7;
-            const unsigned char* src = xb + x3_tile_offset(p, ten, piece, h, prob, t) + pp * 1024 + dma_src;
+            const unsigned char* src = xb + x3_tile_offset(p, NP, ten, piece, h, prob, t) + pp * 1024 + dma_src;
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(src), reinterpret_cast<unsigned*>(dst + piece * X3_PIECE_BYTES + pp * 1024), 16, 0, 0);
         }
     };
@@ -823,10 +819,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            u32x4 a0[3], a1[3];
+            u32x4 a0[NP], a1[NP];
 #pragma unroll
-            for (int piece = 0; piece < 3; ++piece) a0[piece] = frag(Kl, piece, 0, u), a1[piece] = frag(Kl, piece, 1, u);
-            x3_product(s0, s1, a0, a1, qf[u]);
+            for (int piece = 0; piece < NP; ++piece) a0[piece] = frag(Kl, piece, 0, u), a1[piece] = frag(Kl, piece, 1, u);
+            SM::product(s0, s1, a0, a1, qf[u]);
         }
         if (!more && k0 + AT_KT > nk) {  // only the last tile of the keys can be partial
 #pragma unroll
@@ -841,9 +837,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
         mloc = at_halves_max(mloc);
-        const bool rebase = (ts == 0) || (mloc > AT_REBASE);
+        // (f16x2: the reference is kept P_SHIFT below the maximum, so the weights fill fp16's range from the top: <= 2^(AT_REBASE + P_SHIFT) = 2^15)
+        const bool rebase = (ts == 0) || (mloc > AT_REBASE + P_SHIFT);
         if (__any(rebase)) {
-            const float d = rebase ? mloc : 0.f;
+            const float d = rebase ? mloc - P_SHIFT : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s0[r] -= d, s1[r] -= d;
             if (ts > 0) {
@@ -867,25 +864,20 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
         if (more) tile_dma(0, t + 1, Kl);
-        // ---- O^T += V^T P^T: k-step s = 2 T + c takes registers 8 c .. 8 c + 7 of score block T, split into three bf16 pieces on the fly
+        // ---- O^T += V^T P^T: k-step s = 2 T + c takes registers 8 c .. 8 c + 7 of score block T, split into NP pieces on the fly
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            u32x4 pb[3];
+            u32x4 pb[NP];
             {
-                unsigned hi[8], mid[8], lo[8];
+                float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const X3Split sp = x3_split((s >> 1) ? s1[8 * (s & 1) + i] : s0[8 * (s & 1) + i]);
-                    hi[i] = sp.hi, mid[i] = sp.mid, lo[i] = sp.lo;
-                }
-                pb[0] = u32x4{x3_pack(hi[0], hi[1]), x3_pack(hi[2], hi[3]), x3_pack(hi[4], hi[5]), x3_pack(hi[6], hi[7])};
-                pb[1] = u32x4{x3_pack(mid[0], mid[1]), x3_pack(mid[2], mid[3]), x3_pack(mid[4], mid[5]), x3_pack(mid[6], mid[7])};
-                pb[2] = u32x4{x3_pack(lo[0], lo[1]), x3_pack(lo[2], lo[3]), x3_pack(lo[4], lo[5]), x3_pack(lo[6], lo[7])};
+                for (int i = 0; i < 8; ++i) v[i] = (s >> 1) ? s1[8 * (s & 1) + i] : s0[8 * (s & 1) + i];
+                SM::split8(v, pb);
             }
-            u32x4 a0[3], a1[3];
+            u32x4 a0[NP], a1[NP];
 #pragma unroll
-            for (int piece = 0; piece < 3; ++piece) a0[piece] = frag(Vl, piece, 0, s), a1[piece] = frag(Vl, piece, 1, s);
-            x3_product(o0, o1, a0, a1, pb);
+            for (int piece = 0; piece < NP; ++piece) a0[piece] = frag(Vl, piece, 0, s), a1[piece] = frag(Vl, piece, 1, s);
+            SM::product(o0, o1, a0, a1, pb);
         }
         // B2: every wave is done with V(t), K(t + 1) has landed -> the V buffer takes tile t + 1 (it lands under the next S phase + softmax)
         if (more) {
@@ -972,13 +964,16 @@ static int at_fused_waves() {  // GTSFM_ATTENTION_WAVES = 4 | 8 (read per launch
 static int at_xcd_rep(int groups) { return (groups > 0 && groups < 8 && 8 % groups == 0) ? 8 / groups : 1; }
 static int at_fused_grid(int nproblems, int heads, int max_q) { return ceil_div(heads * nproblems, 8) * 8 * ceil_div(max_q, 32 * at_fused_waves()); }
 
-int attention_math_from_env() {  // read per call: GTSFM_ATTENTION_MATH = "bf16x3" selects the split-bf16 products, anything else exact fp32
+int attention_math_from_env() {  // read per call: GTSFM_ATTENTION_MATH = "bf16x3" / "f16x2" select the split products, anything else exact fp32
     const char* env = getenv("GTSFM_ATTENTION_MATH");
-    return (env && env[0] == 'b') ? ATTN_MATH_BF16X3 : ATTN_MATH_F32;
+    if (env && env[0] == 'b') return ATTN_MATH_BF16X3;
+    if (env && env[0] == 'f' && env[1] == '1') return ATTN_MATH_F16X2;  // (not "f32")
+    return ATTN_MATH_F32;
 }
 
-static size_t x3_split_floats(int nproblems, int heads, int max_k) {  // K and V^T, three bf16 pieces each, whole 64-key tiles
-    return (size_t)6 * heads * nproblems * ceil_div(max_k < 1 ? 1 : max_k, AT_KT) * (X3_PIECE_BYTES / sizeof(float));
+static int x3_pieces(int math) { return math == ATTN_MATH_F16X2 ? 2 : 3; }
+static size_t x3_split_floats(int nproblems, int heads, int max_k, int math) {  // K and V^T, NP 16-bit pieces each, whole 64-key tiles
+    return (size_t)2 * x3_pieces(math) * heads * nproblems * ceil_div(max_k < 1 ? 1 : max_k, AT_KT) * (X3_PIECE_BYTES / sizeof(float));
 }
 
 // Sized from the launch GEOMETRY, never from GTSFM_ATTENTION_SPLIT: a workspace is held across calls (the pipeline's per-stream
@@ -987,11 +982,11 @@ static size_t x3_split_floats(int nproblems, int heads, int max_k) {  // K and V
 // The arithmetic mode is the caller's statement (it changes results): bf16x3 adds the split K / V^T tiles.
 size_t attention_workspace_floats(int nproblems, int heads, int max_q, int max_k, size_t rows, int math) {
     if (nproblems <= 0) return 0;
-    const bool x3 = math == ATTN_MATH_BF16X3;
-    const size_t base = x3 ? x3_split_floats(nproblems, heads, max_k) : 0;
+    const bool x3 = math == ATTN_MATH_BF16X3 || math == ATTN_MATH_F16X2;
+    const size_t base = x3 ? x3_split_floats(nproblems, heads, max_k, math) : 0;
     if (at_segments(max_k) < 2) return base;  // one segment: neither schedule needs memory
     const size_t split = (size_t)at_segments(max_k) * rows * ((size_t)heads * 64 + (size_t)heads * 2);
-    const size_t park = x3 ? 0  // bf16x3: the fused schedule keeps its merged state in registers (round 6)
+    const size_t park = x3 ? 0  // bf16x3 / f16x2: the fused schedule keeps its merged state in registers (round 6)
                            : (ATD_PARK_GLOBAL ? (size_t)at_fused_grid(nproblems, heads, max_q) * (ATD_OC_FLOATS / 4 * at_fused_waves()) : 0);  // exact fp32, single buffers: parked in LDS
     return base + (at_geometry_wants_split(nproblems, heads, max_q, max_k) ? (split > park ? split : park) : park);
 }
@@ -999,17 +994,21 @@ size_t attention_workspace_floats(int nproblems, int heads, int max_q, int max_k
 static int launch_attention_x3(const AttnParams& p, int nproblems, int max_q, hipStream_t stream) {
     AttnParams q = p;
     const int max_k = p.max_k > 0 ? p.max_k : max_q;
-    GTSFM_CHECK_ARG(p.max_k > 0, "attention (bf16x3): the caller must state the largest key count");
+    GTSFM_CHECK_ARG(p.max_k > 0, "attention (bf16x3 / f16x2): the caller must state the largest key count");
+    const bool f16 = p.math == ATTN_MATH_F16X2;
     q.qtiles = ceil_div(max_q, AT_QB);
     q.nproblems = nproblems;
     q.x3_tiles = ceil_div(max_k, AT_KT);
-    const size_t x3_floats = x3_split_floats(nproblems, p.heads, max_k);
-    GTSFM_CHECK_ARG(p.workspace && p.workspace_floats >= x3_floats, "attention (bf16x3): workspace too small for the split K / V tiles (%zu < %zu floats)",
+    const size_t x3_floats = x3_split_floats(nproblems, p.heads, max_k, p.math);
+    GTSFM_CHECK_ARG(p.workspace && p.workspace_floats >= x3_floats, "attention (bf16x3 / f16x2): workspace too small for the split K / V tiles (%zu < %zu floats)",
                     p.workspace_floats, x3_floats);
     q.x3 = p.workspace;
     float* rest = p.workspace + x3_floats;
     const size_t rest_floats = p.workspace_floats - x3_floats;
-    hipLaunchKernelGGL(attention_x3_split_kernel, dim3(q.x3_tiles, nproblems, p.heads), dim3(256), 0, stream, q);
+    if (f16)
+        hipLaunchKernelGGL(attention_x3_split_kernel<2>, dim3(q.x3_tiles, nproblems, p.heads), dim3(256), 0, stream, q);
+    else
+        hipLaunchKernelGGL(attention_x3_split_kernel<3>, dim3(q.x3_tiles, nproblems, p.heads), dim3(256), 0, stream, q);
     const int groups = p.heads * nproblems;
     const int nseg = at_segments(max_k);
     const size_t need_split = (size_t)nseg * p.part_rows * ((size_t)p.heads * 64 + (size_t)p.heads * 2);
@@ -1023,12 +1022,18 @@ static int launch_attention_x3(const AttnParams& p, int nproblems, int max_q, hi
         q.part_o = rest;
         q.part_ml = rest + (size_t)nseg * p.part_rows * p.heads * 64;
         dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles * q.nseg);
-        hipLaunchKernelGGL((attention_x3_kernel<true>), grid, dim3(256), X3_LDS_BYTES, stream, q);
+        if (f16)
+            hipLaunchKernelGGL((attention_x3_kernel<true, 2>), grid, dim3(256), X3_LDS_BYTES(2), stream, q);
+        else
+            hipLaunchKernelGGL((attention_x3_kernel<true, 3>), grid, dim3(256), X3_LDS_BYTES(3), stream, q);
         hipLaunchKernelGGL(attention_combine_kernel, dim3(ceil_div(max_q, 4), nproblems), dim3(256), 0, stream, q);
     } else {
         q.nseg = 1;  // (the merged state between segments lives in registers: no parking space)
         dim3 grid(ceil_div(groups, 8) * 8 * q.qtiles);
-        hipLaunchKernelGGL((attention_x3_kernel<false>), grid, dim3(256), X3_LDS_BYTES, stream, q);
+        if (f16)
+            hipLaunchKernelGGL((attention_x3_kernel<false, 2>), grid, dim3(256), X3_LDS_BYTES(2), stream, q);
+        else
+            hipLaunchKernelGGL((attention_x3_kernel<false, 3>), grid, dim3(256), X3_LDS_BYTES(3), stream, q);
     }
     GTSFM_CHECK_LAUNCH("attention kernel (bf16x3)");
     return GTSFM_OK;
@@ -1037,9 +1042,9 @@ static int launch_attention_x3(const AttnParams& p, int nproblems, int max_q, hi
 int launch_attention(const AttnParams& p, int nproblems, int max_q, hipStream_t stream) {
     GTSFM_CHECK_ARG(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, "attention: leading dimensions must be multiples of 4");
     GTSFM_CHECK_ARG(p.heads > 0 && p.heads <= 4, "attention: 1 to 4 heads");
-    GTSFM_CHECK_ARG(p.math == ATTN_MATH_F32 || p.math == ATTN_MATH_BF16X3, "attention: math is 0 (exact fp32) or 1 (bf16x3)");
+    GTSFM_CHECK_ARG(p.math == ATTN_MATH_F32 || p.math == ATTN_MATH_BF16X3 || p.math == ATTN_MATH_F16X2, "attention: math is 0 (exact fp32), 1 (bf16x3) or 2 (f16x2)");
     if (nproblems <= 0 || max_q <= 0) return GTSFM_OK;
-    if (p.math == ATTN_MATH_BF16X3) return launch_attention_x3(p, nproblems, max_q, stream);
+    if (p.math != ATTN_MATH_F32) return launch_attention_x3(p, nproblems, max_q, stream);
     AttnParams q = p;
     q.qtiles = ceil_div(max_q, AT_QB);
     q.nproblems = nproblems;

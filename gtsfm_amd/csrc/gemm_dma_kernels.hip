@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "bf16x3.h"
+#include "f16x2.h"
 #include "gemm_kernels.h"
 #include "gemm_batch.h"
 #include "trace.h"
@@ -52,8 +53,14 @@ __device__ __forceinline__ int dm_swz(int row, int chunk) { return chunk ^ ((row
 //     k-steps of 16; each lane splits the eight fp32 values of its weight row and of its activation row EXACTLY into three bf16 pieces in
 //     registers (bf16x3.h) and every 32 x 32 x 16 block is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-class error per
 //     term, NOT the bits of the default. 24 + 24 MFMAs of 32 cycles per stage and wave instead of 64 of 64 cycles.
-template <bool HAS_RES, bool ROT, bool X3 = false>
+//   * MATH = 2 (round 6, opt-in GTSFM_GEMM_MATH=f16x2; f16x2.h): the same with TWO fp16 pieces per operand and three v_mfma_f32_32x32x16_f16 per
+//     block: 12 + 12 MFMAs per stage and wave. Operands beyond +-65504 give inf / NaN outputs (fp16 has no exponent headroom).
+// MATH: 0 = exact fp32, 1 = bf16x3, 2 = f16x2.
+template <bool HAS_RES, bool ROT, int MATH = 0>
 __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, GemmBatch bt) {
+    constexpr bool X3 = MATH != 0;       // one of the split arithmetics
+    constexpr int NP = MATH == 2 ? 2 : 3;  // 16-bit pieces per operand
+    using SM = SplitMath<NP>;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A 4096 | W 4096]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,14 +220,15 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
     c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.e, a1.e, c11, 0, 0, 0);
         if constexpr (X3) {
             // k-step h of the stage: lane (row, kh) owns floats 16 h + 8 kh .. + 7 of its row = the 16-byte chunks 4 h + 2 kh and 4 h + 2 kh + 1
-            auto frag8 = [&](const float* base, int row, int h, u32x4 (&dst)[3]) {
+            auto frag8 = [&](const float* base, int row, int h, u32x4 (&dst)[NP]) {
                 const f32x4 lo4 = *reinterpret_cast<const f32x4*>(base + row * DM_KC + dm_swz(row, 4 * h + 2 * kh) * 4);
                 const f32x4 hi4 = *reinterpret_cast<const f32x4*>(base + row * DM_KC + dm_swz(row, 4 * h + 2 * kh + 1) * 4);
-                x3_split8(lo4, hi4, dst);
+                const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                SM::split8(v, dst);
             };
 #pragma unroll
             for (int h = 0; h < DM_KC / 16; ++h) {
-                u32x4 a0[3], a1[3], b0[3], b1[3];
+                u32x4 a0[NP], a1[NP], b0[NP], b1[NP];
                 frag8(sA, ra, h, a0), frag8(sA, ra + 32, h, a1);
 #ifdef GTSFM_X3_ABLATE_WSPLIT  // developer ablation (tools/build_variant.sh; results are garbage): what weights that arrive ALREADY split would save -- the
                 {              // weight fragments are read (same LDS traffic as three bf16 planes would cost: 2 x 16 B here, 3 x 16 B then) but not split
@@ -228,16 +236,16 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
                     const f32x4 hi4 = *reinterpret_cast<const f32x4*>(sW + rw * DM_KC + dm_swz(rw, 4 * h + 2 * kh + 1) * 4);
                     const f32x4 lo5 = *reinterpret_cast<const f32x4*>(sW + (rw + 32) * DM_KC + dm_swz(rw + 32, 4 * h + 2 * kh) * 4);
                     const f32x4 hi5 = *reinterpret_cast<const f32x4*>(sW + (rw + 32) * DM_KC + dm_swz(rw + 32, 4 * h + 2 * kh + 1) * 4);
-                    b0[0] = __builtin_bit_cast(u32x4, lo4), b0[1] = __builtin_bit_cast(u32x4, hi4), b0[2] = b0[0];
-                    b1[0] = __builtin_bit_cast(u32x4, lo5), b1[1] = __builtin_bit_cast(u32x4, hi5), b1[2] = b1[0];
+                    b0[0] = __builtin_bit_cast(u32x4, lo4), b0[1] = __builtin_bit_cast(u32x4, hi4), b0[NP - 1] = b0[0];
+                    b1[0] = __builtin_bit_cast(u32x4, lo5), b1[1] = __builtin_bit_cast(u32x4, hi5), b1[NP - 1] = b1[0];
                 }
 #else
                 frag8(sW, rw, h, b0), frag8(sW, rw + 32, h, b1);
 #endif
-                x3_product(c00, c01, b0, b1, a0);  // weights = MFMA A operand (output columns), activations = B operand: a lane owns an output row
+                SM::product(c00, c01, b0, b1, a0);  // weights = MFMA A operand (output columns), activations = B operand: a lane owns an output row
 #pragma unroll
                 for (int i = 0; i < 4; ++i) piece(4 * h + i, na, nw, nA, nW);
-                x3_product(c10, c11, b0, b1, a1);
+                SM::product(c10, c11, b0, b1, a1);
             }
         } else {
 #pragma unroll
@@ -378,9 +386,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, Gem
 #define DS_STAGE_FLOATS (2 * DS_A_FLOATS)
 
 // X3 (round 4): the bf16x3 arithmetic of gemm_dma_walk_kernel<..., X3> with the same six products in the same order per block and k-step, so that the
-// two tilings stay bit-identical to each other under GTSFM_GEMM_MATH=bf16x3 as well (batched == single-pair results).
-template <bool HAS_RES, bool ROT, bool X3 = false>
+// two tilings stay bit-identical to each other under GTSFM_GEMM_MATH=bf16x3 as well (batched == single-pair results). MATH = 2: f16x2, likewise.
+template <bool HAS_RES, bool ROT, int MATH = 0>
 __global__ __launch_bounds__(256, 4) void gemm_dma_small_kernel(GemmParams p) {
+    constexpr bool X3 = MATH != 0;
+    constexpr int NP = MATH == 2 ? 2 : 3;
+    using SM = SplitMath<NP>;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A 2048 | W 2048]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -456,13 +467,15 @@ __global__ __launch_bounds__(256, 4) void gemm_dma_small_kernel(GemmParams p) {
         if constexpr (X3) {
 #pragma unroll
             for (int h = 0; h < DM_KC / 16; ++h) {
-                u32x4 a3[3], b3[3];
-                x3_split8(*reinterpret_cast<const f32x4*>(sA + ra * DM_KC + dm_swz(ra, 4 * h + 2 * kh) * 4),
-                          *reinterpret_cast<const f32x4*>(sA + ra * DM_KC + dm_swz(ra, 4 * h + 2 * kh + 1) * 4), a3);
-                x3_split8(*reinterpret_cast<const f32x4*>(sW + rw * DM_KC + dm_swz(rw, 4 * h + 2 * kh) * 4),
-                          *reinterpret_cast<const f32x4*>(sW + rw * DM_KC + dm_swz(rw, 4 * h + 2 * kh + 1) * 4), b3);
-                c = x3_mfma(b3[2], a3[0], c), c = x3_mfma(b3[0], a3[2], c), c = x3_mfma(b3[1], a3[1], c);  // the order of x3_product
-                c = x3_mfma(b3[1], a3[0], c), c = x3_mfma(b3[0], a3[1], c), c = x3_mfma(b3[0], a3[0], c);
+                u32x4 a3[NP], b3[NP];
+                auto frag8 = [&](const float* base, int row, u32x4 (&dst)[NP]) {
+                    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(base + row * DM_KC + dm_swz(row, 4 * h + 2 * kh) * 4);
+                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(base + row * DM_KC + dm_swz(row, 4 * h + 2 * kh + 1) * 4);
+                    const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                    SM::split8(v, dst);
+                };
+                frag8(sA, ra, a3), frag8(sW, rw, b3);
+                SM::product1(c, b3, a3);  // the products of the large tiling in its order (weights = the MFMA's A operand)
             }
         } else {
 #pragma unroll
@@ -502,9 +515,11 @@ bool gemm_uses_dma(int K, int ldw) {
     return K % DM_KC == 0 && ldw % 4 == 0 && !(which && which[0] == 'm');
 }
 
-int gemm_math_from_env() {
+int gemm_math_from_env() {  // GTSFM_GEMM_MATH = "bf16x3" -> 1, "f16x2" -> 2, anything else (unset, "f32") -> 0
     const char* math_env = getenv("GTSFM_GEMM_MATH");
-    return (math_env && math_env[0] == 'b') ? 1 : 0;
+    if (math_env && math_env[0] == 'b') return 1;
+    if (math_env && math_env[0] == 'f' && math_env[1] == '1') return 2;
+    return 0;
 }
 
 int launch_gemm_dma(const GemmParams& p, hipStream_t stream) {
@@ -541,18 +556,24 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
     // products per block in the same order, so batched == single-pair results stay bit-identical under the switch too. The switch is
     // a field the CALLER sets (matcher_api.hip, the stand-alone linear entry points): SuperPoint's convPb / convDb come through this
     // launcher as well and leave it 0 -- keypoint scores and dense descriptors never change with the environment.
-    const bool x3 = p.math == 1;
+    const bool x3 = p.math == 1, h2 = p.math == 2;
     const char* small_env = getenv("GTSFM_GEMM_SMALL_BELOW");
     const long long small_below = small_env ? atoll(small_env) : 700LL * gtsfm_cu_count() / 256;  // measured on 256 CUs; scales with the chip
     if (!bt.problems && vec_ok && !p.n_dev && nbw == 1 && (long long)mtiles * ncb < small_below) {
         const dim3 sgrid(ceil_div(p.M, 64) * ceil_div(p.N, 64));
         const size_t slds = (size_t)2 * DS_STAGE_FLOATS * sizeof(float);
-        if (x3 && q.rot_enc)
-            hipLaunchKernelGGL((gemm_dma_small_kernel<false, true, true>), sgrid, dim3(256), slds, stream, q);
+        if (h2 && q.rot_enc)
+            hipLaunchKernelGGL((gemm_dma_small_kernel<false, true, 2>), sgrid, dim3(256), slds, stream, q);
+        else if (h2 && q.res)
+            hipLaunchKernelGGL((gemm_dma_small_kernel<true, false, 2>), sgrid, dim3(256), slds, stream, q);
+        else if (h2)
+            hipLaunchKernelGGL((gemm_dma_small_kernel<false, false, 2>), sgrid, dim3(256), slds, stream, q);
+        else if (x3 && q.rot_enc)
+            hipLaunchKernelGGL((gemm_dma_small_kernel<false, true, 1>), sgrid, dim3(256), slds, stream, q);
         else if (x3 && q.res)
-            hipLaunchKernelGGL((gemm_dma_small_kernel<true, false, true>), sgrid, dim3(256), slds, stream, q);
+            hipLaunchKernelGGL((gemm_dma_small_kernel<true, false, 1>), sgrid, dim3(256), slds, stream, q);
         else if (x3)
-            hipLaunchKernelGGL((gemm_dma_small_kernel<false, false, true>), sgrid, dim3(256), slds, stream, q);
+            hipLaunchKernelGGL((gemm_dma_small_kernel<false, false, 1>), sgrid, dim3(256), slds, stream, q);
         else if (q.rot_enc)
             hipLaunchKernelGGL((gemm_dma_small_kernel<false, true>), sgrid, dim3(256), slds, stream, q);
         else if (q.res)
@@ -571,13 +592,23 @@ int launch_gemm_dma_batched(const GemmParams& p, const GemmBatch& bt, hipStream_
         grid.x = 8 * ceil_div(local_rows, q.super_rows) * q.super_rows * ceil_div(groups, 8) * 8;
     }
     const size_t lds_bytes = (size_t)2 * DM_STAGE_FLOATS * sizeof(float);
+    if (h2) {  // opt-in arithmetic (GTSFM_GEMM_MATH=f16x2): the same launch geometry, stages and epilogues
+        if (q.rot_enc)
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, true, 2>), grid, dim3(256), lds_bytes, stream, q, bt);
+        else if (q.res)
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<true, false, 2>), grid, dim3(256), lds_bytes, stream, q, bt);
+        else
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false, 2>), grid, dim3(256), lds_bytes, stream, q, bt);
+        GTSFM_CHECK_LAUNCH("gemm_dma_walk_kernel (f16x2)");
+        return GTSFM_OK;
+    }
     if (x3) {  // opt-in arithmetic (GTSFM_GEMM_MATH=bf16x3): the same launch geometry, stages and epilogues
         if (q.rot_enc)
-            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, true, true>), grid, dim3(256), lds_bytes, stream, q, bt);
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, true, 1>), grid, dim3(256), lds_bytes, stream, q, bt);
         else if (q.res)
-            hipLaunchKernelGGL((gemm_dma_walk_kernel<true, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<true, false, 1>), grid, dim3(256), lds_bytes, stream, q, bt);
         else
-            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false, true>), grid, dim3(256), lds_bytes, stream, q, bt);
+            hipLaunchKernelGGL((gemm_dma_walk_kernel<false, false, 1>), grid, dim3(256), lds_bytes, stream, q, bt);
         GTSFM_CHECK_LAUNCH("gemm_dma_walk_kernel (bf16x3)");
         return GTSFM_OK;
     }

@@ -225,10 +225,10 @@ extern "C" int gtsfm_attention_split_f32(const float* q_dev, int ldq, const floa
 
 extern "C" size_t gtsfm_attention_math_workspace_bytes(int nproblems, int max_q, int max_k, int heads, size_t rows, int math) {
     // either schedule of the chosen arithmetic: the larger of the split schedule's partial states and the fused schedule's parking space,
-    // plus (bf16x3) the split K / V^T tiles
-    if (math != ATTN_MATH_BF16X3) return gtsfm_attention_split_workspace_bytes(nproblems, max_q, max_k, heads, rows);
+    // plus (bf16x3 / f16x2) the split K / V^T tiles: 3 / 2 pieces of 8 KiB per 64-key tile, tensor, head and problem
+    if (math != ATTN_MATH_BF16X3 && math != ATTN_MATH_F16X2) return gtsfm_attention_split_workspace_bytes(nproblems, max_q, max_k, heads, rows);
     const size_t key_tiles = (size_t)((max_k < 1 ? 1 : max_k) + 63) / 64;
-    const size_t tiles = (size_t)6 * heads * nproblems * key_tiles * 8192;
+    const size_t tiles = (size_t)(math == ATTN_MATH_F16X2 ? 4 : 6) * heads * nproblems * key_tiles * 8192;
     return tiles + gtsfm_attention_split_workspace_bytes(nproblems, max_q, max_k, heads, rows);
 }
 
@@ -237,7 +237,7 @@ extern "C" int gtsfm_attention_math_f32(const float* q_dev, int ldq, const float
                                         int heads, float scale, int mode, int math, size_t rows, void* workspace_dev, size_t workspace_bytes, void* stream) {
     GTSFM_CHECK_ARG(q_dev && k_dev && v_dev && out_dev && problems_dev && counts_dev, "attention: null pointer");
     GTSFM_CHECK_ARG(mode >= -1 && mode <= 1, "attention: mode is -1 (fused), 0 (by launch geometry) or 1 (split)");
-    GTSFM_CHECK_ARG(math == 0 || math == 1, "attention: math is 0 (exact fp32) or 1 (bf16x3)");
+    GTSFM_CHECK_ARG(math >= 0 && math <= 2, "attention: math is 0 (exact fp32), 1 (bf16x3) or 2 (f16x2)");
     AttnParams p = {};
     p.q = q_dev, p.ldq = ldq, p.k = k_dev, p.ldk = ldk, p.v = v_dev, p.ldv = ldv, p.out = out_dev, p.ldo = ldo;
     p.problems = (const AttnProblem*)problems_dev, p.counts = counts_dev, p.scale = scale, p.heads = heads;

@@ -1,5 +1,6 @@
-"""-m gpu: the opt-in attention arithmetic GTSFM_ATTENTION_MATH=bf16x3 (both attention products on v_mfma_f32_32x32x16_bf16 with every
-fp32 operand split exactly into three bf16 pieces, fp32 accumulation; attention_kernels.hip) under the SAME parity checks as the
+"""-m gpu: the opt-in arithmetics GTSFM_ATTENTION_MATH / GTSFM_GEMM_MATH = bf16x3 (both attention products on v_mfma_f32_32x32x16_bf16 with every
+fp32 operand split exactly into three bf16 pieces, fp32 accumulation; attention_kernels.hip, bf16x3.h) and = f16x2 (round 6: two fp16 pieces per
+operand, three v_mfma_f32_32x32x16_f16 per block; f16x2.h) -- every test below runs once per mode -- under the SAME parity checks as the
 exact-fp32 default: the reference-written SuperGlue goldens at the benchmark's shapes, the HuggingFace-port LightGlue goldens, the
 LightGlue oracle at the 5000-keypoint cap -- match indices identical, scores within 1e-4 -- and run-to-run determinism of the two-stream
 pipeline. (The kernel-level check against float64 is tests/test_matchers_gpu.py::test_attention_bf16x3_arithmetic; the whole matcher
@@ -15,9 +16,14 @@ from gtsfm_amd.utils import synthetic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def bf16x3(monkeypatch):
-    monkeypatch.setenv("GTSFM_ATTENTION_MATH", "bf16x3")  # read per call by gtsfm_{sg,lg}_workspace_bytes / gtsfm_{sg,lg}_forward*
+MODES = ["bf16x3", "f16x2"]
+
+
+@pytest.fixture(params=MODES)
+def bf16x3(monkeypatch, request):
+    """The attention switch set to one of the two split arithmetics (the fixture keeps its round-4 name)."""
+    monkeypatch.setenv("GTSFM_ATTENTION_MATH", request.param)  # read per call by gtsfm_{sg,lg}_workspace_bytes / gtsfm_{sg,lg}_forward*
+    return request.param
 
 
 @pytest.mark.parametrize("name", ["plain", "early_stop", "pruning", "early_stop_pruning", "n2048_full_depth"])
@@ -40,7 +46,8 @@ def test_lightglue_oracle_at_the_cap_under_bf16x3(gpu_device, bf16x3):
     test_lightglue_full_depth_vs_oracle(gpu_device, *LG_BENCH_CASES[-1])  # 5000 x 4800 with pruning
 
 
-def test_bf16x3_differs_from_exact_fp32_only_within_tolerance(gpu_device, monkeypatch):
+@pytest.mark.parametrize("mode", MODES)
+def test_bf16x3_differs_from_exact_fp32_only_within_tolerance(gpu_device, monkeypatch, mode):
     """The two arithmetics on one pair at N = 2048: the same matches, scores within 1e-4 of each other -- and NOT the same bits (a test
     that silently ran the exact kernel twice would pass everything above)."""
     from gtsfm_amd.runtime import matcher_engine as ME
@@ -52,7 +59,7 @@ def test_bf16x3_differs_from_exact_fp32_only_within_tolerance(gpu_device, monkey
     monkeypatch.delenv("GTSFM_ATTENTION_MATH", raising=False)  # (the file also runs with both switches exported: the first run must still be exact)
     monkeypatch.delenv("GTSFM_GEMM_MATH", raising=False)
     exact = eng.match_pair(k0, d0, k1, d1, (1024, 1024), (1024, 1024))
-    monkeypatch.setenv("GTSFM_ATTENTION_MATH", "bf16x3")
+    monkeypatch.setenv("GTSFM_ATTENTION_MATH", mode)
     split = eng.match_pair(k0, d0, k1, d1, (1024, 1024), (1024, 1024))
     again = eng.match_pair(k0, d0, k1, d1, (1024, 1024), (1024, 1024))
     np.testing.assert_array_equal(exact["matches0"], split["matches0"])
@@ -88,7 +95,8 @@ def test_bf16x3_two_stream_pipeline_is_deterministic(gpu_device, bf16x3):
 
 @pytest.mark.parametrize("m,k,n,relu,res,m_live,n_live", [(1000, 512, 512, 1, 1, 1000, 512), (131, 256, 768, 0, 0, 131, 768), (640, 512, 256, 0, 1, 640, 132),
                                                           (4097, 32, 128, 1, 0, 4097, 128), (260, 256, 300, 0, 1, 200, 296)])
-def test_gemm_bf16x3_arithmetic(gpu_device, monkeypatch, m, k, n, relu, res, m_live, n_live):
+@pytest.mark.parametrize("mode", MODES)
+def test_gemm_bf16x3_arithmetic(gpu_device, monkeypatch, mode, m, k, n, relu, res, m_live, n_live):
     """GTSFM_GEMM_MATH=bf16x3: the LDS-DMA GEMM's products on bf16 MFMA with both operands split exactly into three bf16 pieces in registers,
     same stages / epilogues / masking as the exact kernel. Against a FLOAT64 reference its error must be of the exact kernel's class (at most
     twice + 1e-6 of the result's scale), untouched cells stay untouched, and it must NOT be the exact kernel's bits (the switch did something)."""
@@ -124,7 +132,7 @@ def test_gemm_bf16x3_arithmetic(gpu_device, monkeypatch, m, k, n, relu, res, m_l
         torch.cuda.synchronize()
         return out.cpu()
 
-    exact, x3 = run("f32"), run("bf16x3")
+    exact, x3 = run("f32"), run(mode)
     for got in (exact, x3):
         assert torch.all(got[:, :4] == -5.0) and torch.all(got[:, n_live + 4 :] == -5.0) and torch.all(got[m_live:] == -5.0)
     live = (slice(0, m_live), slice(4, n_live + 4))
@@ -134,22 +142,24 @@ def test_gemm_bf16x3_arithmetic(gpu_device, monkeypatch, m, k, n, relu, res, m_l
     assert not torch.equal(exact[live], x3[live])
 
 
-def test_matcher_goldens_under_both_bf16x3_switches(gpu_device, monkeypatch):
+@pytest.mark.parametrize("mode", MODES)
+def test_matcher_goldens_under_both_bf16x3_switches(gpu_device, monkeypatch, mode):
     """Attention AND projection / score GEMMs in the bf16x3 arithmetic (GTSFM_ATTENTION_MATH + GTSFM_GEMM_MATH): the reference-written
     SuperGlue golden at 5000 x 4800, the HuggingFace-port LightGlue golden at N = 2048 and the LightGlue oracle at the cap still hold --
     indices identical, scores within 1e-4."""
     from test_bench_shapes_gpu import LG_BENCH_CASES, test_lightglue_full_depth_vs_oracle, test_superglue_full_depth_matches_reference_golden
     from test_lightglue_hf_golden_gpu import test_hip_path_equals_the_hf_fixture
 
-    monkeypatch.setenv("GTSFM_ATTENTION_MATH", "bf16x3")
-    monkeypatch.setenv("GTSFM_GEMM_MATH", "bf16x3")
-    monkeypatch.setenv("GTSFM_GEMM_SMALL_BELOW", "0")  # single pairs would otherwise keep the exact small-tile GEMM
+    monkeypatch.setenv("GTSFM_ATTENTION_MATH", mode)
+    monkeypatch.setenv("GTSFM_GEMM_MATH", mode)
+    monkeypatch.setenv("GTSFM_GEMM_SMALL_BELOW", "0")  # (both tilings honour the switch; the goldens are checked on the batch tiling)
     test_superglue_full_depth_matches_reference_golden(gpu_device, GOLDEN / "bench_superglue_5000x4800_s15_it20.npz")
     test_hip_path_equals_the_hf_fixture(gpu_device, "n2048_full_depth")
     test_lightglue_full_depth_vs_oracle(gpu_device, *LG_BENCH_CASES[-1])
 
 
-def test_superpoint_is_bit_identical_under_the_gemm_switch(gpu_device, monkeypatch):
+@pytest.mark.parametrize("mode", MODES)
+def test_superpoint_is_bit_identical_under_the_gemm_switch(gpu_device, monkeypatch, mode):
     """GTSFM_GEMM_MATH=bf16x3 is the MATCHERS' switch (GemmParams.math, set by gtsfm_{sg,lg}_forward* and the stand-alone linear entry points):
     SuperPoint's convPb / convDb reach the same LDS-DMA launcher (superpoint_api.hip, 1x1 convolutions with K = 256) and must stay exact fp32 --
     score maps, keypoints, scores and descriptors bit for bit the same with the variable set (until round 5 the launcher read
@@ -159,8 +169,8 @@ def test_superpoint_is_bit_identical_under_the_gemm_switch(gpu_device, monkeypat
     eng = SuperPointEngine(synthetic.synthetic_superpoint_state_dict(), gpu_device)
     imgs = torch.from_numpy(np.stack([synthetic.synthetic_gray_image(240, 320, s) for s in (5, 6)])).to(gpu_device)
     exact = eng.forward(imgs, return_score_maps=True)
-    monkeypatch.setenv("GTSFM_GEMM_MATH", "bf16x3")
-    monkeypatch.setenv("GTSFM_ATTENTION_MATH", "bf16x3")
+    monkeypatch.setenv("GTSFM_GEMM_MATH", mode)
+    monkeypatch.setenv("GTSFM_ATTENTION_MATH", mode)
     switched = eng.forward(imgs, return_score_maps=True)
     assert int(exact["count"].min()) > 100
     for key in ("count", "dense_scores", "nms_scores"):

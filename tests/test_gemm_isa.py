@@ -37,8 +37,8 @@ def _descriptors(assembly: str) -> dict:
 
 def test_no_gemm_instantiation_uses_scratch(assembly):
     kernels = {k: v for k, v in _descriptors(assembly).items() if "gemm_dma_" in k}
-    # {plain, residual, rotary} x {fp32, bf16x3} x {128 x 128 walk tiles, 64 x 64 small tiles}
-    assert len(kernels) == 12, sorted(kernels)
+    # {plain, residual, rotary} x {fp32, bf16x3, f16x2} x {128 x 128 walk tiles, 64 x 64 small tiles}
+    assert len(kernels) == 18, sorted(kernels)
     for name, d in kernels.items():
         assert d["scratch"] == 0, f"{name}: private_segment_fixed_size = {d['scratch']} (a spill inside an MFMA kernel)"
         assert d["vgprs"] <= 256, (name, d)
@@ -46,11 +46,17 @@ def test_no_gemm_instantiation_uses_scratch(assembly):
 
 
 def test_matrix_instructions_are_where_they_should_be(assembly):
-    """fp32 variants multiply on v_mfma_f32_32x32x2_f32 only, bf16x3 variants on v_mfma_f32_32x32x16_bf16 only."""
+    """fp32 variants multiply on v_mfma_f32_32x32x2_f32 only, bf16x3 variants on v_mfma_f32_32x32x16_bf16 only, f16x2 variants on
+    v_mfma_f32_32x32x16_f16 only -- and the f16x2 split converts with the packed round-to-nearest instruction."""
+    seen = set()
     for block in re.split(r"\n(?=_Z\w+:)", assembly):
         name = block.split(":")[0]
         if "gemm_dma_" not in name or not name.startswith("_Z"):
             continue
-        x3 = "ELb1EEv" in name  # the third template argument
-        f32, bf16 = block.count("v_mfma_f32_32x32x2_f32"), block.count("v_mfma_f32_32x32x16_bf16")
-        assert (bf16 > 0 and f32 == 0) if x3 else (f32 > 0 and bf16 == 0), (name, f32, bf16)
+        math = int(re.search(r"ELi(\d)EEv", name).group(1))  # the third template argument: 0 fp32, 1 bf16x3, 2 f16x2
+        seen.add(math)
+        counts = [block.count("v_mfma_f32_32x32x2_f32"), block.count("v_mfma_f32_32x32x16_bf16"), block.count("v_mfma_f32_32x32x16_f16")]
+        assert counts[math] > 0 and sum(counts) == counts[math], (name, counts)
+        if math == 2:
+            assert "v_cvt_pk_f16_f32" in block and "v_cvt_pkrtz" not in block, name
+    assert seen == {0, 1, 2}

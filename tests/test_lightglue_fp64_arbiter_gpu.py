@@ -36,7 +36,7 @@ def _case_names():
     return sorted(json.loads(str(np.load(path)["cases"]))) if path.exists() else ["missing"]
 
 
-@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+@pytest.mark.parametrize("math", ["f32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("name", _case_names())
 def test_hip_lightglue_against_float64(gpu_device, arbiter, monkeypatch, name, math):
     from gtsfm_amd.runtime.matcher_engine import LightGlueEngine

@@ -99,7 +99,7 @@ def test_restatement_equals_the_hf_port_at_the_cap(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("math", ["f32", "bf16x3_attention", "bf16x3_both"])
+@pytest.mark.parametrize("math", ["f32", "bf16x3_attention", "bf16x3_both", "f16x2_both"])
 @pytest.mark.parametrize("name", CAP_CASES)
 def test_hip_path_equals_the_hf_port_at_the_cap(gpu_device, monkeypatch, name, math):
     """-m gpu: the HIP path at GTSfM's 5000-keypoint cap against the third-party port: matches identical to the port's fp32 run (== its
@@ -107,9 +107,9 @@ def test_hip_path_equals_the_hf_port_at_the_cap(gpu_device, monkeypatch, name, m
     from gtsfm_amd.runtime.matcher_engine import LightGlueEngine
 
     if math != "f32":
-        monkeypatch.setenv("GTSFM_ATTENTION_MATH", "bf16x3")
-    if math == "bf16x3_both":
-        monkeypatch.setenv("GTSFM_GEMM_MATH", "bf16x3")
+        monkeypatch.setenv("GTSFM_ATTENTION_MATH", math.split("_")[0])
+    if math.endswith("_both"):
+        monkeypatch.setenv("GTSFM_GEMM_MATH", math.split("_")[0])
         monkeypatch.setenv("GTSFM_GEMM_SMALL_BELOW", "0")  # single pairs would otherwise take the small-tile GEMM (same arithmetic; kept as in the other both-switch tests)
     g, sd, (k0, d0, k1, d1), shape = _load_cap(name)
     eng = LightGlueEngine(sd, gpu_device)

@@ -1132,9 +1132,10 @@ def test_graph_replay_survives_descriptor_cache_eviction_and_empty_pair_lists(gp
     assert int((first[0]["matches"] > -1).sum()) > 0
 
 
-def test_attention_bf16x3_arithmetic(lib, gpu_device):
-    """The opt-in arithmetic (``gtsfm_attention_math_f32`` with math = 1, GTSFM_ATTENTION_MATH=bf16x3): K Q^T and P V on bf16 MFMA with
-    every fp32 operand split exactly into three bf16 pieces, fp32 accumulation. Against a FLOAT64 reference its error must be of the
+@pytest.mark.parametrize("math", [1, 2], ids=["bf16x3", "f16x2"])
+def test_attention_bf16x3_arithmetic(lib, gpu_device, math):
+    """The opt-in arithmetics (``gtsfm_attention_math_f32`` with math = 1, GTSFM_ATTENTION_MATH=bf16x3: K Q^T and P V on bf16 MFMA with
+    every fp32 operand split exactly into three bf16 pieces; math = 2, =f16x2: two fp16 pieces, three products), fp32 accumulation. Against a FLOAT64 reference its error must be of the
     class of the exact-fp32 kernel's (both are measured; bf16x3 may carry at most twice the exact kernel's error + 2e-6), its fused and
     split schedules must agree bit for bit with each other (same segment merge), rows beyond a count stay untouched, and a problem
     without keys writes zeros. Same ragged problem set as the schedule test: 1, 2, 3 and 5 key segments, cross problems, late dominant keys."""
@@ -1150,7 +1151,7 @@ def test_attention_bf16x3_arithmetic(lib, gpu_device):
     problems = [(0, 0), (1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (7, 6), (7, 5), (4, 2), (2, 4)]
     d = qkv.to(gpu_device)
     cnt = torch.tensor(counts, dtype=torch.int32, device=gpu_device)
-    ws = torch.empty(int(lib.gtsfm_attention_math_workspace_bytes(len(problems), max(counts), max(counts), 4, total, 1)), dtype=torch.uint8, device=gpu_device)
+    ws = torch.empty(int(lib.gtsfm_attention_math_workspace_bytes(len(problems), max(counts), max(counts), 4, total, math)), dtype=torch.uint8, device=gpu_device)
 
     def run(sel, mode, math):
         prob = torch.tensor([[offs[a], a, offs[b], b] for a, b in sel], dtype=torch.int32, device=gpu_device)
@@ -1165,7 +1166,7 @@ def test_attention_bf16x3_arithmetic(lib, gpu_device):
     q64 = qkv.double()
     worst = {"exact": 0.0, "x3": 0.0}
     for sel in ([problems[0], problems[3], problems[5]], [problems[1], problems[2], problems[4], problems[6]], [problems[7]], [problems[8]], [problems[9]]):
-        exact, fused, split = run(sel, -1, 0), run(sel, -1, 1), run(sel, 1, 1)
+        exact, fused, split = run(sel, -1, 0), run(sel, -1, math), run(sel, 1, math)
         touched = torch.zeros(total, dtype=torch.bool)
         for a, b in sel:
             rows = slice(offs[a], offs[a] + counts[a])
@@ -1178,8 +1179,9 @@ def test_attention_bf16x3_arithmetic(lib, gpu_device):
             e_exact, e_x3 = float((exact[rows].double() - ref).abs().max()), float((fused[rows].double() - ref).abs().max())
             worst["exact"], worst["x3"] = max(worst["exact"], e_exact), max(worst["x3"], e_x3)
             assert e_x3 <= 2.0 * e_exact + 2e-6, ((a, b), e_x3, e_exact)
+            assert not torch.equal(exact[rows], fused[rows])  # (the switch did something)
         assert torch.isnan(fused[~touched]).all() and torch.isnan(split[~touched]).all()
-    print(f"attention max |error| against float64: exact fp32 {worst['exact']:.3e}, bf16x3 {worst['x3']:.3e}")
+    print(f"attention max |error| against float64: exact fp32 {worst['exact']:.3e}, {'bf16x3' if math == 1 else 'f16x2'} {worst['x3']:.3e}")
 
 
 @pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
