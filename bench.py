@@ -176,8 +176,9 @@ def measure_conv_roofline(lib, device, batch: int, h: int, w: int, reps: int = 5
 def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5, math: int = 0):
     """Dominant kernel of the detect+match workload (~50 % of GPU time): one launch = the self attention of `npairs`
     pairs (2 sequences x 4 heads each) at N = n. Algorithmic work: 1024 * N^2 FLOP per sequence per layer (SURVEY.md
-    section 8a rows a23 / a36). math 1 = the opt-in bf16x3 arithmetic (6 bf16 MFMAs per 32 x 32 x 16 block of either product):
-    the same algorithmic FLOPs, priced against the same fp32 roof AND as executed bf16 work against the bf16 MFMA roof."""
+    section 8a rows a23 / a36). math 1 = the opt-in bf16x3 arithmetic (6 bf16 MFMAs per 32 x 32 x 16 block of either product), math 2 = the opt-in
+    f16x2 arithmetic (3 fp16 MFMAs): the same algorithmic FLOPs, priced against the same fp32 roof AND as executed 16-bit work against the bf16 / fp16
+    MFMA roof (the same nominal 2.5 PFLOP/s)."""
     from gtsfm_amd.runtime import lib as L
 
     stream = torch.cuda.current_stream(device)
@@ -194,16 +195,21 @@ def measure_attention_roofline(lib, device, n: int, npairs: int, reps: int = 5, 
     ms = _time_launches(lambda: L.check(lib.gtsfm_attention_math_f32(*args), "attention"), stream, reps)
     flops = 1024.0 * n * n * nseq
     achieved = flops / (ms * 1e-3) / 1e12
-    if math == 1:
-        executed = 6.0 * flops  # six bf16 products per fp32 product term
-        tx, ts = pmc_traffic(f"attention_x3_kernel@{nseq}x4x{n}"), pmc_traffic(f"attention_x3_split_kernel@{nseq}x4x{n}")
+    if math in (1, 2):
+        per_term = 6.0 if math == 1 else 3.0  # bf16x3: six bf16 products per fp32 product term; f16x2: three fp16 products
+        name = "bf16x3" if math == 1 else "f16x2"
+        executed = per_term * flops
+        tx, ts = pmc_traffic(f"attention_x3_kernel@{nseq}x4x{n}@{name}"), pmc_traffic(f"attention_x3_split_kernel@{nseq}x4x{n}@{name}")
+        if math == 1 and tx is None:
+            tx, ts = pmc_traffic(f"attention_x3_kernel@{nseq}x4x{n}"), pmc_traffic(f"attention_x3_split_kernel@{nseq}x4x{n}")
         traffic = None if tx is None or ts is None else tx["fetch_bytes"] + tx["write_bytes"] + ts["fetch_bytes"] + ts["write_bytes"]
         return {
-            "bound": "mfma", "kernel": "attention_x3_split_kernel + attention_x3_kernel", "achieved": round(executed / (ms * 1e-3) / 1e12, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s (executed bf16)", "frac": round(executed / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
+            "bound": "mfma", "kernel": f"attention_x3_split_kernel<{3 if math == 1 else 2}> + attention_x3_kernel<.., {3 if math == 1 else 2}>", "achieved": round(executed / (ms * 1e-3) / 1e12, 2),
+            "peak": BF16_MFMA_PEAK_TFLOPS, "unit": f"TFLOP/s (executed {'bf16' if math == 1 else 'fp16'})",
+            "frac": round(executed / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
             "algorithmic_tflops": round(achieved, 2), "algorithmic_frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "flops_per_launch": flops,
             "launch_shape": f"{nseq} sequences x 4 heads, N = {n} queries = keys, head_dim 64 (K / V split pass + attention)", "traffic": traffic,
-            "traffic_note": None if traffic is None else f"HBM-side bytes per launch (split pass + attention, incl. the merged states parked between key segments), rocprofv3 PMC, {tx['source']}",
+            "traffic_note": None if traffic is None else f"HBM-side bytes per launch (split pass + attention), rocprofv3 PMC, {tx['source']}",
         }
     t = pmc_traffic(f"attention_dma_kernel@{nseq}x4x{n}")
     return {
@@ -230,13 +236,17 @@ def measure_gemm_roofline(lib, device, rows: int, k: int, n: int, reps: int = 5)
     args = (a.data_ptr(), k, rows, None, k, w.data_ptr(), k, bias.data_ptr(), n, None, c.data_ptr(), n, 0, None, 0, 1.0, 0, stream.cuda_stream)
     ms = _time_launches(lambda: L.check(lib.gtsfm_linear_rowmajor_f32(*args), "linear_rowmajor"), stream, reps)
     achieved = 2.0 * rows * k * n / (ms * 1e-3) / 1e12
-    if (os.environ.get("GTSFM_GEMM_MATH") or "")[:1] == "b":
-        executed = 6.0 * achieved
+    gm = os.environ.get("GTSFM_GEMM_MATH") or ""
+    if gm[:1] == "b" or gm[:2] == "f1":
+        x3 = gm[:1] == "b"
+        executed = (6.0 if x3 else 3.0) * achieved
         return {
-            "bound": "mfma", "kernel": "gemm_dma_walk_kernel<X3>", "achieved": round(executed, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (executed bf16)",
+            "bound": "mfma", "kernel": f"gemm_dma_walk_kernel<.., {1 if x3 else 2}>", "achieved": round(executed, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+            "unit": f"TFLOP/s (executed {'bf16' if x3 else 'fp16'})",
             "frac": round(executed / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 4), "launch_shape": f"{rows} x {k} -> {n}",
             "algorithmic_tflops": round(achieved, 2), "algorithmic_frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "arithmetic": "bf16x3: six bf16 MFMA products per fp32 product term, operands split in registers", "traffic": None,
+            "arithmetic": ("bf16x3: six bf16 MFMA products per fp32 product term, operands split in registers" if x3
+                           else "f16x2: three fp16 MFMA products per fp32 product term, operands split in registers"), "traffic": None,
         }
     t = pmc_traffic(f"gemm_dma_walk_kernel@{rows}x{k}x{n}")
     return {
@@ -998,6 +1008,8 @@ def main() -> None:
                 if args.matcher == "lightglue" and args.keypoints > 1024:
                     result["secondary"]["attention_bf16x3"] = leg("bf16x3", attention_bf16x3_rate, args, lib, detector, matcher, images, pairs, shapes, device, ora)
                     result["secondary"]["matcher_bf16x3"] = leg("matcher_bf16x3", attention_bf16x3_rate, args, lib, detector, matcher, images, pairs, shapes, device, ora, True)
+                    result["secondary"]["attention_f16x2"] = leg("f16x2", attention_bf16x3_rate, args, lib, detector, matcher, images, pairs, shapes, device, ora, False, "f16x2")
+                    result["secondary"]["matcher_f16x2"] = leg("matcher_f16x2", attention_bf16x3_rate, args, lib, detector, matcher, images, pairs, shapes, device, ora, True, "f16x2")
                 if getattr(pipe, "last_shared_images", 0):
                     result["secondary"]["headline_per_pair_first_layer"] = leg("unshared", unshared_rate, args, detector, matcher, images, pairs, shapes, mk)
                 if args.matcher == "lightglue":
@@ -1011,6 +1023,8 @@ def main() -> None:
                     result["secondary"]["config4_scene_share_cap5000"] = leg("config4", config4_scene_share_rate, args, detector, device, h, w, not args.no_cpu_baseline)
                     result["secondary"]["config4_scene_share_cap5000_bf16x3"] = leg("config4_bf16x3", config4_scene_share_rate, args, detector, device, h, w,
                                                                                             not args.no_cpu_baseline, "bf16x3")
+                    result["secondary"]["config4_scene_share_cap5000_f16x2"] = leg("config4_f16x2", config4_scene_share_rate, args, detector, device, h, w,
+                                                                                           not args.no_cpu_baseline, "f16x2")
         print(emit(result, args.details_file), flush=True)
     if dist is not None:
         dist.barrier()
@@ -1400,11 +1414,12 @@ def config4_scene_share_rate(args, detector, device, h, w, with_oracle: bool, ma
     return out
 
 
-def attention_bf16x3_rate(args, lib, detector, matcher, images, pairs, shapes, device, oracle_out, gemm_too: bool = False):
-    """The opt-in arithmetic GTSFM_ATTENTION_MATH=bf16x3 on the first pairs of the headline workload: both products of every attention
-    launch on v_mfma_f32_32x32x16_bf16 with each fp32 operand split exactly into three bf16 pieces (six of the nine piece products, fp32
-    accumulation: fp32-class error per product, NOT the exact-fp32 kernel's bits); SuperPoint, the GEMMs, the sweeps stay exact fp32. Own
-    timed region; compared pair by pair with the exact-fp32 pipeline on the same input and, for the first pair, with the oracle."""
+def attention_bf16x3_rate(args, lib, detector, matcher, images, pairs, shapes, device, oracle_out, gemm_too: bool = False, mode: str = "bf16x3"):
+    """The opt-in arithmetics GTSFM_ATTENTION_MATH=bf16x3 | f16x2 on the first pairs of the headline workload: both products of every attention
+    launch on v_mfma_f32_32x32x16_bf16 with each fp32 operand split exactly into three bf16 pieces (six of the nine piece products), or on
+    v_mfma_f32_32x32x16_f16 with two fp16 pieces (three products); fp32 accumulation: fp32-class error per product, NOT the exact-fp32 kernel's
+    bits; SuperPoint, the sweeps and -- unless gemm_too -- the GEMMs stay exact fp32. Own timed region; compared pair by pair with the exact-fp32
+    pipeline on the same input and, for the first pair, with the oracle."""
     from gtsfm_amd.runtime.pipeline import FrontEndPipeline
 
     pairs = pairs[:SIDE_LEG_PAIRS]
@@ -1420,11 +1435,11 @@ def attention_bf16x3_rate(args, lib, detector, matcher, images, pairs, shapes, d
     switches = ["GTSFM_ATTENTION_MATH"] + (["GTSFM_GEMM_MATH"] if gemm_too else [])
     old = {k: os.environ.get(k) for k in switches}
     for k in switches:
-        os.environ[k] = "bf16x3"  # read per call / per launch by the C entry points; graphs are captured under them
+        os.environ[k] = mode  # read per call / per launch by the C entry points; graphs are captured under them
     try:
         pipe = make_pipe()
         res, timing = _time_steps(lambda: pipe.match(pipe.detect(images), pairs, shapes), SECONDARY_STEPS, 1, device)
-        roof = measure_attention_roofline(lib, device, args.keypoints, min(args.pair_chunk, len(pairs)), math=1)
+        roof = measure_attention_roofline(lib, device, args.keypoints, min(args.pair_chunk, len(pairs)), math=1 if mode == "bf16x3" else 2)
         if gemm_too:
             rows = 2 * min(args.pair_chunk, len(pairs)) * (-(-args.keypoints // 128) * 128)
             roof = {"attention": roof, "gemm": [measure_gemm_roofline(lib, device, rows, k, nn) for k, nn in ((256, 768), (512, 512), (512, 256))]}
@@ -1450,12 +1465,13 @@ def attention_bf16x3_rate(args, lib, detector, matcher, images, pairs, shapes, d
             nmatch += int((ma[off : off + int(n0[q])] > -1).sum())
             off += t
     out = {"value": round(len(pairs) / (ms * 1e-3), 2), "unit": "image-pairs/s", **timing, "pairs_per_step": len(pairs), "images_per_step": int(images.shape[0]),
-           "dtype": ("f32 via 3 x bf16 split of the attention products AND the matcher's projection / score GEMMs, f32 accumulate (SuperPoint, sweeps: exact f32)" if gemm_too
-                     else "f32 via 3 x bf16 split of both attention products, f32 accumulate (SuperPoint, GEMMs, sweeps: exact f32)"),
+           "dtype": ((f"f32 via {'3 x bf16' if mode == 'bf16x3' else '2 x fp16'} split of the attention products AND the matcher's projection / score GEMMs, f32 accumulate "
+                      "(SuperPoint, sweeps: exact f32)") if gemm_too
+                     else f"f32 via {'3 x bf16' if mode == 'bf16x3' else '2 x fp16'} split of both attention products, f32 accumulate (SuperPoint, GEMMs, sweeps: exact f32)"),
            "matcher_layers_run": float(torch.cat([r["stop"] for r in res]).float().mean()) if res and "stop" in res[0] else None,
            "against_exact_fp32_pipeline": {"pairs_with_identical_match_arrays": same_pairs, "pairs": len(pairs), "max_dscore_on_those": dmax, "matches": nmatch},
            "roofline": roof,
-           "workload": f"the first {len(pairs)} pairs of the headline workload with {' and '.join(k + '=bf16x3' for k in switches)} (opt-in; the headline stays exact fp32)"}
+           "workload": f"the first {len(pairs)} pairs of the headline workload with {' and '.join(k + '=' + mode for k in switches)} (opt-in; the headline stays exact fp32)"}
     if oracle_out is not None and res:
         a = res[0]["n0"][0]
         out["parity_check"] = parity_check(oracle_out, feats, [pairs[0][0], pairs[0][1]], (res[0]["matches"][:a].cpu().numpy(), res[0]["mscores"][:a].cpu().numpy()))
@@ -1521,33 +1537,35 @@ def plugin_api_rate(args, pipe, views_np, device, h, w):
                 for th in ths:
                     th.join()
                 threaded[str(nthreads)] = round(2 * len(pairs) / (time.perf_counter() - t0), 1)
-        # the same calls under the opt-in arithmetic (both switches; the image cache is emptied so that nothing computed in exact fp32 is reused)
-        x3 = {}
-        try:
-            mt._model.release_lanes()
-            old_env = {k: os.environ.get(k) for k in ("GTSFM_ATTENTION_MATH", "GTSFM_GEMM_MATH")}
-            os.environ.update({"GTSFM_ATTENTION_MATH": "bf16x3", "GTSFM_GEMM_MATH": "bf16x3"})
+        # the same calls under the opt-in arithmetics (both switches; the image cache is emptied so that nothing computed in exact fp32 is reused)
+        def switched(mode):
             try:
-                got_x3, each_x3 = [], []
-                for rep in range(2):  # the first round uploads the images (misses), the second is all hits
-                    got_x3, each_x3 = [], []
-                    for i, j in pairs:
-                        t0 = time.perf_counter()
-                        got_x3.append(mt.match(feats[i][0], feats[j][0], feats[i][1], feats[j][1], shape, shape))
-                        each_x3.append(time.perf_counter() - t0)
-            finally:
-                for k, v in old_env.items():
-                    if v is None:
-                        os.environ.pop(k, None)
-                    else:
-                        os.environ[k] = v
                 mt._model.release_lanes()
-            per = float(np.median(each_x3))
-            x3 = {"match_ms_per_pair_resident": round(per * 1e3, 2), "pairs_per_s_match_only_resident": round(1.0 / per, 1),
-                  "calls_with_match_arrays_identical_to_exact_fp32": int(sum(np.array_equal(a, b) for a, b in zip(got, got_x3))), "calls": len(pairs),
-                  "switches": "GTSFM_ATTENTION_MATH=bf16x3 GTSFM_GEMM_MATH=bf16x3 (opt-in)"}
-        except Exception as exc:  # noqa: BLE001 - a side measurement must not cost the leg
-            x3 = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+                old_env = {k: os.environ.get(k) for k in ("GTSFM_ATTENTION_MATH", "GTSFM_GEMM_MATH")}
+                os.environ.update({"GTSFM_ATTENTION_MATH": mode, "GTSFM_GEMM_MATH": mode})
+                try:
+                    got_x3, each_x3 = [], []
+                    for rep in range(2):  # the first round uploads the images (misses), the second is all hits
+                        got_x3, each_x3 = [], []
+                        for i, j in pairs:
+                            t0 = time.perf_counter()
+                            got_x3.append(mt.match(feats[i][0], feats[j][0], feats[i][1], feats[j][1], shape, shape))
+                            each_x3.append(time.perf_counter() - t0)
+                finally:
+                    for k, v in old_env.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
+                    mt._model.release_lanes()
+                per = float(np.median(each_x3))
+                return {"match_ms_per_pair_resident": round(per * 1e3, 2), "pairs_per_s_match_only_resident": round(1.0 / per, 1),
+                        "calls_with_match_arrays_identical_to_exact_fp32": int(sum(np.array_equal(a, b) for a, b in zip(got, got_x3))), "calls": len(pairs),
+                        "switches": f"GTSFM_ATTENTION_MATH={mode} GTSFM_GEMM_MATH={mode} (opt-in)"}
+            except Exception as exc:  # noqa: BLE001 - a side measurement must not cost the leg
+                return {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+
+        x3, h2 = switched("bf16x3"), switched("f16x2")
     # the same pair through the batched, device-resident pipeline (device top-k keeps detection order, the plugin's Keypoints.get_top_k does
     # not, so the index pairs are compared as coordinate pairs)
     dev_feats = pipe.detect(torch.from_numpy(views_np[:n_img]).to(device))
@@ -1568,7 +1586,7 @@ def plugin_api_rate(args, pipe, views_np, device, h, w):
         "value_note": f"exhaustive scene of the headline's shape ({args.images} images, {args.pairs} pairs): 1 / (match + detect x images / pairs), PCIe and per-call synchronisation included",
         "keypoints_per_image": [int(min(len(f[0]) for f in feats)), int(max(len(f[0]) for f in feats))], "matches_first_pair": int(len(got[0])),
         "first_pair_equals_batched_pipeline": bool(ref_set == got_set),
-        "bf16x3": x3,
+        "bf16x3": x3, "f16x2": h2,
         "match_ms_per_pair_resident": round(float(np.median(each[5:])) * 1e3, 2), "pairs_per_s_match_only_resident": round(1.0 / float(np.median(each[5:])), 1),
         "workload": f"SuperPointDetectorDescriptor.detect_and_describe x {n_img} + {type(mt).__name__}.match x {len(pairs)} (numpy in / numpy out, one call at a time)",
     }

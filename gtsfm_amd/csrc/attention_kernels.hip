@@ -715,8 +715,11 @@ __global__ __launch_bounds__(256) void attention_x3_split_kernel(AttnParams p) {
 // 67 - 71 % of the cycles but the clock at 1.6 GHz under the counters (1.8 GHz free-running) where the exact-fp32 kernel holds
 // 2.2 - 2.3 GHz. At this duty cycle the bf16 pipe is power-limited: 3 / 8 of the matrix-pipe cycles buy 1.55 x, not 2.67 x.
 // NP = 2 (f16x2, round 6): 24 + 24 v_mfma_f32_32x32x16_f16 per tile and wave, 32 KiB of LDS tiles, the softmax reference X3_P_SHIFT below the maximum.
+#ifndef X2_WGS_PER_CU
+#define X2_WGS_PER_CU 3  // f16x2: 163 VGPRs and 32 KiB of LDS tiles leave room for a third workgroup per CU (three waves per SIMD share the matrix pipe)
+#endif
 template <bool SPLIT, int NP>
-__global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, NP == 2 ? X2_WGS_PER_CU : 2) void attention_x3_kernel(AttnParams p) {
     using SM = SplitMath<NP>;
     constexpr float P_SHIFT = NP == 2 ? X3_P_SHIFT : 0.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_x3[];
@@ -807,9 +810,11 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     __syncthreads();
 
-    for (int t = t_begin, ts = 0; t < t_end; ++t, ts = (ts + 1 == seg_tiles) ? 0 : ts + 1) {  // ts: tile index inside its segment
+    // One key tile; `last_c` (compile time): the last tile of the walk has its own body -- the only one that can be partial (the mask of keys beyond nk:
+    // 64 compare / select instructions per lane) and the only one without a successor to fetch. ts: tile index inside its segment.
+    auto tile_step = [&](auto last_c, const int t, const int ts) {
+        constexpr bool more = !decltype(last_c)::value;
         const int k0 = t * AT_KT;
-        const bool more = t + 1 < t_end;
         // ---- S^T = K Q^T - m
         f32x16 s0, s1;
         {
@@ -852,18 +857,38 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
             m += d;
         }
         float lsum = 0.f;
+        if constexpr (NP == 2) {  // two running sums, one per key block (v_pk_add_f32: half the add instructions; an order of its own, like everything in this mode)
+            f32x2v sum2 = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r]);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r]);
-            lsum += s0[r] + s1[r];
+            for (int r = 0; r < 16; ++r) {
+                s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+                s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+                sum2 += f32x2v{s0[r], s1[r]};
+            }
+            lsum = sum2.x + sum2.y;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+                s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+                lsum += s0[r] + s1[r];
+            }
         }
         l += at_halves_sum(lsum);
         // B1: every wave is done with K(t) and V(t) has landed (own pieces: vmcnt, the others': the barrier) -> the K buffer takes
         // tile t + 1, which has the whole P V phase to land
+        // (The sched_barrier fences keep [wait, barrier, DMA issue] a block of its own. With `more` a compile-time constant the DMA issue is
+        // straight-line code and the scheduler interleaved it with the softmax tail and the last P V MFMAs across the barrier; that build returned
+        // scores that differed from run to run (1e-5 .. 8e-4, 6 - 35 % of the repetitions) WHEN A SECOND STREAM SHARED THE CHIP -- never alone, never
+        // with the attention launch on its own on two streams. Any one of the fences in front of the DMA issue removed it (0 of 1200 repetitions, both
+        // arithmetics; tools/x3_two_stream_diag.py, profiles/r06_x3_two_stream_bisect.txt); which reordering was the harmful one was not established.
+        // tests/test_attention_bf16x3_gpu.py::test_bf16x3_two_stream_pipeline_is_deterministic holds the property.)
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
         if (more) tile_dma(0, t + 1, Kl);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- O^T += V^T P^T: k-step s = 2 T + c takes registers 8 c .. 8 c + 7 of score block T, split into NP pieces on the fly
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -881,9 +906,12 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
         }
         // B2: every wave is done with V(t), K(t + 1) has landed -> the V buffer takes tile t + 1 (it lands under the next S phase + softmax)
         if (more) {
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0x0f70);
             __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
             tile_dma(1, t + 1, Vl);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- fused schedule, end of a segment: fold (O, m, l) into the merged state (registers pk0 / pk1 / pkm / pkl)
         const bool seg_end = more && ts == seg_tiles - 1;
@@ -909,6 +937,11 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnParams p) {
                 m = 0.f, l = 0.f;
             }
         }
+    };
+    {
+        int t = t_begin, ts = 0;
+        for (; t + 1 < t_end; ++t, ts = (ts + 1 == seg_tiles) ? 0 : ts + 1) tile_step(std::false_type{}, t, ts);
+        tile_step(std::true_type{}, t, ts);
     }
     if (!qvalid) return;
     if (SPLIT) {

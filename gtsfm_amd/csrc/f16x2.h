@@ -23,9 +23,14 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 // (a, b) -> one register of two hi pieces (a in the low half) and one of two lo pieces
 __device__ __forceinline__ void h2_split_pair(float a, float b, unsigned& hi, unsigned& lo) {
     const f16x2v h = __builtin_convertvector(f32x2v{a, b}, f16x2v);  // v_cvt_pk_f16_f32: round to nearest even
-    const float ra = a - (float)h.x, rb = b - (float)h.y;            // exact
+    hi = __builtin_bit_cast(unsigned, h);
+    // the residuals x - hi (exact in fp32) straight from the packed register: v_fma_mix_f32 reads one half of it as an fp16 source -- one
+    // instruction per element where `a - (float)h.x` compiles to a conversion and a subtraction
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
     const f16x2v l = __builtin_convertvector(f32x2v{ra, rb}, f16x2v);
-    hi = __builtin_bit_cast(unsigned, h), lo = __builtin_bit_cast(unsigned, l);
+    lo = __builtin_bit_cast(unsigned, l);
 }
 __device__ __forceinline__ f32x16 h2_mfma(const u32x4 a, const u32x4 b, const f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);

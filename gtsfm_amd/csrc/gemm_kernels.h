@@ -27,7 +27,7 @@ struct GemmParams {
     // pairs rot_enc[row][f][2], f = (column % 64) / 2 (LightGlue apply_cached_rotary_emb on the q and k parts of Wqkv)
     const float* rot_enc;
     int rot_cols;
-    int math;       // 0 = exact fp32 (default; SuperPoint's 1x1 convolutions always), 1 = bf16x3 (opt-in: set by the matchers' forward and the
+    int math;       // 0 = exact fp32 (default; SuperPoint's 1x1 convolutions always), 1 = bf16x3, 2 = f16x2 (opt-in: set by the matchers' forward and the
                     // stand-alone linear entry points from GTSFM_GEMM_MATH via gemm_math_from_env(); LDS-DMA kernel only)
     int nb_per_wg;  // filled by the launcher: 128-column blocks one workgroup walks
     int super_rows; // filled by the launcher (LDS-DMA kernel): 0 = a row tile's column blocks run side by side on one XCD; r > 0 = wide products
@@ -36,7 +36,7 @@ struct GemmParams {
 };
 
 int launch_gemm(const GemmParams& p, hipStream_t stream);
-int gemm_math_from_env();  // GTSFM_GEMM_MATH=bf16x3 -> 1, else 0; read per call by the callers that honour the switch
+int gemm_math_from_env();  // GTSFM_GEMM_MATH=bf16x3 -> 1, f16x2 -> 2, else 0; read per call by the callers that honour the switch
 bool gemm_uses_dma(int K, int ldw);  // whether launch_gemm picks the LDS-DMA kernel for row-major weights of this shape
 int launch_gemm_dma(const GemmParams& p, hipStream_t stream);  // gemm_dma_kernels.hip; launch_gemm dispatches to it
 int launch_pack_rows(const float* B, int ldb, int N, const int* n_dev, int K, float* out, hipStream_t stream);

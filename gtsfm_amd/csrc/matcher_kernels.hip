@@ -641,7 +641,11 @@ __global__ void mutual_matches_kernel(const SeqDesc* __restrict__ seqs, const in
         if (t < m) {
             const int j = idx0[s0.row_off + t];
             const bool mutual = idx1[s1.row_off + j] == t;
-            const float ms = mutual ? expf(max0[s0.row_off + t]) : 0.f;
+            const float mx = max0[s0.row_off + t];
+            float ms = mutual ? expf(mx) : 0.f;
+            // a row whose best log-score is not a finite number saw NaN / inf arithmetic (an operand beyond fp16's range under the opt-in f16x2 switches,
+            // non-finite inputs): its score says so instead of reading "unmatched" (the engines raise on it under f16x2: check_split_arithmetic_range)
+            if (!(fabsf(mx) <= 3.402823466e+38f)) ms = __builtin_nanf("");
             const bool valid = mutual && (ms > threshold);
             matches[s0.row_off + t] = valid ? j : -1;
             mscores[s0.row_off + t] = ms;

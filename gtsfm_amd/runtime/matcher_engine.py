@@ -160,6 +160,16 @@ def _full_digest(arrays: Sequence[np.ndarray]) -> bytes:
     return h.digest()
 
 
+def check_split_arithmetic_range(mscores: np.ndarray) -> None:
+    """The opt-in f16x2 arithmetic (GTSFM_ATTENTION_MATH / GTSFM_GEMM_MATH = f16x2; gtsfm_amd/csrc/f16x2.h) carries every operand in two fp16 pieces:
+    a value beyond +-65504 becomes inf in its leading piece and NaN in every score it reaches. That must not pass for "no matches": raise."""
+    import os
+
+    if any((os.environ.get(k) or "")[:2] == "f1" for k in ("GTSFM_ATTENTION_MATH", "GTSFM_GEMM_MATH")) and np.isnan(mscores).any():
+        raise FloatingPointError("f16x2 arithmetic: an operand of the matcher left fp16's range (|x| > 65504) and the scores are NaN; "
+                                 "run this input with GTSFM_ATTENTION_MATH / GTSFM_GEMM_MATH unset (exact fp32) or =bf16x3")
+
+
 class _MatcherBase:
     # what a lane shares with the engine it was made from: read-only after construction (the weight blob lives on the device)
     _SHARED_ATTRS: Tuple[str, ...] = ("device", "_lib", "weights", "num_layers", "desc_cache_capacity", "max_lanes", "pair_streams")
@@ -567,6 +577,7 @@ class SuperGlueEngine(_MatcherBase):
                 out = eng.match_batch(kp, sc.reshape(-1), de, [n0], [n1], hw, sinkhorn_iterations, match_threshold, return_ot)
             m = out["matches"].cpu().numpy().astype(np.int64)
             ms = out["mscores"].cpu().numpy()
+            check_split_arithmetic_range(ms)
             ot = out["ot"].cpu().numpy() if return_ot else None
         res = {"matches0": m[:n0], "matches1": m[n0:], "matching_scores0": ms[:n0], "matching_scores1": ms[n0:]}
         if return_ot:
@@ -790,6 +801,7 @@ class LightGlueEngine(_MatcherBase):
                 out = eng.match_batch(kp, de, [n0], [n1], hw, **kwargs)
             m = out["matches"].cpu().numpy().astype(np.int64)
             ms = out["mscores"].cpu().numpy()
+            check_split_arithmetic_range(ms)
             out = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in out.items() if k in ("stop", "kept", "sim")}
         m0 = m[:n0]
         valid = m0 > -1

@@ -81,7 +81,9 @@ int gtsfm_linear_f32(const float* a_dev, int lda, int m, const int32_t* m_dev, i
  * device memory (<= n).                                                        same reference lines as gtsfm_linear_f32
  * Environment (read per launch): GTSFM_GEMM_MATH=bf16x3 runs the product (either tiling) in the opt-in arithmetic of
  * gtsfm_attention_math_f32 (operands split exactly into three bf16 pieces, six bf16 MFMA products per block, fp32 accumulation:
- * fp32-class error, NOT the default's bits); the default is exact fp32 and every parity statement is made with it. */
+ * fp32-class error, NOT the default's bits); GTSFM_GEMM_MATH=f16x2 runs it in the second opt-in arithmetic (two fp16 pieces per operand,
+ * three fp16 MFMA products per block; operands beyond +-65504 give NaN); the default is exact fp32 and every parity statement is made
+ * with it. */
 int gtsfm_linear_rowmajor_f32(const float* a_dev, int lda, int m, const int32_t* m_dev, int k, const float* w_dev, int ldw,
                               const float* bias_dev, int n, const int32_t* n_dev, float* c_dev, int ldc, int c_coff,
                               const float* res_dev, int ldres, float alpha, int relu, void* stream);
@@ -212,8 +214,12 @@ int gtsfm_attention_split_f32(const float* q_dev, int ldq, const float* k_dev, i
  * (K Q^T and P V) on v_mfma_f32_32x32x16_bf16 with each fp32 operand split EXACTLY into three bf16 pieces (8 + 8 + 8 significand
  * bits) and six of the nine piece products executed, fp32 accumulation -- fp32-class error per product term (the dropped terms are
  * ~2^-24 of it, below 2^-21 in the worst case), NOT the same bits as math 0, 3/8 of its matrix-pipe time. Opt-in: the matchers take it from the environment
- * variable GTSFM_ATTENTION_MATH=bf16x3 (read per call). max_k must be given (> 0); the workspace additionally holds the split K / V
- * tiles (6 x heads x nproblems x ceil(max_k / 64) x 8 KiB). */
+ * variable GTSFM_ATTENTION_MATH=bf16x3 (read per call). math 2 = "f16x2" (GTSFM_ATTENTION_MATH=f16x2): each operand carried as TWO fp16
+ * pieces (hi = RN16(x), lo = RN16(x - hi)) and three products (lo hi, hi lo, hi hi) on v_mfma_f32_32x32x16_f16, fp32 accumulation --
+ * per product term < 2^-20.9 |x y| worst case, 2^-24 on average (the class of math 1), 3/16 of math 0's matrix-pipe time; fp16 has no
+ * exponent headroom: the softmax weights are kept <= 2^15 by the kernel itself, and a q / k / v value beyond +-65504 gives NaN output rows
+ * (never a clamped value). max_k must be given (> 0) for math 1 and 2; the workspace additionally holds the split K / V tiles
+ * (6 resp. 4 x heads x nproblems x ceil(max_k / 64) x 8 KiB). */
 size_t gtsfm_attention_math_workspace_bytes(int nproblems, int max_q, int max_k, int heads, size_t rows, int math);
 int gtsfm_attention_math_f32(const float* q_dev, int ldq, const float* k_dev, int ldk, const float* v_dev, int ldv,
                              float* out_dev, int ldo, const int32_t* problems_dev, const int32_t* counts_dev, int nproblems,

@@ -71,7 +71,7 @@ def test_bf16x3_differs_from_exact_fp32_only_within_tolerance(gpu_device, monkey
 
 
 def test_bf16x3_two_stream_pipeline_is_deterministic(gpu_device, bf16x3):
-    """Pair chunks alternate over two HIP streams; a chunk's result must not depend on what runs beside it: 40 repetitions of a
+    """Pair chunks alternate over two HIP streams; a chunk's result must not depend on what runs beside it: 80 repetitions of a
     three-chunk step, bit-identical every time (a two-score-tile variant of the kernel failed exactly this in 1 - 5 % of the runs)."""
     from gtsfm_amd.runtime import matcher_engine as ME
     from gtsfm_amd.runtime.pipeline import FrontEndPipeline
@@ -86,7 +86,7 @@ def test_bf16x3_two_stream_pipeline_is_deterministic(gpu_device, bf16x3):
     ref = pipe.match(feats, pairs, [(192, 256)] * 5)
     torch.cuda.synchronize()
     assert sum(int((r["matches"] > -1).sum()) for r in ref) > 0
-    for _ in range(40):
+    for _ in range(80):
         out = pipe.match(feats, pairs, [(192, 256)] * 5)
         torch.cuda.synchronize()
         for x, y in zip(ref, out):
@@ -179,3 +179,25 @@ def test_superpoint_is_bit_identical_under_the_gemm_switch(gpu_device, monkeypat
         k = int(exact["count"][i])
         for key in ("xy", "scores", "descriptors"):
             assert torch.equal(exact[key][i, :k], switched[key][i, :k]), (key, i)
+
+
+def test_f16x2_fails_loudly_beyond_fp16_range(gpu_device, monkeypatch):
+    """f16x2 has fp16's exponent range: descriptors scaled by 1e7 put the tokens and the projected queries / keys beyond 65504, the leading pieces become inf, every
+    score NaN -- and the engine raises instead of returning "no matches". The same input in exact fp32 and under bf16x3 (fp32's range) matches."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+
+    k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(600, 500, (480, 640), (480, 640), seed=5)
+    eng = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(num_layers=2), gpu_device)
+    eng.image_cache_capacity = 0
+    big0, big1 = d0 * np.float32(1e7), d1 * np.float32(1e7)
+    for mode in ("f32", "bf16x3"):
+        monkeypatch.setenv("GTSFM_ATTENTION_MATH", mode)
+        monkeypatch.setenv("GTSFM_GEMM_MATH", mode)
+        out = eng.match_pair(k0, big0, k1, big1, (480, 640), (480, 640))
+        assert not np.isnan(out["matching_scores0"]).any()
+    monkeypatch.setenv("GTSFM_ATTENTION_MATH", "f16x2")
+    monkeypatch.setenv("GTSFM_GEMM_MATH", "f16x2")
+    with pytest.raises(FloatingPointError, match="fp16's range"):
+        eng.match_pair(k0, big0, k1, big1, (480, 640), (480, 640))
+    ok = eng.match_pair(k0, d0, k1, d1, (480, 640), (480, 640))  # the engine is fine afterwards
+    assert not np.isnan(ok["matching_scores0"]).any()

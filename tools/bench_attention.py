@@ -1,6 +1,6 @@
 """Attention kernel on its own: fused vs split schedule at single-pair and batched launch shapes (TFLOP/s of 1024 N^2 per sequence).
 
-    python tools/bench_attention.py [--quick]  # N in {2048, 5000}, 1 pair and the bench's chunk, exact fp32, bf16x3 and f16x2 arithmetic"""
+    python tools/bench_attention.py [--quick] [--math 0|1|2]  # N in {2048, 5000}, 1 pair and the bench's chunk, exact fp32, bf16x3 and f16x2 arithmetic"""
 import sys
 from pathlib import Path
 
@@ -39,9 +39,12 @@ def run(n, npairs, mode, reps=20, math=0):
 
 if __name__ == "__main__":
     quick = "--quick" in sys.argv
+    only = int(sys.argv[sys.argv.index("--math") + 1]) if "--math" in sys.argv else None  # one arithmetic only (0 fp32, 1 bf16x3, 2 f16x2)
     for n, chunk in ((2048, 32), (5000, 16)) if quick else ((2048, 32), (5000, 8), (5000, 16), (1024, 32)):
         for npairs in ((1, chunk) if quick else (1, 2, chunk)):
             for math, label in ((0, "fp32  "), (1, "bf16x3"), (2, "f16x2 ")):
+                if only is not None and math != only:
+                    continue
                 row = [f"N={n} pairs={npairs:2d} {label}"]
                 for name, mode in (("fused", -1), ("split", 1), ("auto", 0)):
                     ms, tf = run(n, npairs, mode, math=math)

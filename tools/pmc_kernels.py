@@ -1,5 +1,5 @@
 """PMC workload (GPU box, run under rocprofv3 --pmc ...): a few launches of ONE kernel at its workload shape.
-    python tools/pmc_kernels.py attention [N pairs] | attention_x3 [N pairs] | gemm ROWS K N | sinkhorn [N pairs] | lg_assign [N pairs] | conv | all
+    python tools/pmc_kernels.py attention [N pairs] | attention_x3 [N pairs] | attention_f16x2 [N pairs] | gemm ROWS K N | sinkhorn [N pairs] | lg_assign [N pairs] | conv | all
 "all" = every kernel bench.py prints a `traffic` figure for, at the headline's launch shapes (16-pair chunks at the 5000-keypoint cap)."""
 import sys
 from pathlib import Path
@@ -13,6 +13,8 @@ if what in ("attention", "all"):
     bench.measure_attention_roofline(lib, dev, *(num or [5000, 16]), reps=4)
 if what == "attention_x3":
     bench.measure_attention_roofline(lib, dev, *(num or [5000, 16]), reps=4, math=1)
+if what == "attention_f16x2":
+    bench.measure_attention_roofline(lib, dev, *(num or [5000, 16]), reps=4, math=2)
 if what == "gemm":
     bench.measure_gemm_roofline(lib, dev, *num, reps=4)
 if what == "all":

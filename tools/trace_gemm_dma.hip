@@ -16,6 +16,7 @@ void gtsfm_set_error(const char* fmt, ...) {
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 131072, K = argc > 2 ? atoi(argv[2]) : 256, N = argc > 3 ? atoi(argv[3]) : 768;
     const int with_res = argc > 4 ? atoi(argv[4]) : 0;
+    const int math = argc > 5 ? atoi(argv[5]) : 0;  // 0 exact fp32, 1 bf16x3, 2 f16x2
     float *A, *W, *C, *B, *R;
     hipMalloc(&A, (size_t)M * K * 4);
     hipMalloc(&C, (size_t)M * N * 4);
@@ -34,6 +35,7 @@ int main(int argc, char** argv) {
     GemmParams p{};
     p.A = A; p.lda = K; p.wraw = W; p.ldw = K; p.bias = B; p.C = C; p.ldc = N; p.c_coff = 0; p.M = M; p.N = N; p.K = K; p.alpha = 1.0f; p.relu = 0;
     p.res = with_res ? R : nullptr; p.ldres = N;
+    p.math = math;
     const size_t nwg = (size_t)((M + 127) / 128 + 7) / 8 * 8 * ((N + 127) / 128);
     const size_t nrec = nwg * 4 * 8;
 #ifdef GTSFM_TRACE
@@ -67,7 +69,7 @@ int main(int argc, char** argv) {
         }
         printf("self-check: max |error| over 512 samples = %.2e %s\n", worst, worst < 1e-3 ? "ok" : "FAILED");
     }
-    printf("gemm_dma %d x %d -> %d%s: %.3f ms, %.1f TFLOP/s (%.1f %% of 157.3)%s\n", M, K, N, with_res ? " +res" : "", ms, tf, 100 * tf / 157.3,
+    printf("math %d: gemm_dma %d x %d -> %d%s: %.3f ms, %.1f TFLOP/s (%.1f %% of 157.3)%s\n", math, M, K, N, with_res ? " +res" : "", ms, tf, 100 * tf / 157.3,
 #ifdef GTSFM_TRACE
            " WITH trace stamps");
 #else
