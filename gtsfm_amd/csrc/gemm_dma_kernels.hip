@@ -54,7 +54,10 @@ __device__ __forceinline__ int dm_swz(int row, int chunk) { return chunk ^ ((row
 //     registers (bf16x3.h) and every 32 x 32 x 16 block is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-class error per
 //     term, NOT the bits of the default. 24 + 24 MFMAs of 32 cycles per stage and wave instead of 64 of 64 cycles.
 //   * MATH = 2 (round 6, opt-in GTSFM_GEMM_MATH=f16x2; f16x2.h): the same with TWO fp16 pieces per operand and three v_mfma_f32_32x32x16_f16 per
-//     block: 12 + 12 MFMAs per stage and wave. Operands beyond +-65504 give inf / NaN outputs (fp16 has no exponent headroom).
+//     block: 12 + 12 MFMAs per stage and wave. Operands beyond +-65504 give inf / NaN outputs (fp16 has no exponent headroom). Cycle budget at
+//     163840 x 512 -> 512 (tools/trace_gemm_dma.hip, math 2): 2850 cycles per stage and wave for 768 cycles of own MFMA time (DMA issue 330, LDS reads +
+//     split + MFMAs 2015, wait + barrier 510): the stage is too short to hide its own fixed costs. Tried: k-step 1's fragments read and split in source order
+//     under k-step 0's MFMAs -- the scheduler regrouped it, 0.343 -> 0.364 ms: removed.
 // MATH: 0 = exact fp32, 1 = bf16x3, 2 = f16x2.
 template <bool HAS_RES, bool ROT, int MATH = 0>
 __global__ __launch_bounds__(256, 2) void gemm_dma_walk_kernel(GemmParams p, GemmBatch bt) {

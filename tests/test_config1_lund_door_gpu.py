@@ -64,7 +64,7 @@ def _record(key, value):
     OBSERVED[key] = value
     out = REPO / "gpurun_out"
     out.mkdir(exist_ok=True)
-    tag = "" if _exact_fp32() else "_bf16x3"
+    tag = "" if _exact_fp32() else "_" + (os.environ.get("GTSFM_ATTENTION_MATH") or os.environ.get("GTSFM_GEMM_MATH") or "switched")
     (out / f"config1_observed{tag}.json").write_text(json.dumps(OBSERVED, indent=1, sort_keys=True))
 
 

@@ -11,6 +11,8 @@ cd $GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -8 > $OUT/gpu_tests.txt
 GTSFM_ATTENTION_MATH=bf16x3 GTSFM_GEMM_MATH=bf16x3 python -m pytest tests/test_matchers_gpu.py tests/test_lightglue_hf_golden_gpu.py tests/test_lightglue_fp64_arbiter_gpu.py \
     tests/test_config1_lund_door_gpu.py tests/test_reference_contract_gpu.py tests/test_superpoint_gpu.py tests/test_attention_bf16x3_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | tail -6 > $OUT/gpu_tests_bf16x3_both_switches.txt
+GTSFM_ATTENTION_MATH=f16x2 GTSFM_GEMM_MATH=f16x2 python -m pytest tests/test_matchers_gpu.py tests/test_lightglue_hf_golden_gpu.py tests/test_lightglue_fp64_arbiter_gpu.py \
+    tests/test_config1_lund_door_gpu.py tests/test_reference_contract_gpu.py tests/test_superpoint_gpu.py tests/test_attention_bf16x3_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | tail -6 > $OUT/gpu_tests_f16x2_both_switches.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
 ( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench_default.log 2>&1
 cp gpurun_out/bench_details.json $OUT/bench_details.json
@@ -23,7 +25,7 @@ cp gpurun_out/prof_plugin_resident/plugin_resident_kernel_stats_k5000.csv $OUT/ 
 python tools/bench_attention.py --quick > $OUT/bench_attention.txt 2>&1
 python tools/bench_sweeps.py 2048 5000:16 5000:1 > $OUT/bench_sweeps.txt 2>&1
 python tools/bench_score_gemm.py 5000 > $OUT/bench_score_gemm.txt 2>&1
-for f in gpu_tests.txt gpu_tests_bf16x3_both_switches.txt smoke.txt scale_selfcheck_n1.txt; do echo "== $f"; tail -3 $OUT/$f; done
+for f in gpu_tests.txt gpu_tests_bf16x3_both_switches.txt gpu_tests_f16x2_both_switches.txt smoke.txt scale_selfcheck_n1.txt; do echo "== $f"; tail -3 $OUT/$f; done
 for f in bench_default bench_scene_config4_cap5000 bench_scene_config4_cap5000_rccl_one_rank; do echo "== $f"; grep "^{" $OUT/$f.log | cut -c1-300; done
 grep real $OUT/bench_default.log; grep "^{" $OUT/bench_default.log | wc -c
 grep -h "keypoints\|matcher kernels" $OUT/plugin_resident.txt | cut -c1-250

@@ -127,6 +127,11 @@ if x3:
     traffic[f"attention_x3_kernel@{nseq}x4x{n}"] = {"launch_shape": f"{nseq} sequences x 4 heads, N = {n} (attention_x3_kernel, fused schedule)", "fetch_bytes": x3[0], "write_bytes": x3[1]}
 if x3s:
     traffic[f"attention_x3_split_kernel@{nseq}x4x{n}"] = {"launch_shape": f"K and V of {nseq} sequences x 4 heads, N = {n} -> three bf16 pieces each", "fetch_bytes": x3s[0], "write_bytes": x3s[1]}
+h2, h2s = per_launch("attention_f16x2_5000_16", "attention_x3_kernel"), per_launch("attention_f16x2_5000_16", "attention_x3_split_kernel")
+if h2:
+    traffic[f"attention_x3_kernel@{nseq}x4x{n}@f16x2"] = {"launch_shape": f"{nseq} sequences x 4 heads, N = {n} (attention_x3_kernel<.., 2>, fused schedule)", "fetch_bytes": h2[0], "write_bytes": h2[1]}
+if h2s:
+    traffic[f"attention_x3_split_kernel@{nseq}x4x{n}@f16x2"] = {"launch_shape": f"K and V of {nseq} sequences x 4 heads, N = {n} -> two fp16 pieces each", "fetch_bytes": h2s[0], "write_bytes": h2s[1]}
 json.dump(traffic, open(out + f"/{ROUND}_pmc_traffic.json", "w"), indent=1)
 for k, v in traffic.items():
     if isinstance(v, dict):

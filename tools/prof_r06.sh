@@ -15,13 +15,13 @@ if [ "${PROF_TRACE:-1}" = "1" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lg -o lg -- $B > $OUT/lg.log 2>&1
   find $OUT -name "*kernel_trace.csv" -delete
 fi
-for W in "all" "gemm 163840 256 512" "attention_x3 5000 16"; do
+for W in "all" "gemm 163840 256 512" "attention_x3 5000 16" "attention_f16x2 5000 16"; do
   TAG=$(echo $W | tr ' ' '_')
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$C -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_kernels.py $W > $OUT/pmc_${TAG}_$C.log 2>&1
   done
 done
-for W in "lg_assign 5000 16" "attention 5000 16"; do
+for W in "lg_assign 5000 16" "attention 5000 16" "attention_f16x2 5000 16"; do
   TAG=$(echo $W | tr ' ' '_')
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE \
     --kernel-trace --output-format csv -d $OUT/sq_$TAG -o sq -- python $GRAFT_REPO_ROOT/tools/pmc_kernels.py $W > $OUT/sq_$TAG.log 2>&1
