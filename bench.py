@@ -116,9 +116,25 @@ def pmc_traffic(kernel: str):
 # ------------------------------------------------------------------------------------------------------------------
 
 
+ROOFLINE_WARM_S = 0.25   # a roofline leg starts on a chip that has idled (host-side legs ran before it): launches for this long before the timed ones,
+ROOFLINE_TIMED_S = 0.15  # and at least this much timed work, so that the figure is the kernel at the clocks the workload holds, not the DVFS ramp
+
+
 def _time_launches(fn, stream, reps: int) -> float:
+    """Average launch duration by HIP events on the launch stream. Round 6: five launches right after an idle phase measured the clock ramp on some
+    boxes (the attention launch 6.65 ms in the bench line against 6.25 ms in the kernel trace of the same run and in tools/bench_attention.py on the
+    same box): the timed launches now follow ROOFLINE_WARM_S of the same launches and cover at least ROOFLINE_TIMED_S."""
+    import time
+
     fn()
     torch.cuda.synchronize()
+    t0, warm = time.perf_counter(), 1
+    while time.perf_counter() - t0 < ROOFLINE_WARM_S:
+        fn()
+        torch.cuda.synchronize()
+        warm += 1
+    per = (time.perf_counter() - t0) / max(1, warm - 1)
+    reps = max(reps, min(2000, int(ROOFLINE_TIMED_S / max(per, 1e-6)) + 1))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(reps):
