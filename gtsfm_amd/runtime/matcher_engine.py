@@ -160,12 +160,17 @@ def _full_digest(arrays: Sequence[np.ndarray]) -> bytes:
     return h.digest()
 
 
+def split_arithmetic_has_fp16_range() -> bool:
+    """True under the opt-in f16x2 switches (read from the environment like the library reads them, per call)."""
+    import os
+
+    return any((os.environ.get(k) or "")[:2] == "f1" for k in ("GTSFM_ATTENTION_MATH", "GTSFM_GEMM_MATH"))
+
+
 def check_split_arithmetic_range(mscores: np.ndarray) -> None:
     """The opt-in f16x2 arithmetic (GTSFM_ATTENTION_MATH / GTSFM_GEMM_MATH = f16x2; gtsfm_amd/csrc/f16x2.h) carries every operand in two fp16 pieces:
     a value beyond +-65504 becomes inf in its leading piece and NaN in every score it reaches. That must not pass for "no matches": raise."""
-    import os
-
-    if any((os.environ.get(k) or "")[:2] == "f1" for k in ("GTSFM_ATTENTION_MATH", "GTSFM_GEMM_MATH")) and np.isnan(mscores).any():
+    if split_arithmetic_has_fp16_range() and np.isnan(np.asarray(mscores)).any():
         raise FloatingPointError("f16x2 arithmetic: an operand of the matcher left fp16's range (|x| > 65504) and the scores are NaN; "
                                  "run this input with GTSFM_ATTENTION_MATH / GTSFM_GEMM_MATH unset (exact fp32) or =bf16x3")
 

@@ -343,12 +343,12 @@ class FrontEndPipeline:
     def matches_to_numpy(results: List[Dict[str, torch.Tensor]], dtype=np.int64) -> Dict[Tuple[int, int], np.ndarray]:
         """(K,2) index arrays per pair, image-i1 keypoint order (the plugins' output format)."""
         out: Dict[Tuple[int, int], np.ndarray] = {}
-        from gtsfm_amd.runtime.matcher_engine import check_split_arithmetic_range
+        from gtsfm_amd.runtime.matcher_engine import check_split_arithmetic_range, split_arithmetic_has_fp16_range
 
         for res in results:
             m = res["matches"].cpu().numpy()
-            if "mscores" in res:
-                check_split_arithmetic_range(res["mscores"].cpu().numpy())  # (only looks under the opt-in f16x2 switches)
+            if "mscores" in res and split_arithmetic_has_fp16_range():  # (the scores travel to the host only under the opt-in f16x2 switches)
+                check_split_arithmetic_range(res["mscores"].cpu().numpy())
             row = 0
             for (i, j), a, b in zip(res["pairs"], res["n0"], res["n1"]):
                 m0 = m[row : row + a]

@@ -81,3 +81,29 @@ def test_out_of_range_operands_fail_loudly():
     hi, lo, _ = split2(np.array([70000.0, -1e6, 65520.0], dtype=np.float32))
     assert np.all(np.isinf(hi.astype(np.float32)))
     assert np.all(np.isnan(lo.astype(np.float32)) | np.isinf(lo.astype(np.float32)))
+
+
+def test_the_engines_raise_on_nan_scores_only_under_the_f16x2_switches(monkeypatch):
+    """``check_split_arithmetic_range``: NaN scores are an error under GTSFM_ATTENTION_MATH / GTSFM_GEMM_MATH = f16x2 (an operand left fp16's range) and are
+    passed through in exact fp32 ("f32" starts with an f as well) and under bf16x3 (fp32's range: NaN there means NaN inputs)."""
+    import pytest
+
+    from gtsfm_amd.runtime.matcher_engine import check_split_arithmetic_range, split_arithmetic_has_fp16_range
+
+    scores = np.array([0.5, np.nan, 0.0], dtype=np.float32)
+    for k in ("GTSFM_ATTENTION_MATH", "GTSFM_GEMM_MATH"):
+        monkeypatch.delenv(k, raising=False)
+    assert not split_arithmetic_has_fp16_range()
+    check_split_arithmetic_range(scores)
+    for value in ("f32", "bf16x3", ""):
+        monkeypatch.setenv("GTSFM_GEMM_MATH", value)
+        assert not split_arithmetic_has_fp16_range()
+        check_split_arithmetic_range(scores)
+    for key in ("GTSFM_ATTENTION_MATH", "GTSFM_GEMM_MATH"):
+        monkeypatch.setenv("GTSFM_GEMM_MATH", "f32")
+        monkeypatch.setenv("GTSFM_ATTENTION_MATH", "f32")
+        monkeypatch.setenv(key, "f16x2")
+        assert split_arithmetic_has_fp16_range()
+        check_split_arithmetic_range(np.zeros(4, dtype=np.float32))
+        with pytest.raises(FloatingPointError, match="fp16's range"):
+            check_split_arithmetic_range(scores)
