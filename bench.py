@@ -564,6 +564,9 @@ def parse_args(argv=None):
     ap.add_argument("--share-first-layer", type=int, default=1,
                     help="1: the matcher block that sees one image (SuperGlue: keypoint encoder + first self layer; LightGlue: first self block) "
                          "runs once per image per step when the pair list reuses images; 0: once per pair side, as the per-pair plugin API does")
+    ap.add_argument("--arithmetic", choices=["f32", "bf16x3", "f16x2"], default="f32",
+                    help="f32 (default): the headline, exact fp32 everywhere. bf16x3 / f16x2: the WHOLE run under both opt-in switches (GTSFM_ATTENTION_MATH and "
+                         "GTSFM_GEMM_MATH; DESIGN.md section 4) -- a side measurement of the same step protocol, labelled in `dtype` and `config.arithmetic`, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rates")
     ap.add_argument("--no-roofline", action="store_true",
@@ -727,6 +730,9 @@ def emit(result: dict, details_file: str) -> str:
 
 def main() -> None:
     args = parse_args()
+    if args.arithmetic != "f32":  # before anything launches (and inherited by the ranks of a re-launch): the C side reads the switches per call
+        os.environ["GTSFM_ATTENTION_MATH"] = os.environ["GTSFM_GEMM_MATH"] = args.arithmetic
+        args.no_secondary = True  # (the secondary legs are statements about the default arithmetic and switch the environment themselves)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(relaunch_one_process_per_gpu(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -912,10 +918,12 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "strong" if scene else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.arithmetic == "f32" else (f"f32 via {'3 x bf16' if args.arithmetic == 'bf16x3' else '2 x fp16'} split of the matchers' attention products and GEMMs, "
+                                                              "f32 accumulate (opt-in; SuperPoint, sweeps: exact f32)"),
             "data": "synthetic",
             "config": {
                 "workload": workload,
+                "arithmetic": args.arithmetic,
                 "mode": args.mode,
                 "pair_definition": args.pair_definition if not detect_only else None,
                 "images_per_gpu_per_step": len(my_images) if scene else n,
@@ -977,7 +985,7 @@ def main() -> None:
                 if detect_only:
                     result["roofline"] = conv_roof
                 else:  # dominant kernel of this workload first; the other kernels alongside
-                    result["roofline"] = measure_attention_roofline(lib, device, args.keypoints, chunk_pairs)
+                    result["roofline"] = measure_attention_roofline(lib, device, args.keypoints, chunk_pairs, math={"f32": 0, "bf16x3": 1, "f16x2": 2}[args.arithmetic])
                     rows = 2 * chunk_pairs * (-(-args.keypoints // 128) * 128)  # LightGlue aligns every keypoint set to 128 rows
                     def guarded(fn, *fargs):  # a secondary kernel's micro-measurement must not cost the line its headline
                         try:
