@@ -1030,7 +1030,6 @@ def main() -> None:
                 sec = leg("secondary_rates", secondary_rates, args, detector, matcher, device, h, w, mk, not args.no_cpu_baseline)
                 result["secondary"] = sec if "error" not in sec else {"rates": sec}
                 if args.matcher == "lightglue" and args.keypoints > 1024:
-                    result["secondary"]["attention_bf16x3"] = leg("bf16x3", attention_bf16x3_rate, args, lib, detector, matcher, images, pairs, shapes, device, ora)
                     result["secondary"]["matcher_bf16x3"] = leg("matcher_bf16x3", attention_bf16x3_rate, args, lib, detector, matcher, images, pairs, shapes, device, ora, True)
                     result["secondary"]["attention_f16x2"] = leg("f16x2", attention_bf16x3_rate, args, lib, detector, matcher, images, pairs, shapes, device, ora, False, "f16x2")
                     result["secondary"]["matcher_f16x2"] = leg("matcher_f16x2", attention_bf16x3_rate, args, lib, detector, matcher, images, pairs, shapes, device, ora, True, "f16x2")
@@ -1047,8 +1046,6 @@ def main() -> None:
                 result["secondary"]["config2_superpoint_480x640"] = leg("config2", config2_superpoint_rate, lib, detector, device, not args.no_cpu_baseline)
                 if args.keypoints > 2500 and (h, w) == (1024, 1024):
                     result["secondary"]["config4_scene_share_cap5000"] = leg("config4", config4_scene_share_rate, args, detector, device, h, w, not args.no_cpu_baseline)
-                    result["secondary"]["config4_scene_share_cap5000_bf16x3"] = leg("config4_bf16x3", config4_scene_share_rate, args, detector, device, h, w,
-                                                                                            not args.no_cpu_baseline, "bf16x3")
                     result["secondary"]["config4_scene_share_cap5000_f16x2"] = leg("config4_f16x2", config4_scene_share_rate, args, detector, device, h, w,
                                                                                            not args.no_cpu_baseline, "f16x2")
         print(emit(result, args.details_file), flush=True)
