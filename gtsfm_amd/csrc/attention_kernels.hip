@@ -703,8 +703,8 @@ __global__ __launch_bounds__(256) void attention_x3_split_kernel(AttnParams p) {
 }
 
 // The attention kernel on the split tiles: same problem / segment / schedule structure as attention_dma_kernel (128 queries of one
-// head per workgroup of 4 waves, a wave owns 32 queries, 64-key tiles, 1024-key segments merged by at_merge, fused or split
-// schedule), ONE transposed score tile per wave. Per tile and wave: 48 + 48 v_mfma_f32_32x32x16_bf16. The fused schedule keeps its
+// head per workgroup of 4 waves, a wave owns 32 queries, 64-key tiles, key segments of at_seg_tiles(nq, nk) tiles merged by at_merge, fused or split
+// schedule), ONE transposed score tile per wave. Per tile and wave: 48 + 48 v_mfma_f32_32x32x16_bf16 (NP = 3) or 24 + 24 v_mfma_f32_32x32x16_f16 (NP = 2). The fused schedule keeps its
 // merged state in registers (round 6; rounds 4 - 5 parked it in the caller's workspace: 48 KiB of LDS tiles + a 34 KiB LDS slab would
 // leave one workgroup per CU).
 // Measured on MI355X, round 4 (tools/bench_attention.py, 32 sequences x 4 heads at N = 5000; exact fp32: 6.17 - 6.22 ms): 3.99 - 4.02 ms
