@@ -1184,6 +1184,55 @@ def test_attention_bf16x3_arithmetic(lib, gpu_device, math):
     print(f"attention max |error| against float64: exact fp32 {worst['exact']:.3e}, {'bf16x3' if math == 1 else 'f16x2'} {worst['x3']:.3e}")
 
 
+@pytest.mark.parametrize("v_scale,q_scale", [(1.0e4, 1.0), (1.0e-5, 1.0), (1.0, 6.0), (3.0e4, 1.0)], ids=["values_near_fp16_max", "values_below_fp16_normal", "peaked_softmax", "values_beyond_fp16_max"])
+def test_attention_f16x2_at_the_edges_of_its_range(lib, gpu_device, v_scale, q_scale):
+    """The documented domain of the f16x2 arithmetic (gtsfm_amd/csrc/f16x2.h) at kernel level, against float64: (1) values up to 4.5e4 (fp16's largest
+    number is 65504): relative accuracy of the exact kernel's class; (2) values of 1e-5, whose fp16 pieces are subnormal: the ABSOLUTE floor -- 2^-25 per
+    operand, so |error| <= 1e-7 -- instead of a relative bound (documented: the mode carries fp32-class RELATIVE accuracy for |x| >= 2^-3 only);
+    (3) scores of +-60 (a one-hot softmax: the weights span the whole range the kernel's shifted reference has to cover); (4) values beyond 65504: the leading
+    piece is inf and the affected outputs are NaN -- never a clamped number."""
+    n, cap = 700, 768
+    gen = torch.Generator().manual_seed(11)
+    qkv = torch.randn((2 * cap, 768), generator=gen)
+    qkv[:, :256] *= q_scale
+    qkv[:, 512:] *= v_scale
+    d = qkv.to(gpu_device)
+    cnt = torch.tensor([n, n], dtype=torch.int32, device=gpu_device)
+    prob = torch.tensor([[0, 0, cap, 1], [cap, 1, 0, 0]], dtype=torch.int32, device=gpu_device)
+    ws = torch.empty(int(lib.gtsfm_attention_math_workspace_bytes(2, n, n, 4, 2 * cap, 2)), dtype=torch.uint8, device=gpu_device)
+
+    def run(math):
+        out = torch.zeros((2 * cap, 256), device=gpu_device)
+        rc = lib.gtsfm_attention_math_f32(d.data_ptr(), 768, d.data_ptr() + 256 * 4, 768, d.data_ptr() + 512 * 4, 768, out.data_ptr(), 256, prob.data_ptr(), cnt.data_ptr(), 2, n, n, 4,
+                                          0.125, 0, math, 2 * cap, ws.data_ptr(), ws.numel(), _stream())
+        assert rc == 0, lib.gtsfm_last_error()
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    exact, split = run(0), run(2)
+    q64 = qkv.double()
+    worst_exact = worst_split = scale = 0.0
+    for a, b in ((0, 1), (1, 0)):
+        rows = slice(a * cap, a * cap + n)
+        ref = _ref_attention(q64[rows, :256], q64[b * cap : b * cap + n, 256:512], q64[b * cap : b * cap + n, 512:], 0.125)
+        if v_scale > 2.0e4:  # some |v| exceed 65504: their channels' outputs are NaN, everything else is finite -- and nothing is silently clamped
+            bad = torch.isnan(split[rows])
+            assert bad.any() and not torch.isinf(split[rows]).any()
+            over = (q64[b * cap : b * cap + n, 512:].abs() > 65504).any(0)  # channels holding a value beyond fp16's range
+            assert bool(over.any()) and not bad[:, ~over].any() and torch.isfinite(exact[rows]).all()
+            continue
+        worst_exact = max(worst_exact, float((exact[rows].double() - ref).abs().max()))
+        worst_split = max(worst_split, float((split[rows].double() - ref).abs().max()))
+        scale = max(scale, float(ref.abs().max()))
+    if v_scale > 2.0e4:
+        return
+    print(f"f16x2 at the edge (v x {v_scale:g}, q x {q_scale:g}): max |error| against float64 {worst_split:.3e} (exact fp32 kernel {worst_exact:.3e}), outputs up to {scale:.3e}")
+    if v_scale < 1e-3:
+        assert worst_split <= 1e-7, worst_split                      # the absolute floor: 2^-25 per operand piece
+    else:
+        assert worst_split <= 2.0 * worst_exact + 2e-6 * scale, (worst_split, worst_exact)
+
+
 @pytest.mark.parametrize("matcher", ["superglue", "lightglue"])
 def test_single_pair_schedules_are_bit_identical_to_the_batch_schedules(gpu_device, monkeypatch, matcher):
     """One pair on its own takes the schedules that fill the chip -- 64 x 64 GEMM tiles, attention split over key segments -- while a
