@@ -193,3 +193,18 @@ def test_recorded_bench_line_is_hygienic():
     assert line["executed_tflops"] < line["algorithmic_tflops"] < 157.3
     kernels = " ".join(str(r.get("kernel")) for r in line["roofline_other"])
     assert "extract_rows" in kernels and "layernorm_gelu_kernel" in kernels  # the kernel furthest below its roof is in the line
+
+
+def test_the_arithmetic_flag_labels_the_line_and_sets_both_switches():
+    """``--arithmetic f16x2`` (round 6): a side measurement of the headline's protocol under both opt-in switches -- the line says so in `dtype` and
+    `config.arithmetic`, the secondary legs (statements about the default arithmetic) are off, and the default run stays `f32`."""
+    p, lines = _run_bench("--plumbing-only", "--images", "5", "--pairs", "8", "--steps", "1", "--warmup", "0", "--arithmetic", "f16x2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    head = json.loads(lines[-1])
+    assert head["config"]["arithmetic"] == "f16x2" and "2 x fp16" in head["dtype"] and "opt-in" in head["dtype"] and "secondary_rates" not in head
+    p, lines = _run_bench("--plumbing-only", "--images", "5", "--pairs", "8", "--steps", "1", "--warmup", "0")
+    head = json.loads(lines[-1])
+    assert head["config"]["arithmetic"] == "f32" and head["dtype"] == "f32"
+    # the switches are exported before anything launches (the ranks of a self-launch inherit them)
+    src = (REPO / "bench.py").read_text()
+    assert src.index('os.environ["GTSFM_ATTENTION_MATH"] = os.environ["GTSFM_GEMM_MATH"] = args.arithmetic') < src.index("relaunch_one_process_per_gpu(args.gpus))")
