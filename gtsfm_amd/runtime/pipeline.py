@@ -10,6 +10,7 @@ pairs are matched from one resident feature table.
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -250,7 +251,8 @@ class FrontEndPipeline:
         return table
 
     def _replay_chunk(self, feats, chunk, k, hw0, matcher_kwargs, si, stream):
-        key = (si, len(chunk), k, tuple(hw0), tuple(sorted(matcher_kwargs.items())))
+        # (the arithmetic switches are read by the C side when a graph is CAPTURED: a graph is only replayed under the values it was captured with)
+        key = (si, len(chunk), k, tuple(hw0), tuple(sorted(matcher_kwargs.items())), os.environ.get("GTSFM_ATTENTION_MATH"), os.environ.get("GTSFM_GEMM_MATH"))
         idx = torch.tensor([i for p in chunk for i in p], dtype=torch.int32, device=feats["xy"].device)
         g = self._graphs.get(key)
         if g is None:

@@ -206,3 +206,43 @@ def test_f16x2_fails_loudly_beyond_fp16_range(gpu_device, monkeypatch):
         eng.match_pair(k0, big0, k1, big1, (480, 640), (480, 640))
     ok = eng.match_pair(k0, d0, k1, d1, (480, 640), (480, 640))  # the engine is fine afterwards
     assert not np.isnan(ok["matching_scores0"]).any()
+
+
+def test_captured_graphs_follow_the_switches(gpu_device, monkeypatch):
+    """``FrontEndPipeline(use_graphs=True)`` replays a captured launch sequence per chunk shape; the C side reads the arithmetic switches when the sequence
+    is CAPTURED. The graph cache is keyed by the switches (round 6), so one pipeline object serves exact fp32 -> f16x2 -> exact fp32 calls with the
+    arithmetic each call asked for: the first and the third result are bit-identical, the second differs from them within the tolerance."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+    from gtsfm_amd.runtime.pipeline import FrontEndPipeline
+    from gtsfm_amd.runtime.superpoint_engine import SuperPointEngine
+
+    for k in ("GTSFM_ATTENTION_MATH", "GTSFM_GEMM_MATH"):
+        monkeypatch.delenv(k, raising=False)
+    det = SuperPointEngine(synthetic.synthetic_superpoint_state_dict(), gpu_device)
+    eng = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(num_layers=3), gpu_device)
+    views = synthetic.synthetic_overlapping_views(4, 192, 256, seed=33)
+    pairs = [(0, 1), (1, 2), (2, 3), (0, 3)]
+    pipe = FrontEndPipeline(det, eng, max_keypoints=256, pair_chunk=2, num_streams=2, use_graphs=True, share_first_layer=False)
+    feats = pipe.detect(torch.from_numpy(views).to(gpu_device))
+    assert int(feats["count"].min()) == 256  # full chunks: the graph path
+
+    def run():
+        out = pipe.match(feats, pairs, [(192, 256)] * 4)
+        torch.cuda.synchronize()
+        return [(r["matches"].clone(), r["mscores"].clone()) for r in out]
+
+    exact = run()
+    graphs_exact = len(pipe._graphs)
+    assert graphs_exact > 0
+    monkeypatch.setenv("GTSFM_ATTENTION_MATH", "f16x2")
+    monkeypatch.setenv("GTSFM_GEMM_MATH", "f16x2")
+    split = run()
+    assert len(pipe._graphs) == 2 * graphs_exact  # its own captures
+    monkeypatch.delenv("GTSFM_ATTENTION_MATH")
+    monkeypatch.delenv("GTSFM_GEMM_MATH")
+    again = run()
+    assert len(pipe._graphs) == 2 * graphs_exact
+    assert sum(int((m > -1).sum()) for m, _ in exact) > 0
+    for (m0, s0), (m1, s1), (m2, s2) in zip(exact, split, again):
+        assert torch.equal(m0, m2) and torch.equal(s0, s2)
+        assert torch.equal(m0, m1) and not torch.equal(s0, s1) and float((s0 - s1).abs().max()) < 1e-4
