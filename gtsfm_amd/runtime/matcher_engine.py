@@ -300,7 +300,10 @@ class _MatcherBase:
             a = np.asarray(a)
             ident.append((a.__array_interface__["data"][0], a.shape, a.dtype.str, a.strides))
             h.update(np.ascontiguousarray(a[rows]).tobytes())
-        return (tuple(ident), (int(shape[0]), int(shape[1])), h.digest())
+        # (the cached entry holds the first block's OUTPUT: it belongs to the arithmetic it was computed under)
+        import os
+
+        return (tuple(ident), (int(shape[0]), int(shape[1])), h.digest(), os.environ.get("GTSFM_ATTENTION_MATH"), os.environ.get("GTSFM_GEMM_MATH"))
 
     def _image_entries(self, images: Sequence[Tuple[Sequence[np.ndarray], Tuple[int, int]]]) -> List[_ImageEntry]:
         """Device-resident inputs of the images of one ``match_pair`` call, on the CURRENT lane (self) and stream. The reference's

@@ -246,3 +246,32 @@ def test_captured_graphs_follow_the_switches(gpu_device, monkeypatch):
     for (m0, s0), (m1, s1), (m2, s2) in zip(exact, split, again):
         assert torch.equal(m0, m2) and torch.equal(s0, s2)
         assert torch.equal(m0, m1) and not torch.equal(s0, s1) and float((s0 - s1).abs().max()) < 1e-4
+
+
+def test_the_image_cache_follows_the_switches(gpu_device, monkeypatch):
+    """The per-call path keeps an image's uploaded keypoints and the OUTPUT of the matcher's per-image first block on the device. That output belongs to the
+    arithmetic it was computed under: the cache key carries the two switches (round 6), so the same host arrays matched exact -> f16x2 -> exact give the exact
+    bits again in the third call and the f16x2 bits (not a mixture) in the second."""
+    from gtsfm_amd.runtime import matcher_engine as ME
+
+    for k in ("GTSFM_ATTENTION_MATH", "GTSFM_GEMM_MATH", "GTSFM_PLUGIN_IMAGE_CACHE"):
+        monkeypatch.delenv(k, raising=False)
+    k0, s0, d0, k1, s1, d1, _ = synthetic.synthetic_pair_features(900, 800, (480, 640), (480, 640), seed=21)
+    eng = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(num_layers=3), gpu_device)
+    assert eng.image_cache_capacity > 0
+    run = lambda: eng.match_pair(k0, d0, k1, d1, (480, 640), (480, 640))  # noqa: E731
+    exact = run()
+    monkeypatch.setenv("GTSFM_ATTENTION_MATH", "f16x2")
+    monkeypatch.setenv("GTSFM_GEMM_MATH", "f16x2")
+    split = run()
+    fresh = ME.LightGlueEngine(synthetic.synthetic_lightglue_state_dict(num_layers=3), gpu_device)  # nothing cached: the mode's own bits
+    fresh.image_cache_capacity = 0
+    split_ref = fresh.match_pair(k0, d0, k1, d1, (480, 640), (480, 640))
+    monkeypatch.delenv("GTSFM_ATTENTION_MATH")
+    monkeypatch.delenv("GTSFM_GEMM_MATH")
+    again = run()
+    assert (exact["matches0"] > -1).sum() > 50
+    np.testing.assert_array_equal(exact["matching_scores0"], again["matching_scores0"])
+    np.testing.assert_array_equal(split["matching_scores0"], split_ref["matching_scores0"])
+    assert not np.array_equal(exact["matching_scores0"], split["matching_scores0"])
+    np.testing.assert_array_equal(exact["matches0"], split["matches0"])
